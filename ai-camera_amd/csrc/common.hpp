@@ -1,0 +1,140 @@
+// common.hpp -- error handling, device context, buffers and event profiling for libaicam.so.
+// MI355X / gfx950 only; no CPU fallback anywhere in this library.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/aicam.h"
+
+namespace aic {
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+void set_last_error(const std::string& m);
+
+#define AIC_REQUIRE(cond, code, msg)                                              \
+    do {                                                                          \
+        if (!(cond)) throw ::aic::Error((code), std::string(msg));                \
+    } while (0)
+
+#define HIP_CHECK(expr)                                                                        \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess)                                                                  \
+            throw ::aic::Error(AIC_ERR_RUNTIME, std::string(#expr) + ": " + hipGetErrorString(_e) + \
+                                                    " (" __FILE__ ":" + std::to_string(__LINE__) + ")"); \
+    } while (0)
+
+// Wraps the body of every extern "C" entry point.
+template <class F>
+static inline int guarded(F&& f) {
+    try {
+        f();
+        return AIC_OK;
+    } catch (const Error& e) {
+        set_last_error(e.what());
+        return e.code;
+    } catch (const std::exception& e) {
+        set_last_error(e.what());
+        return AIC_ERR_RUNTIME;
+    }
+}
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    explicit DevBuf(size_t count) { alloc(count); }
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    DevBuf& operator=(DevBuf&& o) noexcept {
+        if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; }
+        return *this;
+    }
+    ~DevBuf() { release(); }
+    void alloc(size_t count) {
+        release();
+        n = count;
+        if (count) HIP_CHECK(hipMalloc((void**)&p, count * sizeof(T)));
+    }
+    void ensure(size_t count) { if (count > n) alloc(count); }
+    void release() { if (p) { (void)hipFree(p); p = nullptr; } n = 0; }
+    size_t bytes() const { return n * sizeof(T); }
+};
+
+template <class T>
+struct PinBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    PinBuf() = default;
+    PinBuf(const PinBuf&) = delete;
+    PinBuf& operator=(const PinBuf&) = delete;
+    ~PinBuf() { release(); }
+    void alloc(size_t count) {
+        release();
+        n = count;
+        if (count) HIP_CHECK(hipHostMalloc((void**)&p, count * sizeof(T), hipHostMallocDefault));
+    }
+    void ensure(size_t count) { if (count > n) alloc(count); }
+    void release() { if (p) { (void)hipHostFree(p); p = nullptr; } n = 0; }
+};
+
+enum ProfClass { PROF_CONV = 0, PROF_CONV_DIRECT = 1, PROF_MISC = 2, PROF_LETTERBOX = 3, PROF_CROP = 4,
+                 PROF_DET = 5, PROF_TRK = 6 };
+
+// One per visible GPU, created on first use. Owns the streams every handle on that GPU uses.
+struct Device {
+    int id = 0;
+    hipStream_t s_main = nullptr;  // detection + ReID launch groups
+    hipStream_t s_trk = nullptr;   // per-frame association chain
+    int n_cu = 256;
+    bool prof_on = false;
+    struct Pair { hipEvent_t a, b; };
+    std::vector<Pair> pending[AIC_PROF_CLASSES];
+    std::vector<Pair> pool;
+    double ms[AIC_PROF_CLASSES] = {0};
+    int64_t launches[AIC_PROF_CLASSES] = {0};
+    double flops[AIC_PROF_CLASSES] = {0};
+    double bytes[AIC_PROF_CLASSES] = {0};
+
+    void use() const { HIP_CHECK(hipSetDevice(id)); }
+    void prof_begin(int cls, hipStream_t s, double fl, double by);
+    void prof_end(int cls, hipStream_t s);
+    void prof_collect();
+    void prof_reset();
+};
+
+Device& device(int id);
+int device_count();
+
+// RAII bracket around one kernel launch of a profiled class.
+struct Prof {
+    Device& d;
+    int cls;
+    hipStream_t s;
+    Prof(Device& dev, int c, hipStream_t st, double fl = 0, double by = 0) : d(dev), cls(c), s(st) {
+        if (d.prof_on) d.prof_begin(cls, s, fl, by);
+    }
+    ~Prof() {
+        if (d.prof_on) d.prof_end(cls, s);
+    }
+};
+
+static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+
+#define KCHECK() HIP_CHECK(hipGetLastError())
+
+}  // namespace aic

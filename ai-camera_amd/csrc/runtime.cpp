@@ -1,0 +1,127 @@
+// runtime.cpp -- device contexts, error state, HIP-event profiling, library-level C ABI.
+#include "common.hpp"
+
+namespace aic {
+
+static thread_local std::string g_last_error;
+void set_last_error(const std::string& m) { g_last_error = m; }
+
+int device_count() {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return 0;
+    return n;
+}
+
+static std::mutex g_dev_mu;
+static std::vector<std::unique_ptr<Device>> g_devs;
+
+Device& device(int id) {
+    std::lock_guard<std::mutex> lk(g_dev_mu);
+    int n = device_count();
+    AIC_REQUIRE(n > 0, AIC_ERR_NO_DEVICE,
+                "no HIP device visible: libaicam.so has no CPU path (gfx950 / MI355X required)");
+    AIC_REQUIRE(id >= 0 && id < n, AIC_ERR_INVALID, "device id out of range");
+    if ((int)g_devs.size() < n) g_devs.resize(n);
+    if (!g_devs[id]) {
+        auto d = std::make_unique<Device>();
+        d->id = id;
+        HIP_CHECK(hipSetDevice(id));
+        hipDeviceProp_t prop;
+        HIP_CHECK(hipGetDeviceProperties(&prop, id));
+        AIC_REQUIRE(std::strncmp(prop.gcnArchName, "gfx950", 6) == 0, AIC_ERR_NO_DEVICE,
+                    std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
+        d->n_cu = prop.multiProcessorCount;
+        HIP_CHECK(hipStreamCreateWithFlags(&d->s_main, hipStreamNonBlocking));
+        HIP_CHECK(hipStreamCreateWithFlags(&d->s_trk, hipStreamNonBlocking));
+        g_devs[id] = std::move(d);
+    }
+    HIP_CHECK(hipSetDevice(id));
+    return *g_devs[id];
+}
+
+void Device::prof_begin(int cls, hipStream_t s, double fl, double by) {
+    Pair p;
+    if (!pool.empty()) {
+        p = pool.back();
+        pool.pop_back();
+    } else {
+        if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return;
+    }
+    (void)hipEventRecord(p.a, s);
+    pending[cls].push_back(p);
+    launches[cls] += 1;
+    flops[cls] += fl;
+    bytes[cls] += by;
+}
+
+void Device::prof_end(int cls, hipStream_t s) {
+    if (pending[cls].empty()) return;
+    (void)hipEventRecord(pending[cls].back().b, s);
+}
+
+void Device::prof_collect() {
+    (void)hipDeviceSynchronize();
+    for (int c = 0; c < AIC_PROF_CLASSES; ++c) {
+        for (auto& p : pending[c]) {
+            float t = 0.f;
+            if (hipEventElapsedTime(&t, p.a, p.b) == hipSuccess) ms[c] += t;
+            pool.push_back(p);
+        }
+        pending[c].clear();
+    }
+}
+
+void Device::prof_reset() {
+    prof_collect();
+    for (int c = 0; c < AIC_PROF_CLASSES; ++c) ms[c] = 0, launches[c] = 0, flops[c] = 0, bytes[c] = 0;
+}
+
+}  // namespace aic
+
+using namespace aic;
+
+extern "C" {
+
+const char* aic_last_error(void) { return g_last_error.c_str(); }
+int aic_abi_version(void) { return AIC_ABI_VERSION; }
+
+int aic_device_count(int* count) {
+    return guarded([&] {
+        AIC_REQUIRE(count, AIC_ERR_INVALID, "count is NULL");
+        *count = device_count();
+    });
+}
+
+int aic_device_sync(int dev) {
+    return guarded([&] {
+        device(dev);
+        HIP_CHECK(hipDeviceSynchronize());
+    });
+}
+
+int aic_prof_enable(int dev, int on) {
+    return guarded([&] {
+        Device& d = device(dev);
+        if (!on && d.prof_on) d.prof_collect();
+        d.prof_on = on != 0;
+    });
+}
+
+int aic_prof_reset(int dev) {
+    return guarded([&] { device(dev).prof_reset(); });
+}
+
+int aic_prof_read(int dev, int cls, double* ms, int64_t* launches, double* flops, double* bytes) {
+    return guarded([&] {
+        AIC_REQUIRE(cls >= 0 && cls < AIC_PROF_CLASSES, AIC_ERR_INVALID, "profile class out of range");
+        Device& d = device(dev);
+        d.prof_collect();
+        if (ms) *ms = d.ms[cls];
+        if (launches) *launches = d.launches[cls];
+        if (flops) *flops = d.flops[cls];
+        if (bytes) *bytes = d.bytes[cls];
+    });
+}
+
+}  // extern "C"

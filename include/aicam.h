@@ -1,0 +1,238 @@
+/*
+ * aicam.h -- C ABI of libaicam.so, the MI355X (gfx950) detect+track hot path.
+ *
+ * The reference (abdur75648/AI-Camera) is pure Python and has no FFI; its hot path sits
+ * behind Python plugin classes.  Each entry point below replaces the
+ * arithmetic of the reference call site named in its comment (paths relative to the
+ * reference repo) and is what the reference-side ctypes stub in INTEGRATION.md binds.
+ *
+ * Conventions
+ *   - every function returns 0 (AIC_OK) or a negative AIC_ERR_* code; aic_last_error()
+ *     returns the message of the last failure on the calling thread;
+ *   - plain pointers and sizes only; `mem` arguments say where a buffer lives
+ *     (AIC_HOST = host memory, AIC_DEVICE = HBM of the handle's device);
+ *   - outputs are caller-owned buffers with explicit capacities;
+ *   - one handle = one HIP stream; a handle is not thread-safe, distinct handles are
+ *     independent (one process per GPU, one pipeline per video stream);
+ *   - there is NO CPU fallback: without a gfx950 device every compute entry point
+ *     fails with AIC_ERR_NO_DEVICE.  Host-side integer logic (aic_lsap,
+ *     aic_min_cost_matching) is the only code that runs without a GPU, exactly as
+ *     the reference keeps it on the host.
+ */
+#ifndef AICAM_H
+#define AICAM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AIC_ABI_VERSION 1
+
+#define AIC_OK 0
+#define AIC_ERR_INVALID (-1)   /* bad argument            (reference: ValueError / TypeError)  */
+#define AIC_ERR_NOT_FOUND (-2) /* engine file missing     (reference: FileNotFoundError)        */
+#define AIC_ERR_RUNTIME (-3)   /* HIP call / kernel failed (reference: RuntimeError)            */
+#define AIC_ERR_NO_DEVICE (-4) /* no gfx950 device visible                                      */
+#define AIC_ERR_CAPACITY (-5)  /* output buffer / static capacity too small                     */
+#define AIC_ERR_FORMAT (-6)    /* malformed engine file                                         */
+
+#define AIC_HOST 0
+#define AIC_DEVICE 1
+
+#define AIC_F32 0 /* fp32 activations, v_mfma_f32_16x16x4_f32: the parity mode           */
+#define AIC_F16 1 /* fp16 activations / fp32 accumulate, v_mfma_f32_16x16x32_f16          */
+
+#define AIC_MODEL_YOLO 1
+#define AIC_MODEL_REID 2
+
+typedef struct aic_model aic_model;       /* one engine file resident on one GPU          */
+typedef struct aic_tracker aic_tracker;   /* DeepSORT core state of one video stream      */
+typedef struct aic_pipeline aic_pipeline; /* detector + ReID + tracker over resident frames */
+
+/* ------------------------------------------------------------------ library / device */
+const char* aic_last_error(void);
+int aic_abi_version(void);
+int aic_device_count(int* count);
+int aic_device_sync(int device);
+
+/* ------------------------------------------------------------------ engines
+ * Replaces TRTEngine (src/trt_utils/trt_engine.py:15-216): deserialise an engine file
+ * (here: graph IR + fp32 weights written by ai-camera_amd/engine_file.py), keep it
+ * resident, run it on a stream.  max_items = largest batch (frames for YOLO, crops for
+ * ReID) the activation arena is sized for. */
+int aic_model_load(const char* path, int device, int dtype, int max_items, aic_model** out);
+int aic_model_load_mem(const void* blob, size_t nbytes, int device, int dtype, int max_items,
+                       aic_model** out);
+int aic_model_destroy(aic_model* m);
+/* kind, input H/W, classes (YOLO) or feature dim (ReID), anchors per image, conv FLOPs per item */
+int aic_model_info(const aic_model* m, int* kind, int* in_h, int* in_w, int* out_dim,
+                   int* n_anchors, double* flops_per_item, int* n_convs);
+
+/* TRTEngine.infer for the YOLO engine (trt_engine.py:151-203 called at
+ * src/detector/yolo_detector.py:97): images fp32 NCHW RGB in [0,1] -> the four NMS-plugin
+ * tensors the detector reads (yolo_detector.py:44-54,108-112): num_dets[B],
+ * bboxes[B,max_det,4] (xyxy, letterbox space), scores[B,max_det], labels[B,max_det]. */
+int aic_yolo_infer(aic_model* m, const float* images_nchw, int batch, int mem, float conf_thresh,
+                   float iou_thresh, int max_det, int32_t* num_dets, float* bboxes, float* scores,
+                   int32_t* labels);
+/* Raw head of the same engine for parity tests: per anchor 4*reg_max DFL logits and nc class
+ * logits, anchors ordered level-major then row-major (8400 at 640x640). Host outputs. */
+int aic_yolo_head(aic_model* m, const float* images_nchw, int batch, int mem, float* dfl_logits,
+                  float* cls_logits);
+/* Decode of the same head (DFL expectation, ltrb->xyxy*stride, arg-max class): boxes[B,A,4],
+ * max class logit[B,A], label[B,A]. Host outputs. */
+int aic_yolo_decode(aic_model* m, const float* images_nchw, int batch, int mem, float* boxes,
+                    float* max_logit, int32_t* labels);
+
+/* TRTEngine.infer for the ReID engine (src/tracker/reid_model.py:111-126): crops fp32 NCHW,
+ * ImageNet-normalised -> embeddings[N, feature_dim] fp32. */
+int aic_reid_infer(aic_model* m, const float* crops_nchw, int n, int mem, float* embeddings,
+                   int out_mem);
+
+/* ------------------------------------------------------------------ pre / post processing
+ * letterbox + preprocess_yolo_input (src/utils/image_processing.py:7-70,73-102): u8 BGR HWC
+ * frame -> fp32 NCHW RGB /255, padded with 114; also returns r and (pad_w, pad_h). */
+int aic_letterbox(int device, const uint8_t* frame_bgr, int h, int w, int out_h, int out_w,
+                  float* out_nchw, float* ratio, float* pad_w, float* pad_h);
+/* _extract_image_crops + preprocess_reid_input (src/tracker/deepsort_tracker.py:143-159,
+ * image_processing.py:105-138): int-truncate + clamp boxes, bilinear resize to out_h x out_w,
+ * BGR->RGB, (x/255-mean)/std, NCHW. valid[i]=0 for empty crops (their tensor is zero). */
+int aic_crop_resize(int device, const uint8_t* frame_bgr, int h, int w, const float* boxes_xyxy,
+                    int n, int out_h, int out_w, float* out_nchw, int32_t* valid);
+
+/* YOLODetector.detect (src/detector/yolo_detector.py:68-149) for a batch of same-size frames:
+ * letterbox -> engine -> decode+NMS -> score filter -> scale_bboxes
+ * (image_processing.py:141-183). boxes are xyxy in original-frame pixels, clipped. */
+int aic_detect(aic_model* yolo, const uint8_t* frames_bgr, int batch, int h, int w, int mem,
+               float conf_thresh, float iou_thresh, int max_det, int32_t* num_dets, float* boxes_xyxy,
+               float* scores, int32_t* labels);
+
+/* crop -> ReID engine (deepsort_tracker.py:104-113 + reid_model.py:67-126) for one frame. */
+int aic_reid_embed(aic_model* reid, const uint8_t* frame_bgr, int h, int w, int mem,
+                   const float* boxes_xyxy, int n, float* embeddings, int32_t* valid);
+
+/* ------------------------------------------------------------------ Kalman filter (batched)
+ * KalmanFilter.initiate/predict/project/update/gating_distance
+ * (src/tracker/core/kalman_filter.py:55-83,85-120,122-151,153-204,206-249), n independent
+ * filters per launch. mean[n,8], cov[n,8,8], z[n,4] fp32 host arrays. */
+int aic_kf_initiate(int device, const float* z, int n, float* mean, float* cov);
+int aic_kf_predict(int device, float* mean, float* cov, int n);
+int aic_kf_project(int device, const float* mean, const float* cov, int n, float* pmean, float* pcov);
+int aic_kf_update(int device, float* mean, float* cov, const float* z, int n);
+/* d2[n,m]: squared Mahalanobis distance of filter i to measurement zs[i*m+j] (shared_z=0) or
+ * zs[j] (shared_z=1); +inf where S is not positive definite (kalman_filter.py:241-247). */
+int aic_kf_gating(int device, const float* mean, const float* cov, int n, const float* zs, int m,
+                  int shared_z, int only_position, float* d2);
+
+/* ------------------------------------------------------------------ association costs
+ * iou_cost (src/tracker/core/matching.py:13-106): 1-IoU[T,N] of tlwh boxes. */
+int aic_iou_cost(int device, const float* track_tlwh, int t, const float* det_tlwh, int n, float* cost);
+/* appearance_cost_metric + cosine_distance (matching.py:109-217): galleries[T,gmax,dim] with
+ * gallery_len[T] valid rows each, det_feat[N,dim], has_feat[N]; cost[T,N] = min over gallery of
+ * max(0, 1 - cos), INFTY_COST (1e5) where the gallery is empty or the detection has no feature. */
+int aic_appearance_cost(int device, const float* galleries, const int32_t* gallery_len, int t,
+                        int gmax, int dim, const float* det_feat, const uint8_t* has_feat, int n,
+                        float* cost);
+
+/* scipy.optimize.linear_sum_assignment as called at
+ * src/tracker/core/linear_assignment.py:62 (SciPy 1.15.3, rectangular shortest augmenting
+ * path, same tie-breaking). HOST code. row_ind/col_ind hold min(nr,nc) entries. */
+int aic_lsap(const double* cost, int nr, int nc, int64_t* row_ind, int64_t* col_ind);
+/* min_cost_matching on a precomputed fp32 cost block (linear_assignment.py:55-88): clamp
+ * cost>max to max+1e-5, LSAP, accept iff cost<=max. HOST code. Outputs index into rows/cols. */
+int aic_min_cost_matching(const float* cost, int nr, int nc, double max_distance, int32_t* match_row,
+                          int32_t* match_col, int32_t* n_match);
+
+/* ------------------------------------------------------------------ tracker
+ * TrackerCore (src/tracker/core/tracker_core.py:11-198) + Track lifecycle
+ * (src/tracker/core/track.py:16-171).  Kalman state and feature galleries live in HBM;
+ * lifecycle counters and the matching cascade run on the host. */
+typedef struct aic_tracker_params {
+    double max_cosine_distance; /* 0.2  src/config.py:23 (a Python float: kept in fp64)  */
+    double max_iou_distance;    /* 0.7  src/config.py:26 */
+    int32_t nn_budget;         /* 100  src/config.py:29; <=0 means unlimited up to capacity */
+    int32_t max_age;           /* 70   src/config.py:27 */
+    int32_t n_init;            /* 3    src/config.py:28 */
+    int32_t max_tracks;        /* slot capacity (0 -> 512) */
+    int32_t feature_dim;       /* 0 -> fixed by the first update */
+    int32_t first_track_id;    /* 1    src/tracker/core/track.py:21 (per tracker) */
+} aic_tracker_params;
+
+int aic_tracker_create(int device, const aic_tracker_params* p, aic_tracker** out);
+int aic_tracker_destroy(aic_tracker* t);
+/* TrackerCore.predict (tracker_core.py:44-49). */
+int aic_tracker_predict(aic_tracker* t);
+/* TrackerCore.update (tracker_core.py:51-81) on N detections: tlwh[N,4], conf[N], class id[N],
+ * feat[N,dim] (host or device), has_feat[N] (NULL = all). */
+int aic_tracker_update(aic_tracker* t, const float* det_tlwh, const float* conf, const int32_t* cls,
+                       const float* feat, int feat_mem, const uint8_t* has_feat, int n, int dim);
+/* Confirmed tracks updated this frame, formatted as deepsort_tracker.py:126-141:
+ * out[k] = {x1,y1,x2,y2 (round-half-even ints), track_id, class_id}, conf[k]. */
+int aic_tracker_outputs(aic_tracker* t, int32_t* out6, float* conf, int cap, int32_t* n_out);
+int aic_tracker_num_tracks(const aic_tracker* t, int32_t* n);
+/* Attribute surface of Track for callers/tests (track.py): per live track, in list order.
+ * Any pointer may be NULL. mean[T,8], cov[T,8,8] are fetched from HBM. */
+int aic_tracker_export(aic_tracker* t, int cap, int32_t* track_id, int32_t* state, int32_t* hits,
+                       int32_t* age, int32_t* time_since_update, int32_t* cls, float* conf,
+                       int32_t* gallery_len, float* mean, float* cov);
+/* Gallery of live track `index` in FIFO order (track.py:70-74): out[gallery_len, dim]. */
+int aic_tracker_export_gallery(aic_tracker* t, int index, float* out, int cap_rows);
+/* (track_id, detection index) pairs of the last update, and its full cost matrices [T,N]
+ * (appearance, squared Mahalanobis, 1-IoU), T = tracks alive before the update. */
+int aic_tracker_last_matches(aic_tracker* t, int32_t* track_id, int32_t* det, int cap, int32_t* n);
+int aic_tracker_last_costs(aic_tracker* t, float* app, float* maha, float* iou, int cap, int32_t* t_n,
+                           int32_t* d_n);
+
+/* ------------------------------------------------------------------ end-to-end pipeline
+ * The loop body of src/aicamera_tracker.py:169-207 (detect + track, the reference's own FPS
+ * span) over frames that are already resident in HBM, batched: detection and ReID of
+ * `batch` frames per launch group, association strictly frame by frame. */
+typedef struct aic_pipeline_params {
+    int32_t frame_h, frame_w;
+    int32_t batch;          /* frames per detection/ReID launch group                    */
+    int32_t ring_frames;    /* frames kept resident in HBM                                */
+    int32_t max_persons;    /* detections kept per frame for ReID/association             */
+    float conf_thresh;      /* 0.3 src/config.py:17 */
+    float iou_thresh;       /* 0.5 src/config.py:18 (unused by the reference, F4)        */
+    int32_t max_det;        /* 300 (build decision D4)                                    */
+    float min_confidence;   /* 0.3 src/config.py:24 */
+    int32_t inject;         /* 1: association consumes injected boxes         */
+    uint64_t track_class_mask[2]; /* bit c set = class id c is tracked (config.py:53)    */
+    aic_tracker_params tracker;
+} aic_pipeline_params;
+
+int aic_pipeline_create(aic_model* yolo, aic_model* reid, const aic_pipeline_params* p,
+                        aic_pipeline** out);
+int aic_pipeline_destroy(aic_pipeline* p);
+/* Copy `count` u8 BGR frames into ring slots [slot, slot+count). */
+int aic_pipeline_upload(aic_pipeline* p, int slot, const uint8_t* frames_bgr, int count);
+/* Planted detections for ring slots (inject=1): counts[count], boxes[count,max_persons,4] ... */
+int aic_pipeline_inject(aic_pipeline* p, int slot, int count, const int32_t* counts,
+                        const float* boxes_xyxy, const float* conf, const int32_t* cls);
+/* Process ring slots [slot, slot+count) in order. Per frame outputs (any may be NULL):
+ * n_tracks[count], tracks[count,max_persons,6] + track_conf as aic_tracker_outputs;
+ * n_dets[count], det_boxes[count,max_det,4], det_scores, det_labels from the detector. */
+int aic_pipeline_run(aic_pipeline* p, int slot, int count, int32_t* n_tracks, int32_t* tracks6,
+                     float* track_conf, int32_t* n_dets, float* det_boxes, float* det_scores,
+                     int32_t* det_labels);
+int aic_pipeline_tracker(aic_pipeline* p, aic_tracker** out);
+/* Embeddings of the last processed frame (parity tests): emb[n,dim] host. */
+int aic_pipeline_last_embeddings(aic_pipeline* p, float* emb, int cap_rows, int32_t* n, int32_t* dim);
+
+/* ------------------------------------------------------------------ measurement
+ * HIP-event timing of kernel classes on the streams they are launched on (bench.py roofline).
+ * Classes: 0 conv_igemm (MFMA), 1 conv_direct (3-channel stems), 2 pool/upsample/misc,
+ * 3 letterbox, 4 crop_resize, 5 decode+nms, 6 tracker kernels. */
+#define AIC_PROF_CLASSES 7
+int aic_prof_enable(int device, int on);
+int aic_prof_reset(int device);
+/* total ms, launches, algorithmic FLOPs and algorithmic bytes accumulated for a class. */
+int aic_prof_read(int device, int cls, double* ms, int64_t* launches, double* flops, double* bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AICAM_H */
