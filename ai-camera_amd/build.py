@@ -1,0 +1,72 @@
+"""Build libaicam.so in-tree with hipcc for gfx950 (no cmake, no JIT cache).
+
+    python ai-camera_amd/build.py [--force]
+
+One hipcc invocation per translation unit (objects cached under csrc/build/ by mtime), then a
+shared link.  -ffp-contract=off everywhere: the integer-exact preprocessing and the association
+arithmetic must round like the NumPy oracle; the MFMA kernels are unaffected.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "libaicam.so")
+SOURCES = ["runtime.cpp", "lsap.cpp", "tracker.cpp", "engine.cpp", "pipeline.cpp",
+           "kernels_conv.hip", "kernels_pre.hip", "kernels_det.hip", "kernels_trk.hip"]
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-Wall",
+         "-Wno-unused-function", "-Wno-unused-variable", "-DNDEBUG"]
+
+
+def hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    bdir = os.path.join(CSRC, "build")
+    os.makedirs(bdir, exist_ok=True)
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
+    headers.append(os.path.join(os.path.dirname(HERE), "include", "aicam.h"))
+    cc = hipcc()
+    jobs = []
+    for src in SOURCES:
+        sp = os.path.join(CSRC, src)
+        obj = os.path.join(bdir, src + ".o")
+        if force or _stale(obj, [sp] + headers):
+            cmd = [cc] + FLAGS + (["-x", "hip"] if src.endswith(".hip") else ["-x", "hip"]) + ["-c", sp, "-o", obj]
+            jobs.append((src, cmd))
+    def run(job):
+        src, cmd = job
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        return src, r.returncode, r.stdout + r.stderr
+    failed = False
+    with ThreadPoolExecutor(max_workers=min(6, max(1, len(jobs)))) as ex:
+        for src, rc, out in ex.map(run, jobs):
+            if verbose and (rc or out.strip()):
+                print(f"[{src}] rc={rc}\n{out}", file=sys.stderr)
+            failed |= rc != 0
+    if failed:
+        raise RuntimeError("hipcc failed")
+    objs = [os.path.join(bdir, s + ".o") for s in SOURCES]
+    if force or jobs or _stale(OUT, objs):
+        cmd = [cc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", OUT] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode:
+            raise RuntimeError("link failed:\n" + r.stdout + r.stderr)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

@@ -1,0 +1,151 @@
+"""TrackerCore with the interface of src/tracker/core/tracker_core.py:11-198 on top of aic_tracker:
+Kalman state + galleries live in HBM, the cascade / LSAP / lifecycle run in host C++."""
+import ctypes as C
+
+import numpy as np
+
+from .. import _lib as L
+from .. import config
+from .track import Track, TrackView
+
+
+class TrackerCore:
+    def __init__(self, max_cosine_distance=0.2, nn_budget=100, max_iou_distance=0.7, max_age=70, n_init=3,
+                 device=0, max_tracks=512):
+        self.max_cosine_distance = max_cosine_distance
+        self.nn_budget = nn_budget
+        self.max_iou_distance = max_iou_distance
+        self.max_age = max_age
+        self.n_init = n_init
+        self.device = device
+        p = L.TrackerParams(float(max_cosine_distance), float(max_iou_distance), int(nn_budget) if nn_budget else 0,
+                            int(max_age), int(n_init), int(max_tracks), 0, 1)
+        self._h = C.c_void_p()
+        L.call("aic_tracker_create", device, C.byref(p), C.byref(self._h))
+        self._owned = True
+        self._dim = 0
+        Track.reset_id_counter()        # tracker_core.py:42
+        self._names = list(config.CLASSES)
+        self._class_ids = {n: i for i, n in enumerate(self._names)}
+
+    @classmethod
+    def _from_handle(cls, handle, params):
+        self = cls.__new__(cls)
+        self.max_cosine_distance, self.max_iou_distance = params.max_cosine_distance, params.max_iou_distance
+        self.nn_budget, self.max_age, self.n_init = params.nn_budget, params.max_age, params.n_init
+        self.device, self._h, self._owned, self._dim = 0, handle, False, 0
+        self._names = list(config.CLASSES)
+        self._class_ids = {n: i for i, n in enumerate(self._names)}
+        return self
+
+    def _class_id(self, name):
+        """Class names travel through the C ABI as ids; names outside the COCO table get fresh ids."""
+        if name not in self._class_ids:
+            self._class_ids[name] = len(self._names)
+            self._names.append(name)
+        return self._class_ids[name]
+
+    def class_name_of(self, cid):
+        return self._names[cid] if 0 <= cid < len(self._names) else "Unknown"
+
+    def close(self):
+        if getattr(self, "_owned", False) and self._h:
+            L.call("aic_tracker_destroy", self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ reference API
+    def predict(self):                       # tracker_core.py:44-49
+        L.call("aic_tracker_predict", self._h)
+
+    def update(self, detections):            # tracker_core.py:51-81
+        n = len(detections)
+        tlwh = np.zeros((n, 4), np.float32)
+        conf = np.zeros(n, np.float32)
+        cls = np.zeros(n, np.int32)
+        has = np.zeros(n, np.uint8)
+        dim = 0
+        for d in detections:
+            if d.feature is not None:
+                dim = len(d.feature)
+                break
+        feats = np.zeros((n, max(dim, 1)), np.float32)
+        for j, d in enumerate(detections):
+            tlwh[j], conf[j] = d.tlwh, d.confidence
+            cls[j] = self._class_id(d.class_name)
+            if d.feature is not None:
+                feats[j], has[j] = d.feature, 1
+        self.update_arrays(tlwh, conf, cls, feats if dim else None, has)
+
+    def update_arrays(self, tlwh, conf, cls, feats, has_feat=None):
+        """Array form of update(): tlwh [N,4], conf [N], class ids [N], feats [N,D] or None."""
+        tlwh, conf = L.as_f32(tlwh).reshape(-1, 4), L.as_f32(conf).reshape(-1)
+        cls = np.ascontiguousarray(cls, dtype=np.int32).reshape(-1)
+        n = len(tlwh)
+        dim = 0 if feats is None else int(np.asarray(feats).shape[1])
+        f = None if feats is None else L.as_f32(feats)
+        h = None if has_feat is None else np.ascontiguousarray(has_feat, dtype=np.uint8)
+        L.call("aic_tracker_update", self._h, L.ptr(tlwh), L.ptr(conf), L.ptr(cls), L.ptr(f), L.HOST, L.ptr(h), n, dim)
+        if dim:
+            self._dim = dim
+
+    @property
+    def tracks(self):
+        return [TrackView(self, i, rec) for i, rec in enumerate(self._export())]
+
+    def get_active_tracks(self):             # tracker_core.py:196-198
+        return [t for t in self.tracks if not t.is_deleted()]
+
+    # ------------------------------------------------------------------ state access
+    def num_tracks(self):
+        n = C.c_int32()
+        L.call("aic_tracker_num_tracks", self._h, C.byref(n))
+        return n.value
+
+    def export_arrays(self):
+        t = self.num_tracks()
+        a = {k: np.zeros(t, np.int32) for k in ("track_id", "state", "hits", "age", "time_since_update", "cls", "gallery_len")}
+        conf, mean, cov = np.zeros(t, np.float32), np.zeros((t, 8), np.float32), np.zeros((t, 8, 8), np.float32)
+        L.call("aic_tracker_export", self._h, t, L.ptr(a["track_id"]), L.ptr(a["state"]), L.ptr(a["hits"]), L.ptr(a["age"]),
+               L.ptr(a["time_since_update"]), L.ptr(a["cls"]), L.ptr(conf), L.ptr(a["gallery_len"]), L.ptr(mean), L.ptr(cov))
+        a.update(conf=conf, mean=mean, cov=cov)
+        return a
+
+    def _export(self):
+        a = self.export_arrays()
+        for i in range(len(a["track_id"])):
+            yield (int(a["track_id"][i]), int(a["state"][i]), int(a["hits"][i]), int(a["age"][i]),
+                   int(a["time_since_update"][i]), int(a["cls"][i]), float(a["conf"][i]), int(a["gallery_len"][i]),
+                   a["mean"][i], a["cov"][i])
+
+    def _gallery(self, index, glen):
+        if glen == 0 or self._dim == 0:
+            return np.zeros((0, max(self._dim, 1)), np.float32)
+        out = np.zeros((glen, self._dim), np.float32)
+        L.call("aic_tracker_export_gallery", self._h, index, L.ptr(out), glen)
+        return out
+
+    def outputs(self, cap=1024):
+        """(rows int32 [K,6] = x1,y1,x2,y2,track_id,class_id ; conf [K]) of deepsort_tracker.py:126-141."""
+        out, conf, n = np.zeros((cap, 6), np.int32), np.zeros(cap, np.float32), C.c_int32()
+        L.call("aic_tracker_outputs", self._h, L.ptr(out), L.ptr(conf), cap, C.byref(n))
+        return out[:n.value], conf[:n.value]
+
+    def last_matches(self, cap=4096):
+        tid, det, n = np.zeros(cap, np.int32), np.zeros(cap, np.int32), C.c_int32()
+        L.call("aic_tracker_last_matches", self._h, L.ptr(tid), L.ptr(det), cap, C.byref(n))
+        return list(zip(tid[:n.value].tolist(), det[:n.value].tolist()))
+
+    def last_costs(self):
+        tn, dn = C.c_int32(), C.c_int32()
+        L.call("aic_tracker_last_costs", self._h, None, None, None, 1 << 30, C.byref(tn), C.byref(dn))
+        shape = (tn.value, dn.value)
+        app, maha, iou = (np.zeros(shape, np.float32) for _ in range(3))
+        L.call("aic_tracker_last_costs", self._h, L.ptr(app), L.ptr(maha), L.ptr(iou), max(1, shape[0] * shape[1]),
+               C.byref(tn), C.byref(dn))
+        return app, maha, iou

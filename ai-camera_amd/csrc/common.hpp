@@ -101,7 +101,7 @@ struct Device {
     hipStream_t s_main = nullptr;  // detection + ReID launch groups
     hipStream_t s_trk = nullptr;   // per-frame association chain
     int n_cu = 256;
-    bool prof_on = false;
+    unsigned prof_mask = 0;   // bit c set = class c is timed with HIP events
     struct Pair { hipEvent_t a, b; };
     std::vector<Pair> pending[AIC_PROF_CLASSES];
     std::vector<Pair> pool;
@@ -125,11 +125,12 @@ struct Prof {
     Device& d;
     int cls;
     hipStream_t s;
-    Prof(Device& dev, int c, hipStream_t st, double fl = 0, double by = 0) : d(dev), cls(c), s(st) {
-        if (d.prof_on) d.prof_begin(cls, s, fl, by);
+    bool on;
+    Prof(Device& dev, int c, hipStream_t st, double fl = 0, double by = 0) : d(dev), cls(c), s(st), on((dev.prof_mask >> c) & 1u) {
+        if (on) d.prof_begin(cls, s, fl, by);
     }
     ~Prof() {
-        if (d.prof_on) d.prof_end(cls, s);
+        if (on) d.prof_end(cls, s);
     }
 };
 

@@ -1,0 +1,502 @@
+// engine.cpp -- loads an .aicw engine file and runs it: the replacement for TRTEngine
+// (src/trt_utils/trt_engine.py:15-216), plus the fused detector / ReID entry points that replace
+// YOLODetector.detect (src/detector/yolo_detector.py:68-149) and the crop->embed half of
+// DeepSORT.update (src/tracker/deepsort_tracker.py:104-113, src/tracker/reid_model.py:67-126).
+//
+// Data layout in HBM: every activation is NHWC ([items][h][w][c], c contiguous) in the activation
+// dtype (fp16 or fp32); concatenations are channel slices of one buffer; head outputs and
+// embeddings are fp32.  Weights are repacked once at load to [cout][kh][kw][cin] with K padded to
+// the MFMA K-step and zero rows up to cout_pad, so the conv kernel needs no bounds checks on them.
+#include "engine.hpp"
+
+#include <cmath>
+#include <fstream>
+
+namespace aic {
+
+namespace {
+
+struct Reader {
+    const char* p;
+    size_t n, off = 0;
+    template <class T> const T* take(size_t count) {
+        AIC_REQUIRE(off + count * sizeof(T) <= n, AIC_ERR_FORMAT, "engine file truncated");
+        const T* r = reinterpret_cast<const T*>(p + off);
+        off += count * sizeof(T);
+        return r;
+    }
+};
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// IEEE fp32 -> fp16 bits, round-to-nearest-even (host side; no dependence on compiler-rt helpers)
+inline uint16_t f32_to_f16_bits(float f) {
+    uint32_t x;
+    std::memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    x &= 0x7FFFFFFFu;
+    if (x >= 0x7F800000u) return (uint16_t)(sign | (x > 0x7F800000u ? 0x7E00u : 0x7C00u));
+    if (x >= 0x477FF000u) return (uint16_t)(sign | 0x7C00u);            // rounds to inf
+    if (x < 0x33000001u) return (uint16_t)sign;                          // rounds to zero
+    int e = (int)(x >> 23) - 127;
+    uint32_t m = (x & 0x7FFFFFu) | 0x800000u;
+    int shift;
+    uint32_t base;
+    if (e < -14) { shift = 13 + (-14 - e); base = 0; }                   // subnormal half
+    else { shift = 13; base = (uint32_t)(e + 15) << 10; m &= 0x7FFFFFu; }
+    uint32_t q = m >> shift;
+    const uint32_t rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1);
+    if (rem > half || (rem == half && (q & 1u))) ++q;
+    return (uint16_t)(sign | (base + q));
+}
+
+}  // namespace
+
+Model::Model(Device& d, const void* blob, size_t nbytes, int dtype_, int max_items_)
+    : dev(&d), dtype(dtype_), max_items(max_items_) {
+    AIC_REQUIRE(dtype == AIC_F16 || dtype == AIC_F32, AIC_ERR_INVALID, "dtype must be AIC_F16 or AIC_F32");
+    AIC_REQUIRE(max_items > 0, AIC_ERR_INVALID, "max_items must be positive");
+    d.use();
+    Reader rd{reinterpret_cast<const char*>(blob), nbytes};
+    const uint32_t* head = rd.take<uint32_t>(2);
+    AIC_REQUIRE(head[0] == 0x57434941u && head[1] == 1u, AIC_ERR_FORMAT, "not an AICW v1 engine file");
+    const int32_t* h = rd.take<int32_t>(15);
+    kind = h[0], in_h = h[1], in_w = h[2];
+    const int nb = h[3], no = h[4], nw = h[5], nout = h[6];
+    for (int i = 0; i < 8; ++i) meta[i] = h[7 + i];
+    AIC_REQUIRE((kind == KIND_YOLO || kind == KIND_REID) && nb > 0 && no > 0 && nw >= 0 && nout > 0, AIC_ERR_FORMAT,
+                "bad engine header");
+    const int32_t* btab = rd.take<int32_t>((size_t)nb * 4);
+    const int32_t* otab = rd.take<int32_t>((size_t)no * 20);
+    const int64_t* wtab = rd.take<int64_t>((size_t)nw * 6);
+    const int32_t* outtab = rd.take<int32_t>((size_t)nout * 8);
+    const size_t payload_off = rd.off;
+    const float* payload = reinterpret_cast<const float*>(rd.p + payload_off);
+    const size_t payload_n = (nbytes - payload_off) / 4;
+
+    const int esz = dtype == AIC_F16 ? 2 : 4;
+    const int vec = 16 / esz;
+    // ---- activation arena
+    bufs.resize(nb);
+    storage.resize(nb);
+    for (int i = 0; i < nb; ++i) {
+        BufDesc& b = bufs[i];
+        b.h = btab[i * 4], b.w = btab[i * 4 + 1], b.c = btab[i * 4 + 2], b.f32 = btab[i * 4 + 3];
+        AIC_REQUIRE(b.h > 0 && b.w > 0 && b.c > 0, AIC_ERR_FORMAT, "bad buffer shape");
+        b.esize = b.f32 ? 4 : esz;
+        AIC_REQUIRE(b.c % (16 / b.esize) == 0, AIC_ERR_FORMAT, "buffer channel count must be a multiple of 16 bytes");
+        b.per_item = (size_t)b.h * b.w * b.c * b.esize;
+        storage[i].alloc(b.per_item * max_items + 256);
+        HIP_CHECK(hipMemsetAsync(storage[i].p, 0, storage[i].n, d.s_main));
+        b.p = storage[i].p;
+    }
+    AIC_REQUIRE(bufs[0].h == in_h && bufs[0].w == in_w && bufs[0].c == 8, AIC_ERR_FORMAT, "input buffer must be HxWx8");
+    // ---- ops
+    ops.resize(no);
+    for (int i = 0; i < no; ++i) std::memcpy(ops[i].v, otab + (size_t)i * 20, 80);
+    outs.resize(nout);
+    for (int i = 0; i < nout; ++i) std::memcpy(outs[i].v, outtab + (size_t)i * 8, 32);
+    // ---- weights: OIHW fp32 -> [cout_pad][Kp] (kh, kw, cin) in the activation dtype
+    weights.resize(nw);
+    const int bke = 4 * vec;
+    for (int i = 0; i < nw; ++i) {
+        ConvWeights& w = weights[i];
+        w.cout = (int)wtab[i * 6], w.cin = (int)wtab[i * 6 + 1], w.kh = (int)wtab[i * 6 + 2], w.kw = (int)wtab[i * 6 + 3];
+        const size_t woff = (size_t)wtab[i * 6 + 4], boff = (size_t)wtab[i * 6 + 5];
+        const size_t wn = (size_t)w.cout * w.cin * w.kh * w.kw;
+        AIC_REQUIRE(woff + wn <= payload_n && boff + w.cout <= payload_n, AIC_ERR_FORMAT, "weight offsets out of range");
+        w.cin_eff = w.cin == 3 ? 8 : w.cin;
+        AIC_REQUIRE(w.cin_eff % vec == 0, AIC_ERR_FORMAT, "conv input channels must be a multiple of 16 bytes");
+        w.K = w.kh * w.kw * w.cin_eff;
+        w.Kp = round_up(w.K, bke);
+        w.cout_pad = round_up(w.cout, 128) + 128;
+        const float* src = payload + woff;
+        std::vector<char> packed((size_t)w.cout_pad * w.Kp * esz, 0);
+        for (int co = 0; co < w.cout; ++co)
+            for (int ci = 0; ci < w.cin; ++ci)
+                for (int ky = 0; ky < w.kh; ++ky)
+                    for (int kx = 0; kx < w.kw; ++kx) {
+                        const float v = src[(((size_t)co * w.cin + ci) * w.kh + ky) * w.kw + kx];
+                        const size_t k = (size_t)co * w.Kp + (size_t)(ky * w.kw + kx) * w.cin_eff + ci;
+                        if (dtype == AIC_F16) reinterpret_cast<uint16_t*>(packed.data())[k] = f32_to_f16_bits(v);
+                        else reinterpret_cast<float*>(packed.data())[k] = v;
+                    }
+        w.w.alloc(packed.size());
+        HIP_CHECK(hipMemcpy(w.w.p, packed.data(), packed.size(), hipMemcpyHostToDevice));
+        std::vector<float> bias(w.cout_pad, 0.f);
+        std::copy(payload + boff, payload + boff + w.cout, bias.begin());
+        w.bias.alloc(w.cout_pad);
+        HIP_CHECK(hipMemcpy(w.bias.p, bias.data(), bias.size() * 4, hipMemcpyHostToDevice));
+    }
+    // ---- validate ops against buffers, count FLOPs
+    for (const OpDesc& o : ops) {
+        const int* v = o.v;
+        AIC_REQUIRE(v[1] >= 0 && v[1] < nb && v[4] >= 0 && v[4] < nb, AIC_ERR_FORMAT, "op references a missing buffer");
+        const BufDesc& sb = bufs[v[1]];
+        const BufDesc& db = bufs[v[4]];
+        const int cin_chk = (v[0] == OP_CONV && v[3] == 3) ? 8 : v[3];
+        AIC_REQUIRE(v[2] >= 0 && v[2] + cin_chk <= sb.c && v[2] % vec == 0, AIC_ERR_FORMAT, "op source slice out of range");
+        if (v[0] == OP_CONV) {
+            AIC_REQUIRE(v[15] >= 0 && v[15] < nw, AIC_ERR_FORMAT, "conv references a missing weight");
+            const ConvWeights& w = weights[v[15]];
+            AIC_REQUIRE(w.cout == v[6] && w.cin == v[3] && w.kh == v[7] && w.kw == v[8], AIC_ERR_FORMAT, "conv/weight shape mismatch");
+            AIC_REQUIRE(v[5] >= 0 && v[5] + v[6] <= db.c && v[5] % 4 == 0, AIC_ERR_FORMAT, "conv destination slice out of range");
+            AIC_REQUIRE((sb.h + 2 * v[10] - v[7]) / v[9] + 1 == db.h && (sb.w + 2 * v[10] - v[8]) / v[9] + 1 == db.w,
+                        AIC_ERR_FORMAT, "conv geometry mismatch");
+            AIC_REQUIRE(!sb.f32 || dtype == AIC_F32, AIC_ERR_FORMAT, "conv input must be an activation buffer");
+            if (v[14]) {
+                AIC_REQUIRE(v[12] >= 0 && v[12] < nb, AIC_ERR_FORMAT, "residual references a missing buffer");
+                const BufDesc& rb = bufs[v[12]];
+                AIC_REQUIRE(rb.h == db.h && rb.w == db.w && v[13] + v[6] <= rb.c && !rb.f32, AIC_ERR_FORMAT, "residual shape mismatch");
+            }
+            flops_per_item += 2.0 * db.h * db.w * (double)v[6] * v[3] * v[7] * v[8];
+            ++n_convs;
+        }
+    }
+    if (kind == KIND_YOLO) {
+        AIC_REQUIRE(nout <= 4, AIC_ERR_FORMAT, "at most 4 detection levels");
+        n_anchors = 0;
+        for (auto& o : outs) n_anchors += o.v[3] * o.v[4];
+        out_dim = meta[0];
+        max_det_cap = 1024;
+        const size_t ba = (size_t)max_items * n_anchors;
+        d_boxes.alloc(ba * 4), d_maxlogit.alloc(ba), d_labels.alloc(ba);
+        d_ncand.alloc(max_items), d_numdets.alloc(max_items);
+        d_out_boxes.alloc((size_t)max_items * max_det_cap * 4), d_out_boxes_orig.alloc((size_t)max_items * max_det_cap * 4);
+        d_out_scores.alloc((size_t)max_items * max_det_cap), d_out_labels.alloc((size_t)max_items * max_det_cap);
+    } else {
+        out_dim = outs[0].v[1];
+        AIC_REQUIRE(bufs[outs[0].v[0]].f32, AIC_ERR_FORMAT, "embedding buffer must be fp32");
+    }
+    HIP_CHECK(hipStreamSynchronize(d.s_main));
+}
+
+void Model::run(int n, hipStream_t s) {
+    AIC_REQUIRE(n >= 0 && n <= max_items, AIC_ERR_CAPACITY, "batch exceeds the engine's max_items");
+    if (n == 0) return;
+    for (const OpDesc& o : ops) {
+        const int* v = o.v;
+        const BufDesc& sb = bufs[v[1]];
+        const BufDesc& db = bufs[v[4]];
+        if (v[0] == OP_CONV) {
+            const ConvWeights& w = weights[v[15]];
+            ConvArgs a{};
+            a.x = sb.p, a.w = w.w.p, a.bias = w.bias.p, a.y = db.p;
+            a.x_cs = sb.c, a.x_coff = v[2], a.H = sb.h, a.W = sb.w, a.Cin = w.cin_eff;
+            a.y_cs = db.c, a.y_coff = v[5], a.Ho = db.h, a.Wo = db.w, a.Cout = w.cout;
+            a.res = nullptr, a.r_cs = 0, a.r_coff = 0, a.res_mode = v[14], a.act = v[11];
+            if (v[14]) { a.res = bufs[v[12]].p, a.r_cs = bufs[v[12]].c, a.r_coff = v[13]; }
+            a.KH = w.kh, a.KW = w.kw, a.stride = v[9], a.pad = v[10];
+            a.Kp = w.Kp, a.M = n * db.h * db.w, a.out_f32 = db.f32, a.cout_pad = w.cout_pad;
+            const double fl = 2.0 * a.M * (double)w.cout * w.cin * w.kh * w.kw;
+            const double by = ((double)n * sb.h * sb.w * w.cin + (double)a.M * w.cout) * (dtype == AIC_F16 ? 2 : 4) +
+                              (double)w.cout * w.cin * w.kh * w.kw * (dtype == AIC_F16 ? 2 : 4);
+            Prof pr(*dev, PROF_CONV, s, fl, by);
+            launch_conv_igemm(dtype, a, s);
+        } else {
+            EltArgs a{};
+            a.src = sb.p, a.dst = db.p, a.n = n, a.h = sb.h, a.w = sb.w, a.c = v[3];
+            a.s_cs = sb.c, a.s_coff = v[2], a.d_cs = db.c, a.d_coff = v[5];
+            Prof pr(*dev, PROF_MISC, s, 0, 0);
+            switch (v[0]) {
+                case OP_SPPF_POOL: launch_sppf_pool(dtype, a, s); break;
+                case OP_UPSAMPLE2X: launch_upsample2x(dtype, a, s); break;
+                case OP_MAXPOOL3S2: launch_maxpool3s2(dtype, a, s); break;
+                case OP_AVGPOOL: launch_avgpool(dtype, a, s); break;
+                case OP_L2NORM: launch_l2norm(dtype, a, s); break;
+                default: throw Error(AIC_ERR_FORMAT, "unknown op in engine file");
+            }
+        }
+    }
+}
+
+DetArgs Model::det_args(int batch, float conf, float iou, int max_det, const LetterboxGeom* g) {
+    AIC_REQUIRE(kind == KIND_YOLO, AIC_ERR_INVALID, "not a YOLO engine");
+    AIC_REQUIRE(max_det > 0 && max_det <= max_det_cap, AIC_ERR_CAPACITY, "max_det out of range (1..1024)");
+    AIC_REQUIRE(conf > 0.f && conf < 1.f, AIC_ERR_INVALID, "conf_thresh must be in (0,1)");
+    DetArgs a{};
+    int a0 = 0;
+    for (size_t l = 0; l < outs.size(); ++l) {
+        const int* v = outs[l].v;
+        a.lvl[l].box = reinterpret_cast<const float*>(bufs[v[0]].p);
+        a.lvl[l].cls = reinterpret_cast<const float*>(bufs[v[1]].p);
+        a.lvl[l].stride = v[2], a.lvl[l].h = v[3], a.lvl[l].w = v[4], a.lvl[l].a0 = a0;
+        a0 += v[3] * v[4];
+    }
+    a.n_levels = (int)outs.size(), a.n_anchors = n_anchors, a.nc = meta[0], a.reg_max = meta[1], a.batch = batch;
+    a.logit_thr = (float)std::log((double)conf / (1.0 - (double)conf));
+    a.iou_thr = iou, a.max_det = max_det;
+    a.pad_w = g ? g->pad_w : 0.f, a.pad_h = g ? g->pad_h : 0.f, a.ratio = g ? g->ratio : 1.f;
+    a.orig_w = g ? g->src_w : in_w, a.orig_h = g ? g->src_h : in_h;
+    a.boxes = d_boxes.p, a.max_logit = d_maxlogit.p, a.labels = d_labels.p, a.keys = nullptr;
+    a.n_cand = d_ncand.p, a.num_dets = d_numdets.p;
+    a.out_boxes = d_out_boxes.p, a.out_boxes_orig = g ? d_out_boxes_orig.p : nullptr;
+    a.out_scores = d_out_scores.p, a.out_labels = d_out_labels.p;
+    return a;
+}
+
+void Model::decode_nms(int batch, float conf, float iou, int max_det, const LetterboxGeom* g, hipStream_t s) {
+    const DetArgs a = det_args(batch, conf, iou, max_det, g);
+    Prof pr(*dev, PROF_DET, s, 0, (double)batch * n_anchors * (4 * meta[1] + meta[0]) * 4);
+    launch_decode(a, s);
+    launch_select_sort_nms(a, s);
+}
+
+}  // namespace aic
+
+// =================================================================================================
+using namespace aic;
+
+namespace {
+
+// conf passed through Python is a double rounded to float; the logit threshold is computed from the
+// fp64 value of that float so both sides of the parity test agree on the same number.
+void copy_out(void* dst, const void* src, size_t bytes, int mem, hipStream_t s) {
+    if (!bytes || !dst) return;
+    HIP_CHECK(hipMemcpyAsync(dst, src, bytes, mem == AIC_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
+}
+
+void load_input_nchw(Model& m, const float* images, int n, int mem, hipStream_t s) {
+    const size_t cnt = (size_t)n * 3 * m.in_h * m.in_w;
+    const float* src = images;
+    if (mem == AIC_HOST) {
+        m.d_in_f32.ensure(cnt);
+        HIP_CHECK(hipMemcpyAsync(m.d_in_f32.p, images, cnt * 4, hipMemcpyHostToDevice, s));
+        src = m.d_in_f32.p;
+    }
+    Prof pr(*m.dev, PROF_MISC, s);
+    launch_nchw_to_nhwc8(m.dtype, src, m.input(), n, m.in_h, m.in_w, s);
+}
+
+const uint8_t* stage_frames(Model& m, const uint8_t* frames, size_t bytes, int mem, hipStream_t s) {
+    if (mem == AIC_DEVICE) return frames;
+    m.d_frames.ensure(bytes);
+    HIP_CHECK(hipMemcpyAsync(m.d_frames.p, frames, bytes, hipMemcpyHostToDevice, s));
+    return m.d_frames.p;
+}
+
+}  // namespace
+
+extern "C" {
+
+int aic_model_load_mem(const void* blob, size_t nbytes, int device_id, int dtype, int max_items, aic_model** out) {
+    return guarded([&] {
+        AIC_REQUIRE(blob && out, AIC_ERR_INVALID, "NULL argument");
+        *out = new aic_model(device(device_id), blob, nbytes, dtype, max_items);
+    });
+}
+
+int aic_model_load(const char* path, int device_id, int dtype, int max_items, aic_model** out) {
+    return guarded([&] {
+        AIC_REQUIRE(path && out, AIC_ERR_INVALID, "NULL argument");
+        std::ifstream f(path, std::ios::binary | std::ios::ate);
+        AIC_REQUIRE(f.good(), AIC_ERR_NOT_FOUND, std::string("engine file not found: ") + path);
+        const size_t n = (size_t)f.tellg();
+        std::vector<char> blob(n);
+        f.seekg(0);
+        f.read(blob.data(), (std::streamsize)n);
+        AIC_REQUIRE(f.good(), AIC_ERR_FORMAT, std::string("cannot read engine file: ") + path);
+        *out = new aic_model(device(device_id), blob.data(), n, dtype, max_items);
+    });
+}
+
+int aic_model_destroy(aic_model* m) {
+    return guarded([&] {
+        if (m) { m->m.dev->use(); (void)hipDeviceSynchronize(); }
+        delete m;
+    });
+}
+
+int aic_model_info(const aic_model* m, int* kind, int* in_h, int* in_w, int* out_dim, int* n_anchors,
+                   double* flops_per_item, int* n_convs) {
+    return guarded([&] {
+        AIC_REQUIRE(m, AIC_ERR_INVALID, "NULL model");
+        if (kind) *kind = m->m.kind;
+        if (in_h) *in_h = m->m.in_h;
+        if (in_w) *in_w = m->m.in_w;
+        if (out_dim) *out_dim = m->m.out_dim;
+        if (n_anchors) *n_anchors = m->m.n_anchors;
+        if (flops_per_item) *flops_per_item = m->m.flops_per_item;
+        if (n_convs) *n_convs = m->m.n_convs;
+    });
+}
+
+int aic_yolo_infer(aic_model* mm, const float* images, int batch, int mem, float conf, float iou, int max_det,
+                   int32_t* num_dets, float* bboxes, float* scores, int32_t* labels) {
+    return guarded([&] {
+        AIC_REQUIRE(mm && images && batch > 0, AIC_ERR_INVALID, "bad argument");
+        Model& m = mm->m;
+        AIC_REQUIRE(m.kind == KIND_YOLO, AIC_ERR_INVALID, "not a YOLO engine");
+        m.dev->use();
+        hipStream_t s = m.dev->s_main;
+        load_input_nchw(m, images, batch, mem, s);
+        m.run(batch, s);
+        m.decode_nms(batch, conf, iou, max_det, nullptr, s);
+        copy_out(num_dets, m.d_numdets.p, (size_t)batch * 4, mem, s);
+        copy_out(bboxes, m.d_out_boxes.p, (size_t)batch * max_det * 16, mem, s);
+        copy_out(scores, m.d_out_scores.p, (size_t)batch * max_det * 4, mem, s);
+        copy_out(labels, m.d_out_labels.p, (size_t)batch * max_det * 4, mem, s);
+        HIP_CHECK(hipStreamSynchronize(s));
+    });
+}
+
+int aic_yolo_head(aic_model* mm, const float* images, int batch, int mem, float* dfl, float* cls) {
+    return guarded([&] {
+        AIC_REQUIRE(mm && images && batch > 0, AIC_ERR_INVALID, "bad argument");
+        Model& m = mm->m;
+        AIC_REQUIRE(m.kind == KIND_YOLO, AIC_ERR_INVALID, "not a YOLO engine");
+        m.dev->use();
+        hipStream_t s = m.dev->s_main;
+        load_input_nchw(m, images, batch, mem, s);
+        m.run(batch, s);
+        const int nc = m.meta[0], nb = 4 * m.meta[1];
+        int a0 = 0;
+        for (auto& o : m.outs) {
+            const int hw = o.v[3] * o.v[4];
+            const float* bsrc = reinterpret_cast<const float*>(m.bufs[o.v[0]].p);
+            const float* csrc = reinterpret_cast<const float*>(m.bufs[o.v[1]].p);
+            for (int b = 0; b < batch; ++b) {
+                if (dfl) HIP_CHECK(hipMemcpyAsync(dfl + ((size_t)b * m.n_anchors + a0) * nb, bsrc + (size_t)b * hw * nb,
+                                                  (size_t)hw * nb * 4, hipMemcpyDeviceToHost, s));
+                if (cls) HIP_CHECK(hipMemcpyAsync(cls + ((size_t)b * m.n_anchors + a0) * nc, csrc + (size_t)b * hw * nc,
+                                                  (size_t)hw * nc * 4, hipMemcpyDeviceToHost, s));
+            }
+            a0 += hw;
+        }
+        HIP_CHECK(hipStreamSynchronize(s));
+    });
+}
+
+int aic_yolo_decode(aic_model* mm, const float* images, int batch, int mem, float* boxes, float* max_logit, int32_t* labels) {
+    return guarded([&] {
+        AIC_REQUIRE(mm && images && batch > 0, AIC_ERR_INVALID, "bad argument");
+        Model& m = mm->m;
+        AIC_REQUIRE(m.kind == KIND_YOLO, AIC_ERR_INVALID, "not a YOLO engine");
+        m.dev->use();
+        hipStream_t s = m.dev->s_main;
+        load_input_nchw(m, images, batch, mem, s);
+        m.run(batch, s);
+        const DetArgs a = m.det_args(batch, 0.5f, 0.5f, 1, nullptr);
+        launch_decode(a, s);
+        const size_t ba = (size_t)batch * m.n_anchors;
+        copy_out(boxes, m.d_boxes.p, ba * 16, AIC_HOST, s);
+        copy_out(max_logit, m.d_maxlogit.p, ba * 4, AIC_HOST, s);
+        copy_out(labels, m.d_labels.p, ba * 4, AIC_HOST, s);
+        HIP_CHECK(hipStreamSynchronize(s));
+    });
+}
+
+int aic_reid_infer(aic_model* mm, const float* crops, int n, int mem, float* emb, int out_mem) {
+    return guarded([&] {
+        AIC_REQUIRE(mm && n >= 0, AIC_ERR_INVALID, "bad argument");
+        if (n == 0) return;
+        AIC_REQUIRE(crops && emb, AIC_ERR_INVALID, "NULL argument");
+        Model& m = mm->m;
+        AIC_REQUIRE(m.kind == KIND_REID, AIC_ERR_INVALID, "not a ReID engine");
+        m.dev->use();
+        hipStream_t s = m.dev->s_main;
+        load_input_nchw(m, crops, n, mem, s);
+        m.run(n, s);
+        copy_out(emb, m.embeddings(), (size_t)n * m.out_dim * 4, out_mem, s);
+        HIP_CHECK(hipStreamSynchronize(s));
+    });
+}
+
+int aic_letterbox(int device_id, const uint8_t* frame, int h, int w, int out_h, int out_w, float* out, float* ratio,
+                  float* pad_w, float* pad_h) {
+    return guarded([&] {
+        AIC_REQUIRE(frame && out && h > 0 && w > 0 && out_h > 0 && out_w > 0, AIC_ERR_INVALID, "bad argument");
+        Device& d = device(device_id);
+        hipStream_t s = d.s_main;
+        const LetterboxGeom g = letterbox_geometry(h, w, out_h, out_w);
+        DevBuf<uint8_t> df((size_t)h * w * 3);
+        DevBuf<float> dout((size_t)3 * out_h * out_w);
+        HIP_CHECK(hipMemcpyAsync(df.p, frame, df.n, hipMemcpyHostToDevice, s));
+        {
+            Prof pr(d, PROF_LETTERBOX, s, 0, (double)h * w * 3 + 12.0 * out_h * out_w);
+            launch_letterbox(df.p, 1, g, 0, AIC_F32, dout.p, s);
+        }
+        HIP_CHECK(hipMemcpyAsync(out, dout.p, dout.n * 4, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        if (ratio) *ratio = g.ratio;
+        if (pad_w) *pad_w = g.pad_w;
+        if (pad_h) *pad_h = g.pad_h;
+    });
+}
+
+int aic_crop_resize(int device_id, const uint8_t* frame, int h, int w, const float* boxes, int n, int out_h, int out_w,
+                    float* out, int32_t* valid) {
+    return guarded([&] {
+        AIC_REQUIRE(n >= 0 && h > 0 && w > 0 && out_h > 0 && out_w > 0, AIC_ERR_INVALID, "bad argument");
+        if (n == 0) return;
+        AIC_REQUIRE(frame && boxes && out, AIC_ERR_INVALID, "NULL argument");
+        Device& d = device(device_id);
+        hipStream_t s = d.s_main;
+        DevBuf<uint8_t> df((size_t)h * w * 3);
+        DevBuf<float> db((size_t)n * 4), dout((size_t)n * 3 * out_h * out_w);
+        DevBuf<int> dv(n);
+        HIP_CHECK(hipMemcpyAsync(df.p, frame, df.n, hipMemcpyHostToDevice, s));
+        HIP_CHECK(hipMemcpyAsync(db.p, boxes, (size_t)n * 16, hipMemcpyHostToDevice, s));
+        {
+            Prof pr(d, PROF_CROP, s, 0, (double)n * out_h * out_w * 15);
+            launch_crop_resize(df.p, h, w, db.p, nullptr, n, nullptr, out_h, out_w, 0, AIC_F32, dout.p, dv.p, s);
+        }
+        HIP_CHECK(hipMemcpyAsync(out, dout.p, dout.n * 4, hipMemcpyDeviceToHost, s));
+        if (valid) HIP_CHECK(hipMemcpyAsync(valid, dv.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+    });
+}
+
+int aic_detect(aic_model* mm, const uint8_t* frames, int batch, int h, int w, int mem, float conf, float iou, int max_det,
+               int32_t* num_dets, float* boxes, float* scores, int32_t* labels) {
+    return guarded([&] {
+        AIC_REQUIRE(mm && frames && batch > 0 && h > 0 && w > 0, AIC_ERR_INVALID, "bad argument");
+        Model& m = mm->m;
+        AIC_REQUIRE(m.kind == KIND_YOLO, AIC_ERR_INVALID, "not a YOLO engine");
+        AIC_REQUIRE(batch <= m.max_items, AIC_ERR_CAPACITY, "batch exceeds the engine's max_items");
+        m.dev->use();
+        hipStream_t s = m.dev->s_main;
+        const uint8_t* df = stage_frames(m, frames, (size_t)batch * h * w * 3, mem, s);
+        const LetterboxGeom g = letterbox_geometry(h, w, m.in_h, m.in_w);
+        {
+            Prof pr(*m.dev, PROF_LETTERBOX, s, 0, (double)batch * ((double)h * w * 3 + 16.0 * m.in_h * m.in_w));
+            launch_letterbox(df, batch, g, 1, m.dtype, m.input(), s);
+        }
+        m.run(batch, s);
+        m.decode_nms(batch, conf, iou, max_det, &g, s);
+        copy_out(num_dets, m.d_numdets.p, (size_t)batch * 4, AIC_HOST, s);
+        copy_out(boxes, m.d_out_boxes_orig.p, (size_t)batch * max_det * 16, AIC_HOST, s);
+        copy_out(scores, m.d_out_scores.p, (size_t)batch * max_det * 4, AIC_HOST, s);
+        copy_out(labels, m.d_out_labels.p, (size_t)batch * max_det * 4, AIC_HOST, s);
+        HIP_CHECK(hipStreamSynchronize(s));
+    });
+}
+
+int aic_reid_embed(aic_model* mm, const uint8_t* frame, int h, int w, int mem, const float* boxes, int n, float* emb,
+                   int32_t* valid) {
+    return guarded([&] {
+        AIC_REQUIRE(mm && n >= 0 && h > 0 && w > 0, AIC_ERR_INVALID, "bad argument");
+        if (n == 0) return;
+        AIC_REQUIRE(frame && boxes && emb, AIC_ERR_INVALID, "NULL argument");
+        Model& m = mm->m;
+        AIC_REQUIRE(m.kind == KIND_REID, AIC_ERR_INVALID, "not a ReID engine");
+        AIC_REQUIRE(n <= m.max_items, AIC_ERR_CAPACITY, "crop count exceeds the engine's max_items");
+        m.dev->use();
+        hipStream_t s = m.dev->s_main;
+        const uint8_t* df = stage_frames(m, frame, (size_t)h * w * 3, mem, s);
+        m.d_crop_boxes.ensure((size_t)n * 4);
+        m.d_valid.ensure(n);
+        HIP_CHECK(hipMemcpyAsync(m.d_crop_boxes.p, boxes, (size_t)n * 16, hipMemcpyHostToDevice, s));
+        {
+            Prof pr(*m.dev, PROF_CROP, s, 0, (double)n * m.in_h * m.in_w * 19);
+            launch_crop_resize(df, h, w, m.d_crop_boxes.p, nullptr, n, nullptr, m.in_h, m.in_w, 1, m.dtype, m.input(),
+                               m.d_valid.p, s);
+        }
+        m.run(n, s);
+        copy_out(emb, m.embeddings(), (size_t)n * m.out_dim * 4, AIC_HOST, s);
+        if (valid) HIP_CHECK(hipMemcpyAsync(valid, m.d_valid.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+    });
+}
+
+}  // extern "C"

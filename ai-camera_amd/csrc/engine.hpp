@@ -1,0 +1,48 @@
+// engine.hpp -- executor of an .aicw engine file (graph IR + weights) on one GPU.
+#pragma once
+#include "kernels.hpp"
+
+namespace aic {
+
+enum { OP_CONV = 1, OP_SPPF_POOL = 2, OP_UPSAMPLE2X = 3, OP_MAXPOOL3S2 = 4, OP_AVGPOOL = 5, OP_L2NORM = 6 };
+enum { KIND_YOLO = 1, KIND_REID = 2 };
+
+struct BufDesc { int h, w, c, f32; void* p; size_t per_item; int esize; };
+struct ConvWeights { DevBuf<char> w; DevBuf<float> bias; int cout, cin, cin_eff, kh, kw, K, Kp, cout_pad; };
+struct OpDesc { int v[20]; };
+struct OutDesc { int v[8]; };
+
+struct Model {
+    Device* dev = nullptr;
+    int kind = 0, in_h = 0, in_w = 0, dtype = AIC_F16, max_items = 0;
+    int meta[8] = {0};
+    std::vector<BufDesc> bufs;
+    std::vector<DevBuf<char>> storage;
+    std::vector<OpDesc> ops;
+    std::vector<ConvWeights> weights;
+    std::vector<OutDesc> outs;
+    double flops_per_item = 0;
+    int n_convs = 0, n_anchors = 0, out_dim = 0;
+
+    // detector workspace (YOLO)
+    int max_det_cap = 0;
+    DevBuf<float> d_boxes, d_maxlogit, d_out_boxes, d_out_boxes_orig, d_out_scores;
+    DevBuf<int> d_labels, d_ncand, d_numdets, d_out_labels;
+    // staging
+    DevBuf<float> d_in_f32;
+    DevBuf<uint8_t> d_frames;
+    DevBuf<float> d_crop_boxes;
+    DevBuf<int> d_valid;
+
+    Model(Device& d, const void* blob, size_t nbytes, int dtype_, int max_items_);
+    void* input() { return bufs[0].p; }
+    void run(int n_items, hipStream_t s);
+    // YOLO post-processing on the buffers left by run()
+    DetArgs det_args(int batch, float conf, float iou, int max_det, const LetterboxGeom* g);
+    void decode_nms(int batch, float conf, float iou, int max_det, const LetterboxGeom* g, hipStream_t s);
+    const float* embeddings() const { return reinterpret_cast<const float*>(bufs[outs[0].v[0]].p); }
+};
+
+}  // namespace aic
+
+struct aic_model { aic::Model m; aic_model(aic::Device& d, const void* b, size_t n, int dt, int mi) : m(d, b, n, dt, mi) {} };

@@ -1,0 +1,101 @@
+// kernels.hpp -- host-callable launchers of the gfx950 kernels (defined in the .hip files).
+#pragma once
+#include "common.hpp"
+
+namespace aic {
+
+typedef _Float16 half_t;
+
+// ------------------------------------------------------------------ conv / graph ops (kernels_conv.hip)
+struct ConvArgs {
+    const void* x;      // NHWC input, element type T
+    const void* w;      // packed weights [CoutPad][Kp], element type T, K = (kh, kw, cin)
+    const float* bias;  // [CoutPad]
+    void* y;            // NHWC output (T, or float when out_f32)
+    const void* res;    // residual, same layout family as y (type T)
+    int x_cs, x_coff, H, W, Cin;       // pixel stride (elements), channel offset, spatial dims, cin (multiple of 16B/sizeof(T))
+    int y_cs, y_coff, Ho, Wo, Cout;
+    int r_cs, r_coff, res_mode, act;
+    int KH, KW, stride, pad;
+    int Kp;             // K padded to a multiple of the K-step
+    int M;              // N * Ho * Wo
+    int out_f32;
+    int cout_pad;       // rows in w / bias (multiple of 128)
+};
+// dtype: AIC_F16 or AIC_F32 (type of x / w / res and, unless out_f32, y)
+void launch_conv_igemm(int dtype, const ConvArgs& a, hipStream_t s);
+
+struct EltArgs {
+    const void* src; void* dst;
+    int n, h, w, c;            // source extent, channels processed
+    int s_cs, s_coff, d_cs, d_coff;
+};
+void launch_sppf_pool(int dtype, const EltArgs& a, hipStream_t s);     // writes 3 pooled copies at d_coff + k*c
+void launch_upsample2x(int dtype, const EltArgs& a, hipStream_t s);
+void launch_maxpool3s2(int dtype, const EltArgs& a, hipStream_t s);
+void launch_avgpool(int dtype, const EltArgs& a, hipStream_t s);
+void launch_l2norm(int dtype, const EltArgs& a, hipStream_t s);        // dst is float
+// fp32 NCHW [n,3,h,w] -> NHWC8 (RGB + zeros) of the activation dtype
+void launch_nchw_to_nhwc8(int dtype, const float* src, void* dst, int n, int h, int w, hipStream_t s);
+// gather float NHWC buffer rows -> dense float [n, hw, c] (head export)
+void launch_copy_f32(const float* src, float* dst, size_t count, hipStream_t s);
+
+// ------------------------------------------------------------------ pre-processing (kernels_pre.hip)
+struct LetterboxGeom {
+    int src_h, src_w, out_h, out_w, unpad_h, unpad_w, top, left;
+    float ratio, pad_w, pad_h;
+};
+LetterboxGeom letterbox_geometry(int h, int w, int out_h, int out_w);
+// frames u8 [n,h,w,3] BGR (device). mode 0: fp32 NCHW RGB/255 ; mode 1: NHWC8 activation dtype
+void launch_letterbox(const uint8_t* frames, int n, const LetterboxGeom& g, int mode, int dtype, void* out,
+                      hipStream_t s);
+// boxes [n,4] xyxy (device), frame_of[n] (device, may be NULL = frame 0), frames u8 [*,h,w,3].
+// n_dev (device int, may be NULL) caps the number of live crops. valid[n] written.
+void launch_crop_resize(const uint8_t* frames, int h, int w, const float* boxes, const int* frame_of, int n,
+                        const int* n_dev, int out_h, int out_w, int mode, int dtype, void* out, int* valid,
+                        hipStream_t s);
+
+// ------------------------------------------------------------------ detection head (kernels_det.hip)
+struct HeadLevel { const float* box; const float* cls; int h, w, stride, a0; };
+struct DetArgs {
+    HeadLevel lvl[4];
+    int n_levels, n_anchors, nc, reg_max, batch;
+    float logit_thr, iou_thr;
+    int max_det;
+    // letterbox undo (K4)
+    float pad_w, pad_h, ratio; int orig_w, orig_h;
+    // outputs / workspace (device)
+    float* boxes;      // [B,A,4]
+    float* max_logit;  // [B,A]
+    int* labels;       // [B,A]
+    unsigned long long* keys;  // [B,A] sort keys
+    int* n_cand;       // [B]
+    int* num_dets;     // [B]
+    float* out_boxes;  // [B,max_det,4] letterbox space
+    float* out_boxes_orig;  // [B,max_det,4] original frame space (may be NULL)
+    float* out_scores; // [B,max_det]
+    int* out_labels;   // [B,max_det]
+};
+void launch_decode(const DetArgs& a, hipStream_t s);
+void launch_select_sort_nms(const DetArgs& a, hipStream_t s);
+
+// ------------------------------------------------------------------ tracker (kernels_trk.hip)
+void launch_kf_initiate(const float* z, int n, float* mean, float* cov, const int* slots, hipStream_t s);
+void launch_kf_initiate_idx(const float* z, const int* zidx, int n, float* mean, float* cov, const int* slots, hipStream_t s);
+void launch_kf_predict(float* mean, float* cov, const int* slots, int n, hipStream_t s);
+void launch_kf_project(const float* mean, const float* cov, int n, float* pmean, float* pcov, hipStream_t s);
+void launch_kf_update(float* mean, float* cov, const int* slots, const float* z, const int* zidx, int n,
+                      float* out_tlwh, hipStream_t s);
+void launch_kf_gating(const float* mean, const float* cov, const int* slots, int n, const float* zs, int m,
+                      int shared_z, int only_position, float* d2, hipStream_t s);
+void launch_iou_cost(const float* trk_tlwh, const float* mean, const int* slots, int t, const float* det_tlwh,
+                     int n, float* cost, hipStream_t s);
+void launch_fill(float* p, float v, size_t n, hipStream_t s);
+void launch_normalize_rows(const float* src, float* dst, int n, int dim, hipStream_t s);
+// galleries: base [slots][gmax][dim]; per row t: slot index + valid length; det_n normalised rows.
+void launch_cosine_min(const float* gal, const int* slots, const int* glen, int t, int gmax, int dim,
+                       const float* det_n, const unsigned char* has_feat, int n, float* cost, hipStream_t s);
+void launch_gallery_append(float* gal, int gmax, int dim, const int* slot, const int* pos, const int* det,
+                           const float* feat, int count, hipStream_t s);
+
+}  // namespace aic

@@ -1,0 +1,461 @@
+// kernels_conv.hip -- implicit-GEMM convolution on the gfx950 matrix cores + the small graph ops.
+//
+// conv_igemm: NHWC activations, weights packed [Cout][kh][kw][cin] so both GEMM operands are
+// contiguous along K.  GEMM view: D[cout][pixel] = sum_k W[cout][k] * X[pixel][k] with
+// K = kh*kw*cin walked tap-major; the MFMA "A" operand is the weight tile and the "B" operand
+// the gathered pixel tile, so each lane ends up with 4 CONSECUTIVE output channels of one
+// pixel (row = 4*(lane>>4)+i, col = lane&15 of v_mfma_f32_16x16x*) and the epilogue stores
+// them as one 8-byte (fp16) / 16-byte (fp32) NHWC vector: no transpose through LDS.
+//
+//   fp16 mode: v_mfma_f32_16x16x32_f16, fp32 accumulate  (throughput mode)
+//   fp32 mode: v_mfma_f32_16x16x4_f32, exact fp32 fmaf chain (parity mode)
+//
+// Per K-step each tile row holds 64 B (32 halves / 16 floats).  LDS image: row*64 +
+// 16*(chunk ^ ((row>>1)&3)) -- an XOR swizzle that is conflict-free for the ds_read_b128
+// lane groups of gfx950 (checked exhaustively against the group table of
+// MI355X_MICROARCH.md §LDS) and for the staging ds_write_b128.  Global->register->LDS staging
+// with the next step's loads issued before the current step's MFMAs (register double buffer):
+// zero-padding, image borders and the K tail are resolved per 16-byte chunk at load time.
+#include "kernels.hpp"
+
+namespace aic {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+    if (act == 1) return v / (1.0f + __expf(-v));   // SiLU
+    if (act == 2) return fmaxf(v, 0.0f);             // ReLU
+    return v;
+}
+
+template <typename T> struct Frag;
+template <> struct Frag<half_t> {
+    typedef half8 type;
+    static __device__ __forceinline__ floatx4 mma(const half8& a, const half8& b, floatx4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct Frag<float> {
+    typedef floatx4 type;
+    static __device__ __forceinline__ floatx4 mma(const floatx4& a, const floatx4& b, floatx4 c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], c, 0, 0, 0);
+        return c;
+    }
+};
+
+__device__ __forceinline__ int lds_off(int row, int chunk) { return row * 64 + 16 * (chunk ^ ((row >> 1) & 3)); }
+
+// 4 waves per block arranged WM x WN; each wave owns MT x NT tiles of 16 pixels x 16 channels.
+template <typename T, int MT, int NT, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
+    constexpr int CH = 16 / (int)sizeof(T);   // elements per 16-byte chunk
+    constexpr int BKE = 4 * CH;                // K elements per step
+    constexpr int BM = WM * MT * 16;           // pixels per block
+    constexpr int BN = WN * NT * 16;           // output channels per block
+    constexpr int A_PER = BM / 64;             // 16-byte chunks of the pixel tile per thread
+    constexpr int B_PER = (BN + 63) / 64;      // ... of the weight tile
+    constexpr int TILE = (BM + BN) * 64;       // bytes per stage
+    static_assert(WM * WN == 4 && BM % 64 == 0, "block is 4 waves; pixel tile a multiple of 64");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int t = threadIdx.x;
+    const int kc = t & 3;        // which 16-byte chunk of the 64-byte K-step this thread stages
+    const int r0 = t >> 2;       // first tile row this thread stages
+    const int m0 = blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+
+    const T* __restrict__ xg = reinterpret_cast<const T*>(a.x);
+    const T* __restrict__ wg = reinterpret_cast<const T*>(a.w);
+
+    // ---- per-thread description of the pixel rows it gathers
+    size_t pix_base[A_PER];
+    int ih0[A_PER], iw0[A_PER];
+    const int HoWo = a.Ho * a.Wo;
+#pragma unroll
+    for (int i = 0; i < A_PER; ++i) {
+        const int m = m0 + r0 + 64 * i;
+        if (m < a.M) {
+            const int img = m / HoWo;
+            const int rem = m - img * HoWo;
+            const int oh = rem / a.Wo;
+            const int ow = rem - oh * a.Wo;
+            pix_base[i] = (size_t)img * a.H * a.W;
+            ih0[i] = oh * a.stride - a.pad;
+            iw0[i] = ow * a.stride - a.pad;
+        } else {
+            pix_base[i] = 0;
+            ih0[i] = -(1 << 28);   // never in range -> zero rows
+            iw0[i] = 0;
+        }
+    }
+    // ---- position of this thread's chunk inside K: (kh, kw, c)
+    int c_in = kc * CH, kw = 0, kh = 0;
+    while (c_in >= a.Cin) {
+        c_in -= a.Cin;
+        if (++kw == a.KW) { kw = 0; ++kh; }
+    }
+
+    uint4 a_reg[A_PER], b_reg[B_PER];
+    const int nsteps = a.Kp / BKE;
+
+    auto load_step = [&](int step) {
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) {
+            const int ih = ih0[i] + kh, iw = iw0[i] + kw;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (kh < a.KH && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W) {
+                const size_t off = (pix_base[i] + (size_t)ih * a.W + iw) * a.x_cs + a.x_coff + c_in;
+                v = *reinterpret_cast<const uint4*>(xg + off);
+            }
+            a_reg[i] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < B_PER; ++j) {
+            const int row = r0 + 64 * j;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (row < BN) v = *reinterpret_cast<const uint4*>(wg + (size_t)(n0 + row) * a.Kp + step * BKE + kc * CH);
+            b_reg[j] = v;
+        }
+        // advance (kh, kw, c) by one K-step
+        c_in += BKE;
+        while (c_in >= a.Cin) {
+            c_in -= a.Cin;
+            if (++kw == a.KW) { kw = 0; ++kh; }
+        }
+    };
+    auto store_step = [&](int stage) {
+        char* base = smem + stage * TILE;
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) {
+            const int row = r0 + 64 * i;
+            *reinterpret_cast<uint4*>(base + lds_off(row, kc)) = a_reg[i];
+        }
+#pragma unroll
+        for (int j = 0; j < B_PER; ++j) {
+            const int row = r0 + 64 * j;
+            if (row < BN) *reinterpret_cast<uint4*>(base + BM * 64 + lds_off(row, kc)) = b_reg[j];
+        }
+    };
+
+    const int lane = t & 63, wv = t >> 6;
+    const int wm = wv / WN, wn = wv % WN;
+    const int q = lane >> 4, r = lane & 15;
+
+    floatx4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    load_step(0);
+    store_step(0);
+    __syncthreads();
+
+    typedef typename Frag<T>::type frag_t;
+    for (int step = 0; step < nsteps; ++step) {
+        const int cur = step & 1;
+        const bool more = step + 1 < nsteps;
+        if (more) load_step(step + 1);   // global loads in flight under the MFMAs below
+        const char* base = smem + cur * TILE;
+        frag_t xf[MT], wf[NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int row = (wm * MT + i) * 16 + r;
+            xf[i] = *reinterpret_cast<const frag_t*>(base + lds_off(row, q));
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int row = (wn * NT + j) * 16 + r;
+            wf[j] = *reinterpret_cast<const frag_t*>(base + BM * 64 + lds_off(row, q));
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = Frag<T>::mma(wf[j], xf[i], acc[i][j]);
+        if (more) store_step(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias, residual, activation; 4 consecutive channels per lane
+    const float* __restrict__ bias = a.bias;
+    const T* __restrict__ rg = reinterpret_cast<const T*>(a.res);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int m = m0 + (wm * MT + i) * 16 + r;
+        if (m >= a.M) continue;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int n = n0 + (wn * NT + j) * 16 + 4 * q;
+            if (n >= a.Cout) continue;
+            const floatx4 b4 = *reinterpret_cast<const floatx4*>(bias + n);
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] + b4[e];
+            float rv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (a.res_mode) {
+                const T* rp = rg + (size_t)m * a.r_cs + a.r_coff + n;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) rv[e] = (n + e < a.Cout) ? (float)rp[e] : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float x = v[e];
+                if (a.res_mode == 1) x += rv[e];
+                x = act_apply(x, a.act);
+                if (a.res_mode == 2) x += rv[e];
+                v[e] = x;
+            }
+            const size_t yoff = (size_t)m * a.y_cs + a.y_coff + n;
+            if (n + 4 <= a.Cout) {
+                if (a.out_f32) {
+                    *reinterpret_cast<floatx4*>(reinterpret_cast<float*>(a.y) + yoff) = floatx4{v[0], v[1], v[2], v[3]};
+                } else if constexpr (sizeof(T) == 2) {
+                    half4 h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+                    *reinterpret_cast<half4*>(reinterpret_cast<half_t*>(a.y) + yoff) = h;
+                } else {
+                    *reinterpret_cast<floatx4*>(reinterpret_cast<float*>(a.y) + yoff) = floatx4{v[0], v[1], v[2], v[3]};
+                }
+            } else {
+                for (int e = 0; e < 4 && n + e < a.Cout; ++e) {
+                    if (a.out_f32 || sizeof(T) == 4) reinterpret_cast<float*>(a.y)[yoff + e] = v[e];
+                    else reinterpret_cast<half_t*>(a.y)[yoff + e] = (half_t)v[e];
+                }
+            }
+        }
+    }
+}
+
+template <typename T, int MT, int NT, int WM, int WN>
+static void launch_variant(const ConvArgs& a, hipStream_t s) {
+    constexpr int BM = WM * MT * 16, BN = WN * NT * 16;
+    dim3 grid(ceil_div(a.M, BM), ceil_div(a.Cout, BN));
+    const size_t lds = 2 * (size_t)(BM + BN) * 64;
+    hipLaunchKernelGGL((conv_igemm_kernel<T, MT, NT, WM, WN>), grid, dim3(256), lds, s, a);
+    KCHECK();
+}
+
+template <typename T>
+static void launch_conv_t(const ConvArgs& a, hipStream_t s) {
+    const int c = a.Cout;
+    const long blocks128 = (long)ceil_div(a.M, 128);
+    if (c % 128 == 0 || c > 160) {
+        if (blocks128 * ceil_div(c, 128) >= 128) launch_variant<T, 4, 4, 2, 2>(a, s);   // 128 px x 128 ch
+        else launch_variant<T, 2, 2, 2, 2>(a, s);                                       // 64 px x 64 ch (small maps)
+    } else if (c % 80 == 0) {
+        launch_variant<T, 2, 5, 4, 1>(a, s);                                            // 128 px x 80 ch
+    } else if (c % 64 == 0) {
+        if (blocks128 >= 512) launch_variant<T, 4, 4, 4, 1>(a, s);                      // 256 px x 64 ch
+        else launch_variant<T, 2, 4, 4, 1>(a, s);                                       // 128 px x 64 ch
+    } else if (c % 48 == 0) {
+        launch_variant<T, 2, 3, 4, 1>(a, s);                                            // 128 px x 48 ch
+    } else if (c % 32 == 0 || c > 16) {
+        launch_variant<T, 4, 2, 4, 1>(a, s);                                            // 256 px x 32 ch
+    } else {
+        launch_variant<T, 4, 1, 4, 1>(a, s);                                            // 256 px x 16 ch
+    }
+}
+
+void launch_conv_igemm(int dtype, const ConvArgs& a, hipStream_t s) {
+    if (a.M <= 0) return;
+    if (dtype == AIC_F16) launch_conv_t<half_t>(a, s);
+    else launch_conv_t<float>(a, s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Small NHWC ops. One thread per 16-byte channel chunk (8 halves / 4 floats); HBM/L2-bound.
+template <typename T> struct Vec;
+template <> struct Vec<half_t> { typedef half8 type; static constexpr int N = 8; };
+template <> struct Vec<float> { typedef floatx4 type; static constexpr int N = 4; };
+
+template <typename T>
+__device__ __forceinline__ typename Vec<T>::type vmax(typename Vec<T>::type a, typename Vec<T>::type b) {
+    typename Vec<T>::type o;
+#pragma unroll
+    for (int e = 0; e < Vec<T>::N; ++e) o[e] = a[e] > b[e] ? a[e] : b[e];
+    return o;
+}
+
+template <typename T>
+__global__ void sppf_pool_kernel(const EltArgs a) {
+    typedef typename Vec<T>::type V;
+    constexpr int VN = Vec<T>::N;
+    const int cv = a.c / VN;
+    const long total = (long)a.n * a.h * a.w * cv;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int cc = (int)(idx % cv);
+    long p = idx / cv;
+    const int x = (int)(p % a.w); p /= a.w;
+    const int y = (int)(p % a.h);
+    const int img = (int)(p / a.h);
+    const T* src = reinterpret_cast<const T*>(a.src);
+    T* dst = reinterpret_cast<T*>(a.dst);
+    V m5, m9, m13;
+    const T lowest = (T)(-65504.0f);
+#pragma unroll
+    for (int e = 0; e < VN; ++e) m5[e] = m9[e] = m13[e] = lowest;
+    for (int dy = -6; dy <= 6; ++dy) {
+        const int yy = y + dy;
+        if (yy < 0 || yy >= a.h) continue;
+        for (int dx = -6; dx <= 6; ++dx) {
+            const int xx = x + dx;
+            if (xx < 0 || xx >= a.w) continue;
+            const V v = *reinterpret_cast<const V*>(src + ((size_t)(img * a.h + yy) * a.w + xx) * a.s_cs + a.s_coff + cc * VN);
+            m13 = vmax<T>(m13, v);
+            const int ad = max(abs(dy), abs(dx));
+            if (ad <= 4) m9 = vmax<T>(m9, v);
+            if (ad <= 2) m5 = vmax<T>(m5, v);
+        }
+    }
+    T* o = dst + ((size_t)(img * a.h + y) * a.w + x) * a.d_cs + a.d_coff + cc * VN;
+    *reinterpret_cast<V*>(o) = m5;
+    *reinterpret_cast<V*>(o + a.c) = m9;
+    *reinterpret_cast<V*>(o + 2 * a.c) = m13;
+}
+
+template <typename T>
+__global__ void upsample2x_kernel(const EltArgs a) {
+    typedef typename Vec<T>::type V;
+    constexpr int VN = Vec<T>::N;
+    const int cv = a.c / VN;
+    const int oh = 2 * a.h, ow = 2 * a.w;
+    const long total = (long)a.n * oh * ow * cv;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int cc = (int)(idx % cv);
+    long p = idx / cv;
+    const int x = (int)(p % ow); p /= ow;
+    const int y = (int)(p % oh);
+    const int img = (int)(p / oh);
+    const T* src = reinterpret_cast<const T*>(a.src);
+    T* dst = reinterpret_cast<T*>(a.dst);
+    const V v = *reinterpret_cast<const V*>(src + ((size_t)(img * a.h + (y >> 1)) * a.w + (x >> 1)) * a.s_cs + a.s_coff + cc * VN);
+    *reinterpret_cast<V*>(dst + ((size_t)(img * oh + y) * ow + x) * a.d_cs + a.d_coff + cc * VN) = v;
+}
+
+template <typename T>
+__global__ void maxpool3s2_kernel(const EltArgs a) {
+    typedef typename Vec<T>::type V;
+    constexpr int VN = Vec<T>::N;
+    const int cv = a.c / VN;
+    const int oh = (a.h + 2 - 3) / 2 + 1, ow = (a.w + 2 - 3) / 2 + 1;
+    const long total = (long)a.n * oh * ow * cv;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int cc = (int)(idx % cv);
+    long p = idx / cv;
+    const int x = (int)(p % ow); p /= ow;
+    const int y = (int)(p % oh);
+    const int img = (int)(p / oh);
+    const T* src = reinterpret_cast<const T*>(a.src);
+    T* dst = reinterpret_cast<T*>(a.dst);
+    V m;
+#pragma unroll
+    for (int e = 0; e < VN; ++e) m[e] = (T)(-65504.0f);
+    for (int dy = -1; dy <= 1; ++dy) {
+        const int yy = 2 * y + dy;
+        if (yy < 0 || yy >= a.h) continue;
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int xx = 2 * x + dx;
+            if (xx < 0 || xx >= a.w) continue;
+            m = vmax<T>(m, *reinterpret_cast<const V*>(src + ((size_t)(img * a.h + yy) * a.w + xx) * a.s_cs + a.s_coff + cc * VN));
+        }
+    }
+    *reinterpret_cast<V*>(dst + ((size_t)(img * oh + y) * ow + x) * a.d_cs + a.d_coff + cc * VN) = m;
+}
+
+// global average pool: one thread per (item, channel); h*w is 32 for the ReID trunk.
+template <typename T>
+__global__ void avgpool_kernel(const EltArgs a) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)a.n * a.c) return;
+    const int ch = (int)(idx % a.c);
+    const int img = (int)(idx / a.c);
+    const T* src = reinterpret_cast<const T*>(a.src) + (size_t)img * a.h * a.w * a.s_cs + a.s_coff + ch;
+    float sum = 0.f;
+    const int hw = a.h * a.w;
+    for (int p = 0; p < hw; ++p) sum += (float)src[(size_t)p * a.s_cs];
+    reinterpret_cast<T*>(a.dst)[(size_t)img * a.d_cs + a.d_coff + ch] = (T)(sum / (float)hw);
+}
+
+// L2 normalise: one wavefront per item, fp32 output.
+template <typename T>
+__global__ void l2norm_kernel(const EltArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int item = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (item >= a.n) return;
+    const T* src = reinterpret_cast<const T*>(a.src) + (size_t)item * a.s_cs + a.s_coff;
+    float ss = 0.f;
+    for (int c = lane; c < a.c; c += 64) { const float v = (float)src[c]; ss += v * v; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+    const float nrm = fmaxf(sqrtf(ss), 1e-12f);
+    float* dst = reinterpret_cast<float*>(a.dst) + (size_t)item * a.d_cs + a.d_coff;
+    for (int c = lane; c < a.c; c += 64) dst[c] = (float)src[c] / nrm;
+}
+
+template <typename T>
+__global__ void nchw_to_nhwc8_kernel(const float* __restrict__ src, T* __restrict__ dst, int n, int h, int w) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long hw = (long)h * w;
+    if (idx >= (long)n * hw) return;
+    const long img = idx / hw, p = idx - img * hw;
+    const float* s = src + img * 3 * hw + p;
+    T o[8];
+    o[0] = (T)s[0]; o[1] = (T)s[hw]; o[2] = (T)s[2 * hw];
+#pragma unroll
+    for (int e = 3; e < 8; ++e) o[e] = (T)0.f;
+    T* d = dst + idx * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) d[e] = o[e];
+}
+
+__global__ void copy_f32_kernel(const float* __restrict__ src, float* __restrict__ dst, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+
+#define ELT_LAUNCH(kernel, total)                                                                  \
+    do {                                                                                           \
+        const long _tot = (total);                                                                 \
+        if (_tot <= 0) return;                                                                     \
+        if (dtype == AIC_F16) hipLaunchKernelGGL(kernel<half_t>, dim3(ceil_div(_tot, 256)), dim3(256), 0, s, a); \
+        else hipLaunchKernelGGL(kernel<float>, dim3(ceil_div(_tot, 256)), dim3(256), 0, s, a);     \
+        KCHECK();                                                                                  \
+    } while (0)
+
+static inline int vecn(int dtype) { return dtype == AIC_F16 ? 8 : 4; }
+
+void launch_sppf_pool(int dtype, const EltArgs& a, hipStream_t s) { ELT_LAUNCH(sppf_pool_kernel, (long)a.n * a.h * a.w * (a.c / vecn(dtype))); }
+void launch_upsample2x(int dtype, const EltArgs& a, hipStream_t s) { ELT_LAUNCH(upsample2x_kernel, (long)a.n * 4 * a.h * a.w * (a.c / vecn(dtype))); }
+void launch_maxpool3s2(int dtype, const EltArgs& a, hipStream_t s) {
+    const int oh = (a.h - 1) / 2 + 1, ow = (a.w - 1) / 2 + 1;
+    ELT_LAUNCH(maxpool3s2_kernel, (long)a.n * oh * ow * (a.c / vecn(dtype)));
+}
+void launch_avgpool(int dtype, const EltArgs& a, hipStream_t s) { ELT_LAUNCH(avgpool_kernel, (long)a.n * a.c); }
+void launch_l2norm(int dtype, const EltArgs& a, hipStream_t s) {
+    if (a.n <= 0) return;
+    if (dtype == AIC_F16) hipLaunchKernelGGL(l2norm_kernel<half_t>, dim3(ceil_div(a.n, 4)), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(l2norm_kernel<float>, dim3(ceil_div(a.n, 4)), dim3(256), 0, s, a);
+    KCHECK();
+}
+void launch_nchw_to_nhwc8(int dtype, const float* src, void* dst, int n, int h, int w, hipStream_t s) {
+    const long tot = (long)n * h * w;
+    if (tot <= 0) return;
+    if (dtype == AIC_F16) hipLaunchKernelGGL(nchw_to_nhwc8_kernel<half_t>, dim3(ceil_div(tot, 256)), dim3(256), 0, s, src, (half_t*)dst, n, h, w);
+    else hipLaunchKernelGGL(nchw_to_nhwc8_kernel<float>, dim3(ceil_div(tot, 256)), dim3(256), 0, s, src, (float*)dst, n, h, w);
+    KCHECK();
+}
+void launch_copy_f32(const float* src, float* dst, size_t count, hipStream_t s) {
+    if (!count) return;
+    hipLaunchKernelGGL(copy_f32_kernel, dim3(ceil_div((long)count, 256)), dim3(256), 0, s, src, dst, count);
+    KCHECK();
+}
+
+}  // namespace aic

@@ -1,0 +1,199 @@
+// kernels_det.hip -- YOLOv8 head decode (K3) + candidate sort + greedy NMS + un-letterbox (K4).
+//
+// In the reference all of this is inside the TensorRT engine's NMS plugin; only its four output
+// tensors are visible (src/detector/yolo_detector.py:44-54,108-112), followed on the host by the
+// score filter (:131-135) and scale_bboxes (src/utils/image_processing.py:141-183).  Semantics are
+// build decision D4, stated once in oracle/nets_oracle.py::nms:
+//   candidate  <=> max-class logit >= logit(conf)        (fp32 compare on the raw logit)
+//   order       = (logit descending, anchor index ascending)
+//   suppression = same label and IoU > iou_thresh, greedy, at most max_det survivors
+// Compiled with -ffp-contract=off so the IoU arithmetic rounds exactly like the oracle's NumPy.
+#include "kernels.hpp"
+
+namespace aic {
+
+// ---- decode: one thread per (image, anchor). DFL softmax expectation per side (wave-free: the 16
+// bins of a side sit in one thread's registers), arg-max class on raw logits.
+__global__ void decode_kernel(const DetArgs a) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)a.batch * a.n_anchors) return;
+    const int img = (int)(idx / a.n_anchors);
+    const int an = (int)(idx - (long)img * a.n_anchors);
+    int l = 0;
+#pragma unroll
+    for (int k = 1; k < 4; ++k)
+        if (k < a.n_levels && an >= a.lvl[k].a0) l = k;
+    const HeadLevel L = a.lvl[l];
+    const int cell = an - L.a0;
+    const int gy = cell / L.w, gx = cell - gy * L.w;
+    const size_t pix = (size_t)img * L.h * L.w + cell;
+    const float* d = L.box + pix * (4 * a.reg_max);
+    float dist[4];
+    for (int sd = 0; sd < 4; ++sd) {
+        const float* v = d + sd * a.reg_max;
+        float mx = v[0];
+        for (int k = 1; k < a.reg_max; ++k) mx = fmaxf(mx, v[k]);
+        float sum = 0.f, ex = 0.f;
+        for (int k = 0; k < a.reg_max; ++k) {
+            const float e = expf(v[k] - mx);
+            sum += e;
+            ex += e * (float)k;
+        }
+        dist[sd] = ex / sum;
+    }
+    const float cx = (float)gx + 0.5f, cy = (float)gy + 0.5f, st = (float)L.stride;
+    float* b = a.boxes + idx * 4;
+    b[0] = (cx - dist[0]) * st;
+    b[1] = (cy - dist[1]) * st;
+    b[2] = (cx + dist[2]) * st;
+    b[3] = (cy + dist[3]) * st;
+    const float* c = L.cls + pix * a.nc;
+    float best = c[0];
+    int arg = 0;
+    for (int k = 1; k < a.nc; ++k) {
+        const float v = c[k];
+        if (v > best) { best = v; arg = k; }   // first maximum wins, as np.argmax
+    }
+    a.max_logit[idx] = best;
+    a.labels[idx] = arg;
+}
+
+__device__ __forceinline__ unsigned int ordered_bits(float f) {
+    const unsigned int u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);   // monotone map float -> uint
+}
+
+__device__ __forceinline__ float iou_xyxy(const float4 p, const float4 q) {
+    const float iw = fmaxf(0.f, fminf(p.z, q.z) - fmaxf(p.x, q.x));
+    const float ih = fmaxf(0.f, fminf(p.w, q.w) - fmaxf(p.y, q.y));
+    const float inter = iw * ih;
+    const float area_p = (p.z - p.x) * (p.w - p.y);
+    const float area_q = (q.z - q.x) * (q.w - q.y);
+    return inter / fmaxf(area_p + area_q - inter, 1e-9f);
+}
+
+// ---- one block per image: select candidates, bitonic-sort their keys in LDS, greedy NMS against
+// the kept list (<= max_det boxes in LDS), write the four output tensors + un-letterboxed boxes.
+// Dynamic LDS: keys[P] (u64) | kept boxes[max_det] (float4) | kept labels[max_det] | flags[NT]
+constexpr int NMS_THREADS = 1024;
+
+__global__ __launch_bounds__(NMS_THREADS) void select_sort_nms_kernel(const DetArgs a, int P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);
+    float4* kbox = reinterpret_cast<float4*>(smem + (size_t)P * 8);
+    int* klab = reinterpret_cast<int*>(kbox + a.max_det);
+    int* flags = klab + a.max_det;
+    // counters live at the end of the dynamic region: a static __shared__ in front of it would shift
+    // the 16-byte alignment of the dynamic base (cdna_hip_programming.md Guideline 17)
+    int& s_count = flags[NMS_THREADS];
+    int& s_kept = flags[NMS_THREADS + 1];
+
+    const int img = blockIdx.x, t = threadIdx.x;
+    const float* ml = a.max_logit + (size_t)img * a.n_anchors;
+    if (t == 0) { s_count = 0; s_kept = 0; }
+    __syncthreads();
+    // 1. select (unordered append; the sort fixes the order)
+    for (int i = t; i < a.n_anchors; i += NMS_THREADS) {
+        const float v = ml[i];
+        if (v >= a.logit_thr) {
+            const int pos = atomicAdd(&s_count, 1);
+            keys[pos] = ((unsigned long long)ordered_bits(v) << 32) | (unsigned int)(0xFFFFFFFFu - (unsigned int)i);
+        }
+    }
+    __syncthreads();
+    const int n = s_count;
+    int p2 = 1;
+    while (p2 < n) p2 <<= 1;
+    for (int i = n + t; i < p2; i += NMS_THREADS) keys[i] = 0ull;   // sorts to the end
+    __syncthreads();
+    // 2. bitonic sort, descending
+    for (int k = 2; k <= p2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = t; i < p2; i += NMS_THREADS) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const unsigned long long x = keys[i], y = keys[ixj];
+                    const bool desc = (i & k) == 0;
+                    if (desc ? (x < y) : (x > y)) { keys[i] = y; keys[ixj] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (t == 0) a.n_cand[img] = n;
+    // 3. greedy NMS in chunks of NMS_THREADS candidates
+    const float4* boxes = reinterpret_cast<const float4*>(a.boxes) + (size_t)img * a.n_anchors;
+    const int* labels = a.labels + (size_t)img * a.n_anchors;
+    for (int c0 = 0; c0 < n; c0 += NMS_THREADS) {
+        if (s_kept >= a.max_det) break;
+        const int ci = c0 + t;
+        const bool have = ci < n;
+        int anchor = 0, lab = -1;
+        float4 bx = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (have) {
+            anchor = (int)(0xFFFFFFFFu - (unsigned int)(keys[ci] & 0xFFFFFFFFull));
+            bx = boxes[anchor];
+            lab = labels[anchor];
+        }
+        bool alive = have;
+        const int nk0 = s_kept;
+        for (int k = 0; k < nk0 && alive; ++k)
+            if (klab[k] == lab && iou_xyxy(kbox[k], bx) > a.iou_thr) alive = false;
+        flags[t] = alive ? 1 : 0;
+        __syncthreads();
+        const int lim = min(NMS_THREADS, n - c0);
+        for (int i = 0; i < lim; ++i) {
+            if (!flags[i]) continue;            // block-uniform (LDS broadcast)
+            const int slot = s_kept;            // uniform: only thread i updates it below, after the barrier
+            if (slot >= a.max_det) break;
+            if (t == i) {
+                kbox[slot] = bx;
+                klab[slot] = lab;
+                const size_t o = (size_t)img * a.max_det + slot;
+                reinterpret_cast<float4*>(a.out_boxes)[o] = bx;
+                a.out_scores[o] = 1.0f / (1.0f + expf(-ml[anchor]));
+                a.out_labels[o] = lab;
+                if (a.out_boxes_orig) {
+                    // image_processing.py:161-181: remove padding, divide by ratio, clip
+                    float4 ob;
+                    ob.x = fminf(fmaxf((bx.x - a.pad_w) / a.ratio, 0.f), (float)a.orig_w);
+                    ob.y = fminf(fmaxf((bx.y - a.pad_h) / a.ratio, 0.f), (float)a.orig_h);
+                    ob.z = fminf(fmaxf((bx.z - a.pad_w) / a.ratio, 0.f), (float)a.orig_w);
+                    ob.w = fminf(fmaxf((bx.w - a.pad_h) / a.ratio, 0.f), (float)a.orig_h);
+                    reinterpret_cast<float4*>(a.out_boxes_orig)[o] = ob;
+                }
+            }
+            __syncthreads();
+            if (t == i) s_kept = slot + 1;
+            if (t > i && flags[t] && lab == klab[slot] && iou_xyxy(kbox[slot], bx) > a.iou_thr) flags[t] = 0;
+            __syncthreads();
+        }
+        __syncthreads();
+    }
+    if (t == 0) a.num_dets[img] = min(s_kept, a.max_det);
+}
+
+void launch_decode(const DetArgs& a, hipStream_t s) {
+    const long tot = (long)a.batch * a.n_anchors;
+    if (tot <= 0) return;
+    hipLaunchKernelGGL(decode_kernel, dim3(ceil_div(tot, 128)), dim3(128), 0, s, a);
+    KCHECK();
+}
+
+void launch_select_sort_nms(const DetArgs& a, hipStream_t s) {
+    if (a.batch <= 0) return;
+    int P = 1;
+    while (P < a.n_anchors) P <<= 1;
+    const size_t lds = (size_t)P * 8 + (size_t)a.max_det * (16 + 4) + NMS_THREADS * 4 + 16;
+    AIC_REQUIRE(lds <= 160 * 1024 - 64, AIC_ERR_CAPACITY, "too many anchors / max_det for the NMS LDS budget");
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(select_sort_nms_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(select_sort_nms_kernel, dim3(a.batch), dim3(NMS_THREADS), lds, s, a, P);
+    KCHECK();
+}
+
+}  // namespace aic

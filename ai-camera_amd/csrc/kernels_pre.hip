@@ -1,0 +1,201 @@
+// kernels_pre.hip -- letterbox+normalise (K1) and crop+resize+normalise (K5), HBM-bound u8 work.
+//
+// Replaces letterbox / preprocess_yolo_input (src/utils/image_processing.py:7-70,73-102) and
+// _extract_image_crops + preprocess_reid_input (src/tracker/deepsort_tracker.py:143-159,
+// image_processing.py:105-138).  The u8 resize restates cv2.resize INTER_LINEAR for 8-bit images
+// (opencv-python 4.11: half-pixel centres, 11-bit fixed-point taps, the 2x2 area fast path when both
+// scales are exactly 2) bit for bit the way oracle/image_oracle.py states it -- SURVEY.md §7.1 D5.
+// Compiled with -ffp-contract=off: the coordinate arithmetic must round like NumPy's.
+//
+// One thread per output pixel; every thread reads its <= 4 source pixels straight from the u8
+// frame in HBM (rows are contiguous, neighbouring threads read neighbouring bytes) and writes one
+// 16-byte NHWC8 pixel (engine input) or three fp32 planes (API parity output).
+#include "kernels.hpp"
+
+#include <cmath>
+
+namespace aic {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+// ---- host: geometry of image_processing.py:33-67 (auto=False, scaleup=False as called at :92)
+static long py_round(double v) {   // Python round(): half to even
+    return (long)std::nearbyint(v);
+}
+
+LetterboxGeom letterbox_geometry(int h, int w, int out_h, int out_w) {
+    LetterboxGeom g{};
+    double rh = (double)out_h / h, rw = (double)out_w / w;
+    rh = rh < 1.0 ? rh : 1.0;
+    rw = rw < 1.0 ? rw : 1.0;
+    const double r = rh < rw ? rh : rw;
+    g.src_h = h, g.src_w = w, g.out_h = out_h, g.out_w = out_w;
+    g.unpad_h = (int)py_round(h * r);
+    g.unpad_w = (int)py_round(w * r);
+    const double dw = (out_w - g.unpad_w) / 2.0, dh = (out_h - g.unpad_h) / 2.0;
+    g.top = (int)py_round(dh - 0.1);
+    g.left = (int)py_round(dw - 0.1);
+    // bottom/right = round(d + 0.1); the output canvas is cropped/padded to out_h x out_w
+    g.ratio = (float)r;
+    g.pad_w = (float)dw;
+    g.pad_h = (float)dh;
+    return g;
+}
+
+struct Taps { int i0, i1, w0, w1; };
+
+// cv2 horizontal taps: clamp with the weight forced onto the surviving tap
+__device__ __forceinline__ Taps taps_x(int d, double scale, int n) {
+    float f = (float)(((double)d + 0.5) * scale - 0.5);
+    int s = (int)floorf(f);
+    f = f - (float)s;
+    if (s < 0) { f = 0.f; s = 0; }
+    if (s >= n - 1) { f = 0.f; s = n - 1; }
+    Taps t;
+    t.i0 = s;
+    t.i1 = min(s + 1, n - 1);
+    t.w0 = __float2int_rn((1.f - f) * 2048.f);
+    t.w1 = __float2int_rn(f * 2048.f);
+    return t;
+}
+// cv2 vertical taps: rows clipped, weights kept
+__device__ __forceinline__ Taps taps_y(int d, double scale, int n) {
+    float f = (float)(((double)d + 0.5) * scale - 0.5);
+    const int s = (int)floorf(f);
+    f = f - (float)s;
+    Taps t;
+    t.i0 = min(max(s, 0), n - 1);
+    t.i1 = min(max(s + 1, 0), n - 1);
+    t.w0 = __float2int_rn((1.f - f) * 2048.f);
+    t.w1 = __float2int_rn(f * 2048.f);
+    return t;
+}
+
+// Resample one output pixel (3 channels, BGR order as stored) from a u8 region.
+// region origin (x0,y0), size (sw,sh) inside a frame with row pitch `pitch` bytes.
+__device__ __forceinline__ void sample_px(const uint8_t* __restrict__ img, int pitch, int x0, int y0, int sw, int sh,
+                                          int dx, int dy, int dw, int dh, bool area2, double scale_x, double scale_y,
+                                          int out[3]) {
+    if (area2) {
+        const uint8_t* p0 = img + (size_t)(y0 + 2 * dy) * pitch + (size_t)(x0 + 2 * dx) * 3;
+        const uint8_t* p1 = p0 + pitch;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) out[c] = ((int)p0[c] + (int)p0[3 + c] + (int)p1[c] + (int)p1[3 + c] + 2) >> 2;
+        return;
+    }
+    const Taps tx = taps_x(dx, scale_x, sw);
+    const Taps ty = taps_y(dy, scale_y, sh);
+    const uint8_t* r0 = img + (size_t)(y0 + ty.i0) * pitch + (size_t)x0 * 3;
+    const uint8_t* r1 = img + (size_t)(y0 + ty.i1) * pitch + (size_t)x0 * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int h0 = (int)r0[tx.i0 * 3 + c] * tx.w0 + (int)r0[tx.i1 * 3 + c] * tx.w1;
+        const int h1 = (int)r1[tx.i0 * 3 + c] * tx.w0 + (int)r1[tx.i1 * 3 + c] * tx.w1;
+        out[c] = (((ty.w0 * (h0 >> 4)) >> 16) + ((ty.w1 * (h1 >> 4)) >> 16) + 2) >> 2;
+    }
+}
+
+__device__ __forceinline__ bool is_area2(int sw, int sh, int dw, int dh) { return sw == 2 * dw && sh == 2 * dh; }
+
+template <typename T>
+__device__ __forceinline__ void store_nhwc8(T* dst, float r, float g, float b) {
+    T o[8] = {(T)r, (T)g, (T)b, (T)0.f, (T)0.f, (T)0.f, (T)0.f, (T)0.f};
+    if constexpr (sizeof(T) == 2) {
+        *reinterpret_cast<half8*>(dst) = *reinterpret_cast<half8*>(o);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dst[e] = o[e];
+    }
+}
+
+// mode 0: fp32 NCHW planes; mode 1: NHWC8 of T
+template <typename T>
+__global__ void letterbox_kernel(const uint8_t* __restrict__ frames, int n, LetterboxGeom g, int mode, void* out) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long per = (long)g.out_h * g.out_w;
+    if (idx >= per * n) return;
+    const int img = (int)(idx / per);
+    const int p = (int)(idx - (long)img * per);
+    const int oy = p / g.out_w, ox = p - oy * g.out_w;
+    const int y = oy - g.top, x = ox - g.left;
+    int px[3] = {114, 114, 114};
+    if (y >= 0 && y < g.unpad_h && x >= 0 && x < g.unpad_w) {
+        const uint8_t* f = frames + (size_t)img * g.src_h * g.src_w * 3;
+        const double sx = 1.0 / ((double)g.unpad_w / (double)g.src_w);
+        const double sy = 1.0 / ((double)g.unpad_h / (double)g.src_h);
+        sample_px(f, g.src_w * 3, 0, 0, g.src_w, g.src_h, x, y, g.unpad_w, g.unpad_h,
+                  is_area2(g.src_w, g.src_h, g.unpad_w, g.unpad_h), sx, sy, px);
+    }
+    // BGR -> RGB, /255 in fp32 (image_processing.py:93-99)
+    const float r = (float)px[2] / 255.0f, gg = (float)px[1] / 255.0f, b = (float)px[0] / 255.0f;
+    if (mode == 0) {
+        float* o = reinterpret_cast<float*>(out) + (size_t)img * 3 * per + p;
+        o[0] = r; o[per] = gg; o[2 * per] = b;
+    } else {
+        store_nhwc8<T>(reinterpret_cast<T*>(out) + (size_t)idx * 8, r, gg, b);
+    }
+}
+
+template <typename T>
+__global__ void crop_resize_kernel(const uint8_t* __restrict__ frames, int fh, int fw, const float* __restrict__ boxes,
+                                   const int* __restrict__ frame_of, int n, const int* __restrict__ n_dev, int oh, int ow,
+                                   int mode, void* out, int* __restrict__ valid) {
+    const int crop = blockIdx.y;
+    const int live = n_dev ? min(*n_dev, n) : n;
+    const int per = oh * ow;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= per) return;
+    // deepsort_tracker.py:148-153: int() truncation towards zero, then clamp
+    int x1 = 0, y1 = 0, x2 = 0, y2 = 0;
+    if (crop < live) {
+        const float* b = boxes + (size_t)crop * 4;
+        const float lim = 1.0e9f;
+        x1 = (int)fminf(fmaxf(b[0], -lim), lim); y1 = (int)fminf(fmaxf(b[1], -lim), lim);
+        x2 = (int)fminf(fmaxf(b[2], -lim), lim); y2 = (int)fminf(fmaxf(b[3], -lim), lim);
+        x1 = max(0, x1); y1 = max(0, y1); x2 = min(fw, x2); y2 = min(fh, y2);
+    }
+    const bool ok = crop < live && x1 < x2 && y1 < y2;
+    if (p == 0 && valid) valid[crop] = ok ? 1 : 0;
+    const int oy = p / ow, ox = p - oy * ow;
+    float v[3] = {0.f, 0.f, 0.f};
+    if (ok) {
+        const int fi = frame_of ? frame_of[crop] : 0;
+        const uint8_t* f = frames + (size_t)fi * fh * fw * 3;
+        const int sw = x2 - x1, sh = y2 - y1;
+        const double sx = 1.0 / ((double)ow / (double)sw);
+        const double sy = 1.0 / ((double)oh / (double)sh);
+        int px[3];
+        sample_px(f, fw * 3, x1, y1, sw, sh, ox, oy, ow, oh, is_area2(sw, sh, ow, oh), sx, sy, px);
+        // image_processing.py:126-131: BGR->RGB, (x/255 - mean)/std in fp32
+        const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[c] = ((float)px[2 - c] / 255.0f - mean[c]) / stdv[c];
+    }
+    if (mode == 0) {
+        float* o = reinterpret_cast<float*>(out) + (size_t)crop * 3 * per + p;
+        o[0] = v[0]; o[per] = v[1]; o[2 * per] = v[2];
+    } else {
+        store_nhwc8<T>(reinterpret_cast<T*>(out) + ((size_t)crop * per + p) * 8, v[0], v[1], v[2]);
+    }
+}
+
+void launch_letterbox(const uint8_t* frames, int n, const LetterboxGeom& g, int mode, int dtype, void* out, hipStream_t s) {
+    const long tot = (long)n * g.out_h * g.out_w;
+    if (tot <= 0) return;
+    if (dtype == AIC_F16) hipLaunchKernelGGL(letterbox_kernel<half_t>, dim3(ceil_div(tot, 256)), dim3(256), 0, s, frames, n, g, mode, out);
+    else hipLaunchKernelGGL(letterbox_kernel<float>, dim3(ceil_div(tot, 256)), dim3(256), 0, s, frames, n, g, mode, out);
+    KCHECK();
+}
+
+void launch_crop_resize(const uint8_t* frames, int h, int w, const float* boxes, const int* frame_of, int n,
+                        const int* n_dev, int out_h, int out_w, int mode, int dtype, void* out, int* valid, hipStream_t s) {
+    if (n <= 0) return;
+    dim3 grid(ceil_div((long)out_h * out_w, 256), n);
+    if (dtype == AIC_F16)
+        hipLaunchKernelGGL(crop_resize_kernel<half_t>, grid, dim3(256), 0, s, frames, h, w, boxes, frame_of, n, n_dev, out_h, out_w, mode, out, valid);
+    else
+        hipLaunchKernelGGL(crop_resize_kernel<float>, grid, dim3(256), 0, s, frames, h, w, boxes, frame_of, n, n_dev, out_h, out_w, mode, out, valid);
+    KCHECK();
+}
+
+}  // namespace aic

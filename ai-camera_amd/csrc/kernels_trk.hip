@@ -1,0 +1,412 @@
+// kernels_trk.hip -- batched Kalman filter (K7, K8, K12), IoU cost (K10), cosine-min over the
+// per-track feature galleries (K9).  fp32 throughout, -ffp-contract=off.
+//
+// Reference arithmetic (all fp32, per track / per pair in Python loops):
+//   KalmanFilter.initiate/predict/project/update/gating_distance
+//       src/tracker/core/kalman_filter.py:55-83, 85-120, 122-151, 153-204, 206-249
+//   iou / iou_cost                      src/tracker/core/matching.py:13-106
+//   cosine_distance / appearance_cost   src/tracker/core/matching.py:109-217
+//
+// Noise terms follow NumPy 2.x scalar promotion exactly: std = fp32(weight) * h in
+// fp32, squared in fp64, rounded to fp32 once.  predict is bit-exact with the reference
+// (F P F^T has at most two non-zero terms per element and multi_dot evaluates F (P F^T));
+// project/update/gating go through a 4x4 Cholesky like LAPACK's potrf + trtrs / potrs and agree
+// to fp32 rounding.
+//
+// Layout: state SoA in HBM, mean[slot][8], cov[slot][64]; one wavefront (64 lanes = the 8x8
+// covariance) per track for predict/update, one thread per (track, detection) pair for gating/IoU.
+#include "kernels.hpp"
+
+namespace aic {
+
+__device__ __forceinline__ float sq64(float s) { return (float)((double)s * (double)s); }
+
+#define W_POS 0.05f       /* fp32(1/20)   kalman_filter.py:52  */
+#define W_VEL 0.00625f    /* fp32(1/160)  kalman_filter.py:53  */
+
+__device__ __forceinline__ float q_diag(int i, float h) {   // process noise, kalman_filter.py:99-112
+    if (i == 2) return (float)(1e-2 * 1e-2);
+    if (i == 6) return (float)(1e-5 * 1e-5);
+    return sq64((i < 4 ? W_POS : W_VEL) * h);
+}
+__device__ __forceinline__ float r_diag(int i, float h) {   // measurement noise, kalman_filter.py:136-143
+    if (i == 2) return (float)(1e-1 * 1e-1);
+    return sq64(W_POS * h);
+}
+
+__global__ void kf_initiate_kernel(const float* __restrict__ z, int n, float* mean, float* cov, const int* slots,
+                                   const int* zidx) {
+    const int k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (k >= n) return;
+    const int lane = threadIdx.x & 63, i = lane >> 3, j = lane & 7;
+    const int slot = slots ? slots[k] : k;
+    const float* zz = z + (size_t)(zidx ? zidx[k] : k) * 4;
+    const float h = zz[3];
+    float v = 0.f;
+    if (i == j) {   // kalman_filter.py:72-82
+        if (i == 2) v = (float)(1e-2 * 1e-2);
+        else if (i == 6) v = (float)(1e-5 * 1e-5);
+        else v = sq64((i < 4 ? 0.1f : 0.0625f) * h);
+    }
+    cov[(size_t)slot * 64 + lane] = v;
+    if (j == 0) mean[(size_t)slot * 8 + i] = i < 4 ? zz[i] : 0.f;
+}
+
+__global__ void kf_predict_kernel(float* mean, float* cov, const int* slots, int n) {
+    const int k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (k >= n) return;
+    const int lane = threadIdx.x & 63, i = lane >> 3, j = lane & 7;
+    const int slot = slots ? slots[k] : k;
+    float* P = cov + (size_t)slot * 64;
+    float* m = mean + (size_t)slot * 8;
+    const float h = m[3];
+    // T1 = P F^T ; T2 = F T1   (np.linalg.multi_dot picks F (P F^T) for equal cost)
+    float t1 = P[i * 8 + j];
+    if (j < 4) t1 = t1 + P[i * 8 + j + 4];
+    float t2 = t1;
+    if (i < 4) {
+        float u = P[(i + 4) * 8 + j];
+        if (j < 4) u = u + P[(i + 4) * 8 + j + 4];
+        t2 = t1 + u;
+    }
+    if (i == j) t2 = t2 + q_diag(i, h);
+    float mi = 0.f;
+    if (j == 0) { mi = m[i]; if (i < 4) mi = mi + m[i + 4]; }
+    P[i * 8 + j] = t2;          // same wavefront: every load above has retired before these stores
+    if (j == 0) m[i] = mi;
+}
+
+// S = H P H^T + R (4x4, symmetric) and its lower Cholesky factor. Returns false if not PD.
+__device__ __forceinline__ void innovation_cov(const float* P, float h, float S[4][4]) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) S[a][b] = P[a * 8 + b] + (a == b ? r_diag(a, h) : 0.f);
+}
+template <int N>
+__device__ __forceinline__ bool cholesky(const float S[4][4], float L[4][4]) {
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        float d = S[j][j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) d = d - L[j][k] * L[j][k];
+        if (!(d > 0.f)) ok = false;
+        const float ljj = sqrtf(d);
+        L[j][j] = ljj;
+#pragma unroll
+        for (int i = j + 1; i < N; ++i) {
+            float s = S[i][j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) s = s - L[i][k] * L[j][k];
+            L[i][j] = s / ljj;
+        }
+    }
+    return ok;
+}
+template <int N>
+__device__ __forceinline__ void fwd_solve(const float L[4][4], const float b[4], float y[4]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        float s = b[i];
+#pragma unroll
+        for (int k = 0; k < i; ++k) s = s - L[i][k] * y[k];
+        y[i] = s / L[i][i];
+    }
+}
+__device__ __forceinline__ void bwd_solve(const float L[4][4], const float y[4], float x[4]) {   // L^T x = y
+#pragma unroll
+    for (int i = 3; i >= 0; --i) {
+        float s = y[i];
+#pragma unroll
+        for (int k = i + 1; k < 4; ++k) s = s - L[k][i] * x[k];
+        x[i] = s / L[i][i];
+    }
+}
+
+__global__ void kf_project_kernel(const float* __restrict__ mean, const float* __restrict__ cov, int n, float* pmean, float* pcov) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const float* P = cov + (size_t)k * 64;
+    const float* m = mean + (size_t)k * 8;
+    float S[4][4];
+    innovation_cov(P, m[3], S);
+    for (int a = 0; a < 4; ++a) {
+        pmean[(size_t)k * 4 + a] = m[a];
+        for (int b = 0; b < 4; ++b) pcov[(size_t)k * 16 + a * 4 + b] = S[a][b];
+    }
+}
+
+// grid.x = tracks, threads over measurements.
+__global__ void kf_gating_kernel(const float* __restrict__ mean, const float* __restrict__ cov, const int* __restrict__ slots,
+                                 int n, const float* __restrict__ zs, int m, int shared_z, int only_position, float* d2) {
+    const int t = blockIdx.x;
+    if (t >= n) return;
+    const int slot = slots ? slots[t] : t;
+    const float* P = cov + (size_t)slot * 64;
+    const float* mu = mean + (size_t)slot * 8;
+    float S[4][4], L[4][4];
+    innovation_cov(P, mu[3], S);
+    const bool ok = only_position ? cholesky<2>(S, L) : cholesky<4>(S, L);
+    for (int j = threadIdx.x; j < m; j += blockDim.x) {
+        const float* z = zs + (size_t)(shared_z ? j : (size_t)t * m + j) * 4;
+        float d[4], y[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) d[a] = z[a] - mu[a];
+        float acc;
+        if (only_position) {
+            fwd_solve<2>(L, d, y);
+            acc = y[0] * y[0] + y[1] * y[1];
+        } else {
+            fwd_solve<4>(L, d, y);
+            acc = y[0] * y[0];
+            acc = acc + y[1] * y[1];
+            acc = acc + y[2] * y[2];
+            acc = acc + y[3] * y[3];
+        }
+        d2[(size_t)t * m + j] = ok ? acc : __builtin_inff();   // kalman_filter.py:241-247
+    }
+}
+
+// One wavefront per (track, measurement) pair: lane (i,j) owns P[i][j].
+__global__ void kf_update_kernel(float* mean, float* cov, const int* slots, const float* __restrict__ z,
+                                 const int* __restrict__ zidx, int n, float* out_tlwh) {
+    const int k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (k >= n) return;
+    const int lane = threadIdx.x & 63, i = lane >> 3, j = lane & 7;
+    const int slot = slots ? slots[k] : k;
+    float* P = cov + (size_t)slot * 64;
+    float* m = mean + (size_t)slot * 8;
+    const float* zz = z + (size_t)(zidx ? zidx[k] : k) * 4;
+    float S[4][4], L[4][4];
+    innovation_cov(P, m[3], S);
+    cholesky<4>(S, L);
+    // rows i and j of K = (S^-1 (P H^T)^T)^T, kalman_filter.py:185-190
+    float bi[4], bj[4], y[4], Ki[4], Kj[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) { bi[a] = P[i * 8 + a]; bj[a] = P[j * 8 + a]; }
+    fwd_solve<4>(L, bi, y); bwd_solve(L, y, Ki);
+    fwd_solve<4>(L, bj, y); bwd_solve(L, y, Kj);
+    // P - K (S K^T), kalman_filter.py:201-202
+    float acc = 0.f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        float u = 0.f;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) u = u + S[a][b] * Kj[b];
+        acc = acc + Ki[a] * u;
+    }
+    const float pij = P[i * 8 + j] - acc;
+    // mean + K (z - H mean), kalman_filter.py:193-196
+    float mi = m[i];
+    {
+        float dot = 0.f;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) dot = dot + Ki[a] * (zz[a] - m[a]);
+        mi = mi + dot;
+    }
+    P[i * 8 + j] = pij;
+    if (j == 0) m[i] = mi;
+    if (out_tlwh) {   // Track.to_tlwh of the updated state, track.py:133-151
+        const float cx = __shfl(mi, 0), cy = __shfl(mi, 8), ar = __shfl(mi, 16), hh = __shfl(mi, 24);
+        if (lane == 0) {
+            float w = 0.f, h2 = hh;
+            if (hh > 0.f) w = ar * hh; else h2 = fmaxf(0.f, hh);
+            float* o = out_tlwh + (size_t)k * 4;
+            o[0] = cx - w / 2.0f; o[1] = cy - h2 / 2.0f; o[2] = w; o[3] = h2;
+        }
+    }
+}
+
+// 1 - IoU in tlwh (matching.py:13-106). Track boxes either given or derived from the state means.
+__global__ void iou_cost_kernel(const float* __restrict__ trk_tlwh, const float* __restrict__ mean, const int* __restrict__ slots,
+                                int t, const float* __restrict__ det, int n, float* cost) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= t * n) return;
+    const int ti = idx / n, di = idx - ti * n;
+    float bx, by, bw, bh;
+    if (trk_tlwh) {
+        bx = trk_tlwh[ti * 4], by = trk_tlwh[ti * 4 + 1], bw = trk_tlwh[ti * 4 + 2], bh = trk_tlwh[ti * 4 + 3];
+    } else {
+        const float* m = mean + (size_t)(slots ? slots[ti] : ti) * 8;
+        float w = 0.f, h = m[3];
+        if (h > 0.f) w = m[2] * h; else h = fmaxf(0.f, h);
+        bx = m[0] - w / 2.0f; by = m[1] - h / 2.0f; bw = w; bh = h;
+    }
+    const float* c = det + (size_t)di * 4;
+    const float brx = bx + bw, bry = by + bh, crx = c[0] + c[2], cry = c[1] + c[3];
+    const float iw = fmaxf(0.f, fminf(brx, crx) - fmaxf(bx, c[0]));
+    const float ih = fmaxf(0.f, fminf(bry, cry) - fmaxf(by, c[1]));
+    const float inter = iw * ih;
+    const float uni = bw * bh + c[2] * c[3] - inter;
+    cost[idx] = 1.0f - inter / fmaxf(uni, 1e-7f);
+}
+
+__global__ void fill_kernel(float* p, float v, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// rows / max(||row||, 1e-7)  (matching.py:126-130); one wavefront per row.
+__global__ void normalize_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int n, int dim) {
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const int lane = threadIdx.x & 63;
+    const float* s = src + (size_t)row * dim;
+    float ss = 0.f;
+    for (int c = lane; c < dim; c += 64) ss = ss + s[c] * s[c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss = ss + __shfl_xor(ss, o);
+    const float nrm = fmaxf(sqrtf(ss), 1e-7f);
+    for (int c = lane; c < dim; c += 64) dst[(size_t)row * dim + c] = s[c] / nrm;
+}
+
+// cost[t][n] = min over gallery rows g of max(0, 1 - <gal_n[g], det_n[n]>)   (matching.py:136-141,207)
+// grid (tracks, gallery chunks of 16 rows); each wave normalises 4 gallery rows in registers, then
+// streams the (L2-resident) normalised detection features past them. atomicMin on the fp32 bit
+// pattern is order-preserving because every value is >= +0.
+template <int NPER>
+__global__ __launch_bounds__(256) void cosine_min_kernel(const float* __restrict__ gal, const int* __restrict__ slots,
+                                                         const int* __restrict__ glen, int gmax, int dim,
+                                                         const float* __restrict__ det_n, const unsigned char* __restrict__ has_feat,
+                                                         int n, float* cost) {
+    const int t = blockIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int g0 = blockIdx.y * 16 + wv * 4;
+    const int len = glen[t];
+    if (g0 >= len) return;
+    const float* base = gal + ((size_t)slots[t] * gmax) * dim;
+    float a[4][NPER];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const bool live = g0 + r < len;
+        float ss = 0.f;
+#pragma unroll
+        for (int k = 0; k < NPER; ++k) {
+            const int c = k * 64 + lane;
+            const float v = (live && c < dim) ? base[(size_t)(g0 + r) * dim + c] : 0.f;
+            a[r][k] = v;
+            ss = ss + v * v;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ss = ss + __shfl_xor(ss, o);
+        const float nrm = fmaxf(sqrtf(ss), 1e-7f);
+#pragma unroll
+        for (int k = 0; k < NPER; ++k) a[r][k] = a[r][k] / nrm;
+    }
+    unsigned int* out = reinterpret_cast<unsigned int*>(cost) + (size_t)t * n;
+    for (int d = 0; d < n; ++d) {
+        if (has_feat && !has_feat[d]) continue;
+        float b[NPER];
+#pragma unroll
+        for (int k = 0; k < NPER; ++k) {
+            const int c = k * 64 + lane;
+            b[k] = c < dim ? det_n[(size_t)d * dim + c] : 0.f;
+        }
+        float dot[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < NPER; ++k) s = s + a[r][k] * b[k];
+            dot[r] = s;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dot[r] = dot[r] + __shfl_xor(dot[r], o);
+        }
+        if (lane == 0) {
+            float best = 3.0e38f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (g0 + r < len) {
+                    float dist = 1.0f - dot[r];
+                    dist = dist > 0.f ? dist : 0.f;
+                    best = fminf(best, dist);
+                }
+            }
+            atomicMin(out + d, __float_as_uint(best));
+        }
+    }
+}
+
+// gallery[slot][pos] <- feat[det]   (track.py:70-74; FIFO realised as a ring, the host keeps heads)
+__global__ void gallery_append_kernel(float* gal, int gmax, int dim, const int* __restrict__ slot, const int* __restrict__ pos,
+                                      const int* __restrict__ det, const float* __restrict__ feat, int count) {
+    const int k = blockIdx.x;
+    if (k >= count) return;
+    float* dst = gal + ((size_t)slot[k] * gmax + pos[k]) * dim;
+    const float* src = feat + (size_t)det[k] * dim;
+    for (int c = threadIdx.x; c < dim; c += blockDim.x) dst[c] = src[c];
+}
+
+// ------------------------------------------------------------------------------------------------
+void launch_kf_initiate(const float* z, int n, float* mean, float* cov, const int* slots, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(kf_initiate_kernel, dim3(ceil_div(n, 4)), dim3(256), 0, s, z, n, mean, cov, slots, (const int*)nullptr);
+    KCHECK();
+}
+void launch_kf_initiate_idx(const float* z, const int* zidx, int n, float* mean, float* cov, const int* slots, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(kf_initiate_kernel, dim3(ceil_div(n, 4)), dim3(256), 0, s, z, n, mean, cov, slots, zidx);
+    KCHECK();
+}
+void launch_kf_predict(float* mean, float* cov, const int* slots, int n, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(kf_predict_kernel, dim3(ceil_div(n, 4)), dim3(256), 0, s, mean, cov, slots, n);
+    KCHECK();
+}
+void launch_kf_project(const float* mean, const float* cov, int n, float* pmean, float* pcov, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(kf_project_kernel, dim3(ceil_div(n, 64)), dim3(64), 0, s, mean, cov, n, pmean, pcov);
+    KCHECK();
+}
+void launch_kf_update(float* mean, float* cov, const int* slots, const float* z, const int* zidx, int n, float* out_tlwh, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(kf_update_kernel, dim3(ceil_div(n, 4)), dim3(256), 0, s, mean, cov, slots, z, zidx, n, out_tlwh);
+    KCHECK();
+}
+void launch_kf_gating(const float* mean, const float* cov, const int* slots, int n, const float* zs, int m, int shared_z,
+                      int only_position, float* d2, hipStream_t s) {
+    if (n <= 0 || m <= 0) return;
+    hipLaunchKernelGGL(kf_gating_kernel, dim3(n), dim3(64), 0, s, mean, cov, slots, n, zs, m, shared_z, only_position, d2);
+    KCHECK();
+}
+void launch_iou_cost(const float* trk_tlwh, const float* mean, const int* slots, int t, const float* det_tlwh, int n, float* cost, hipStream_t s) {
+    if (t <= 0 || n <= 0) return;
+    hipLaunchKernelGGL(iou_cost_kernel, dim3(ceil_div((long)t * n, 256)), dim3(256), 0, s, trk_tlwh, mean, slots, t, det_tlwh, n, cost);
+    KCHECK();
+}
+void launch_fill(float* p, float v, size_t n, hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(fill_kernel, dim3(ceil_div((long)n, 256)), dim3(256), 0, s, p, v, n);
+    KCHECK();
+}
+void launch_normalize_rows(const float* src, float* dst, int n, int dim, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(normalize_rows_kernel, dim3(ceil_div(n, 4)), dim3(256), 0, s, src, dst, n, dim);
+    KCHECK();
+}
+void launch_cosine_min(const float* gal, const int* slots, const int* glen, int t, int gmax, int dim, const float* det_n,
+                       const unsigned char* has_feat, int n, float* cost, hipStream_t s) {
+    if (t <= 0 || n <= 0 || gmax <= 0) return;
+    dim3 grid(t, ceil_div(gmax, 16));
+    AIC_REQUIRE(dim <= 1024, AIC_ERR_CAPACITY, "feature dimension above 1024 is not supported");
+#define COS_LAUNCH(NP) hipLaunchKernelGGL(cosine_min_kernel<NP>, grid, dim3(256), 0, s, gal, slots, glen, gmax, dim, det_n, has_feat, n, cost)
+    if (dim <= 64) COS_LAUNCH(1);
+    else if (dim <= 128) COS_LAUNCH(2);
+    else if (dim <= 256) COS_LAUNCH(4);
+    else if (dim <= 512) COS_LAUNCH(8);
+    else COS_LAUNCH(16);
+#undef COS_LAUNCH
+    KCHECK();
+}
+void launch_gallery_append(float* gal, int gmax, int dim, const int* slot, const int* pos, const int* det, const float* feat,
+                           int count, hipStream_t s) {
+    if (count <= 0) return;
+    hipLaunchKernelGGL(gallery_append_kernel, dim3(count), dim3(128), 0, s, gal, gmax, dim, slot, pos, det, feat, count);
+    KCHECK();
+}
+
+}  // namespace aic

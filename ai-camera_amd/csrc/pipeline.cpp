@@ -1,0 +1,283 @@
+// pipeline.cpp -- the timed loop body of the reference (detect + track,
+// src/aicamera_tracker.py:169-207) over frames resident in HBM.
+//
+// Frame-independent work (letterbox, YOLO, decode+NMS, crop+resize, ReID) is issued for `batch`
+// frames per launch group on the device's main stream; association is a per-stream recurrence and
+// runs strictly frame by frame on the tracker stream + host (tracker.cpp).  Two chunk contexts
+// ping-pong so that the launch group of chunk k+1 is already queued on the GPU while the host walks
+// the frames of chunk k.
+//
+// inject = 1: the seeded engines cannot "see" the planted persons, so the
+// detector runs in full on every frame (its outputs are returned) while crop/ReID/association
+// consume the planted boxes handed over with aic_pipeline_inject.  inject = 0: the detector's own
+// boxes feed the tracker (one extra host round trip per chunk for the order-preserving filter of
+// src/tracker/deepsort_tracker.py:88-101).
+#include "engine.hpp"
+#include "tracker.hpp"
+
+#include <algorithm>
+
+namespace aic {
+
+struct FrameDets {
+    int n = 0, crop0 = 0;
+    std::vector<float> tlwh, xyxy, conf;
+    std::vector<int32_t> cls;
+};
+
+struct Chunk {
+    int frames = 0, first_slot = 0, n_crops = 0;
+    PinBuf<float> h_boxes;
+    PinBuf<int> h_frame_of, h_valid;
+    DevBuf<float> d_boxes, d_emb;
+    DevBuf<int> d_frame_of, d_valid;
+    PinBuf<int> h_numdets, h_labels;
+    PinBuf<float> h_detboxes, h_scores;
+    std::vector<FrameDets> dets;
+    hipEvent_t done = nullptr;
+};
+
+struct Pipeline {
+    Device* dev;
+    Model* yolo;
+    Model* reid;
+    aic_pipeline_params prm;
+    std::unique_ptr<aic_tracker> trk_handle;
+    Tracker& trk;
+    LetterboxGeom geom;
+    size_t frame_bytes;
+    DevBuf<uint8_t> ring;
+    std::vector<int> inj_count, inj_cls;
+    std::vector<float> inj_boxes, inj_conf;
+    Chunk ck[2];
+    int dim;
+    std::vector<float> last_emb;
+    int last_emb_n = 0;
+
+    Pipeline(Model* y, Model* r, const aic_pipeline_params& p)
+        : dev(y->dev), yolo(y), reid(r), prm(p), trk_handle(new aic_tracker(*y->dev, p.tracker)), trk(trk_handle->t) {
+        AIC_REQUIRE(y->kind == KIND_YOLO && r->kind == KIND_REID, AIC_ERR_INVALID, "pipeline needs a YOLO and a ReID engine");
+        AIC_REQUIRE(y->dev == r->dev, AIC_ERR_INVALID, "engines live on different devices");
+        AIC_REQUIRE(p.frame_h > 0 && p.frame_w > 0 && p.batch > 0 && p.ring_frames >= p.batch && p.max_persons > 0,
+                    AIC_ERR_INVALID, "bad pipeline geometry");
+        AIC_REQUIRE(p.batch <= y->max_items, AIC_ERR_CAPACITY, "batch exceeds the YOLO engine's max_items");
+        AIC_REQUIRE((long)p.batch * p.max_persons <= r->max_items, AIC_ERR_CAPACITY,
+                    "batch * max_persons exceeds the ReID engine's max_items");
+        AIC_REQUIRE(p.max_det > 0 && p.max_det <= y->max_det_cap, AIC_ERR_CAPACITY, "max_det out of range");
+        dev->use();
+        geom = letterbox_geometry(p.frame_h, p.frame_w, y->in_h, y->in_w);
+        frame_bytes = (size_t)p.frame_h * p.frame_w * 3;
+        ring.alloc(frame_bytes * p.ring_frames);
+        dim = r->out_dim;
+        inj_count.assign(p.ring_frames, 0);
+        inj_boxes.assign((size_t)p.ring_frames * p.max_persons * 4, 0.f);
+        inj_conf.assign((size_t)p.ring_frames * p.max_persons, 0.f);
+        inj_cls.assign((size_t)p.ring_frames * p.max_persons, 0);
+        const size_t maxc = (size_t)p.batch * p.max_persons;
+        for (Chunk& c : ck) {
+            c.h_boxes.alloc(maxc * 4), c.h_frame_of.alloc(maxc), c.h_valid.alloc(maxc);
+            c.d_boxes.alloc(maxc * 4), c.d_frame_of.alloc(maxc), c.d_valid.alloc(maxc), c.d_emb.alloc(maxc * dim);
+            c.h_numdets.alloc(p.batch), c.h_labels.alloc((size_t)p.batch * p.max_det);
+            c.h_detboxes.alloc((size_t)p.batch * p.max_det * 4), c.h_scores.alloc((size_t)p.batch * p.max_det);
+            c.dets.resize(p.batch);
+            HIP_CHECK(hipEventCreateWithFlags(&c.done, hipEventDisableTiming));
+        }
+    }
+    ~Pipeline() {
+        for (Chunk& c : ck)
+            if (c.done) (void)hipEventDestroy(c.done);
+    }
+
+    bool tracked_class(int c) const { return c >= 0 && c < 128 && ((prm.track_class_mask[c >> 6] >> (c & 63)) & 1ull); }
+
+    // deepsort_tracker.py:88-101: order-preserving confidence / class filter (+ capacity cap)
+    void collect(FrameDets& fd, int n, const float* boxes_xyxy, const float* conf, const int* cls) {
+        fd.n = 0;
+        fd.tlwh.clear(), fd.xyxy.clear(), fd.conf.clear(), fd.cls.clear();
+        for (int i = 0; i < n && fd.n < prm.max_persons; ++i) {
+            if (!(conf[i] >= prm.min_confidence) || !tracked_class(cls[i])) continue;
+            const float* b = boxes_xyxy + (size_t)i * 4;
+            fd.tlwh.insert(fd.tlwh.end(), {b[0], b[1], b[2] - b[0], b[3] - b[1]});   // deepsort_tracker.py:185-186
+            fd.xyxy.insert(fd.xyxy.end(), b, b + 4);                                    // crops use the xyxy box (:148)
+            fd.conf.push_back(conf[i]);
+            fd.cls.push_back(cls[i]);
+            ++fd.n;
+        }
+    }
+
+    void stage_a(Chunk& c, int slot, int frames) {
+        hipStream_t s = dev->s_main;
+        c.frames = frames, c.first_slot = slot;
+        const uint8_t* f0 = ring.p + (size_t)slot * frame_bytes;
+        {
+            Prof pr(*dev, PROF_LETTERBOX, s, 0, (double)frames * ((double)frame_bytes + 16.0 * yolo->in_h * yolo->in_w));
+            launch_letterbox(f0, frames, geom, 1, yolo->dtype, yolo->input(), s);
+        }
+        yolo->run(frames, s);
+        yolo->decode_nms(frames, prm.conf_thresh, prm.iou_thresh, prm.max_det, &geom, s);
+        HIP_CHECK(hipMemcpyAsync(c.h_numdets.p, yolo->d_numdets.p, (size_t)frames * 4, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipMemcpyAsync(c.h_detboxes.p, yolo->d_out_boxes_orig.p, (size_t)frames * prm.max_det * 16, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipMemcpyAsync(c.h_scores.p, yolo->d_out_scores.p, (size_t)frames * prm.max_det * 4, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipMemcpyAsync(c.h_labels.p, yolo->d_out_labels.p, (size_t)frames * prm.max_det * 4, hipMemcpyDeviceToHost, s));
+        if (!prm.inject) HIP_CHECK(hipStreamSynchronize(s));
+        // detection set handed to ReID + association
+        int nc = 0;
+        for (int f = 0; f < frames; ++f) {
+            FrameDets& fd = c.dets[f];
+            if (prm.inject) {
+                const int sl = slot + f;
+                collect(fd, inj_count[sl], inj_boxes.data() + (size_t)sl * prm.max_persons * 4,
+                        inj_conf.data() + (size_t)sl * prm.max_persons, inj_cls.data() + (size_t)sl * prm.max_persons);
+            } else {
+                const int nd = std::min(c.h_numdets.p[f], prm.max_det);
+                collect(fd, nd, c.h_detboxes.p + (size_t)f * prm.max_det * 4, c.h_scores.p + (size_t)f * prm.max_det,
+                        c.h_labels.p + (size_t)f * prm.max_det);
+            }
+            fd.crop0 = nc;
+            for (int i = 0; i < fd.n; ++i) {
+                std::copy(fd.xyxy.begin() + i * 4, fd.xyxy.begin() + i * 4 + 4, c.h_boxes.p + (size_t)(nc + i) * 4);
+                c.h_frame_of.p[nc + i] = f;
+            }
+            nc += fd.n;
+        }
+        c.n_crops = nc;
+        if (nc) {
+            HIP_CHECK(hipMemcpyAsync(c.d_boxes.p, c.h_boxes.p, (size_t)nc * 16, hipMemcpyHostToDevice, s));
+            HIP_CHECK(hipMemcpyAsync(c.d_frame_of.p, c.h_frame_of.p, (size_t)nc * 4, hipMemcpyHostToDevice, s));
+            {
+                Prof pr(*dev, PROF_CROP, s, 0, (double)nc * reid->in_h * reid->in_w * 19);
+                launch_crop_resize(f0, prm.frame_h, prm.frame_w, c.d_boxes.p, c.d_frame_of.p, nc, nullptr, reid->in_h,
+                                   reid->in_w, 1, reid->dtype, reid->input(), c.d_valid.p, s);
+            }
+            reid->run(nc, s);
+            HIP_CHECK(hipMemcpyAsync(c.d_emb.p, reid->embeddings(), (size_t)nc * dim * 4, hipMemcpyDeviceToDevice, s));
+            HIP_CHECK(hipMemcpyAsync(c.h_valid.p, c.d_valid.p, (size_t)nc * 4, hipMemcpyDeviceToHost, s));
+        }
+        HIP_CHECK(hipEventRecord(c.done, s));
+    }
+
+    void stage_b(Chunk& c, int out_base, int32_t* n_tracks, int32_t* tracks6, float* track_conf, int32_t* n_dets,
+                 float* det_boxes, float* det_scores, int32_t* det_labels) {
+        HIP_CHECK(hipEventSynchronize(c.done));
+        std::vector<uint8_t> has;
+        for (int f = 0; f < c.frames; ++f) {
+            FrameDets& fd = c.dets[f];
+            has.assign(fd.n, 1);
+            for (int i = 0; i < fd.n; ++i) has[i] = c.h_valid.p[fd.crop0 + i] ? 1 : 0;   // empty crop -> feature None
+            trk.predict();
+            trk.update(fd.tlwh.data(), fd.conf.data(), fd.cls.data(), fd.n ? c.d_emb.p + (size_t)fd.crop0 * dim : nullptr,
+                       AIC_DEVICE, has.data(), fd.n, dim);
+            const int o = out_base + f;
+            if (n_tracks) n_tracks[o] = (int32_t)trk.outputs.size();
+            for (size_t k = 0; k < trk.outputs.size() && (int)k < prm.max_persons; ++k) {
+                const TrackOut& t = trk.outputs[k];
+                if (tracks6) {
+                    int32_t* r = tracks6 + ((size_t)o * prm.max_persons + k) * 6;
+                    r[0] = t.x1, r[1] = t.y1, r[2] = t.x2, r[3] = t.y2, r[4] = t.id, r[5] = t.cls;
+                }
+                if (track_conf) track_conf[(size_t)o * prm.max_persons + k] = t.conf;
+            }
+            if (n_dets) n_dets[o] = c.h_numdets.p[f];
+            const size_t md = prm.max_det;
+            if (det_boxes) std::copy(c.h_detboxes.p + f * md * 4, c.h_detboxes.p + (f + 1) * md * 4, det_boxes + (size_t)o * md * 4);
+            if (det_scores) std::copy(c.h_scores.p + f * md, c.h_scores.p + (f + 1) * md, det_scores + (size_t)o * md);
+            if (det_labels) std::copy(c.h_labels.p + f * md, c.h_labels.p + (f + 1) * md, det_labels + (size_t)o * md);
+            if (f == c.frames - 1) {
+                last_emb_n = fd.n;
+                last_emb.resize((size_t)fd.n * dim);
+                if (fd.n) {
+                    HIP_CHECK(hipMemcpy(last_emb.data(), c.d_emb.p + (size_t)fd.crop0 * dim, last_emb.size() * 4, hipMemcpyDeviceToHost));
+                }
+            }
+        }
+    }
+
+    void run(int slot, int count, int32_t* n_tracks, int32_t* tracks6, float* track_conf, int32_t* n_dets, float* det_boxes,
+             float* det_scores, int32_t* det_labels) {
+        AIC_REQUIRE(slot >= 0 && count >= 0 && slot + count <= prm.ring_frames, AIC_ERR_INVALID, "slot range outside the ring");
+        dev->use();
+        const int nchunks = ceil_div(count, prm.batch);
+        if (!nchunks) return;
+        auto span = [&](int k) { return std::min(prm.batch, count - k * prm.batch); };
+        stage_a(ck[0], slot, span(0));
+        for (int k = 0; k < nchunks; ++k) {
+            if (k + 1 < nchunks) stage_a(ck[(k + 1) & 1], slot + (k + 1) * prm.batch, span(k + 1));
+            stage_b(ck[k & 1], k * prm.batch, n_tracks, tracks6, track_conf, n_dets, det_boxes, det_scores, det_labels);
+        }
+    }
+};
+
+}  // namespace aic
+
+using namespace aic;
+
+struct aic_pipeline { Pipeline p; aic_pipeline(Model* y, Model* r, const aic_pipeline_params& q) : p(y, r, q) {} };
+
+extern "C" {
+
+int aic_pipeline_create(aic_model* yolo, aic_model* reid, const aic_pipeline_params* p, aic_pipeline** out) {
+    return guarded([&] {
+        AIC_REQUIRE(yolo && reid && p && out, AIC_ERR_INVALID, "NULL argument");
+        *out = new aic_pipeline(&yolo->m, &reid->m, *p);
+    });
+}
+
+int aic_pipeline_destroy(aic_pipeline* p) {
+    return guarded([&] {
+        if (p) { p->p.dev->use(); (void)hipDeviceSynchronize(); }
+        delete p;
+    });
+}
+
+int aic_pipeline_upload(aic_pipeline* p, int slot, const uint8_t* frames, int count) {
+    return guarded([&] {
+        AIC_REQUIRE(p && frames && count >= 0, AIC_ERR_INVALID, "bad argument");
+        Pipeline& q = p->p;
+        AIC_REQUIRE(slot >= 0 && slot + count <= q.prm.ring_frames, AIC_ERR_INVALID, "slot range outside the ring");
+        q.dev->use();
+        HIP_CHECK(hipMemcpy(q.ring.p + (size_t)slot * q.frame_bytes, frames, (size_t)count * q.frame_bytes, hipMemcpyHostToDevice));
+    });
+}
+
+int aic_pipeline_inject(aic_pipeline* p, int slot, int count, const int32_t* counts, const float* boxes, const float* conf,
+                        const int32_t* cls) {
+    return guarded([&] {
+        AIC_REQUIRE(p && counts && boxes && conf && cls && count >= 0, AIC_ERR_INVALID, "bad argument");
+        Pipeline& q = p->p;
+        AIC_REQUIRE(slot >= 0 && slot + count <= q.prm.ring_frames, AIC_ERR_INVALID, "slot range outside the ring");
+        const int mp = q.prm.max_persons;
+        for (int f = 0; f < count; ++f) {
+            AIC_REQUIRE(counts[f] >= 0 && counts[f] <= mp, AIC_ERR_CAPACITY, "injected count exceeds max_persons");
+            q.inj_count[slot + f] = counts[f];
+            std::copy(boxes + (size_t)f * mp * 4, boxes + (size_t)(f + 1) * mp * 4, q.inj_boxes.begin() + (size_t)(slot + f) * mp * 4);
+            std::copy(conf + (size_t)f * mp, conf + (size_t)(f + 1) * mp, q.inj_conf.begin() + (size_t)(slot + f) * mp);
+            std::copy(cls + (size_t)f * mp, cls + (size_t)(f + 1) * mp, q.inj_cls.begin() + (size_t)(slot + f) * mp);
+        }
+    });
+}
+
+int aic_pipeline_run(aic_pipeline* p, int slot, int count, int32_t* n_tracks, int32_t* tracks6, float* track_conf,
+                     int32_t* n_dets, float* det_boxes, float* det_scores, int32_t* det_labels) {
+    return guarded([&] {
+        AIC_REQUIRE(p, AIC_ERR_INVALID, "NULL pipeline");
+        p->p.run(slot, count, n_tracks, tracks6, track_conf, n_dets, det_boxes, det_scores, det_labels);
+    });
+}
+
+int aic_pipeline_tracker(aic_pipeline* p, aic_tracker** out) {
+    return guarded([&] {
+        AIC_REQUIRE(p && out, AIC_ERR_INVALID, "NULL argument");
+        *out = p->p.trk_handle.get();   // owned by the pipeline: do not destroy
+    });
+}
+
+int aic_pipeline_last_embeddings(aic_pipeline* p, float* emb, int cap_rows, int32_t* n, int32_t* dim) {
+    return guarded([&] {
+        AIC_REQUIRE(p && n && dim, AIC_ERR_INVALID, "NULL argument");
+        *n = p->p.last_emb_n, *dim = p->p.dim;
+        AIC_REQUIRE(p->p.last_emb_n <= cap_rows, AIC_ERR_CAPACITY, "embedding capacity too small");
+        if (emb) std::copy(p->p.last_emb.begin(), p->p.last_emb.end(), emb);
+    });
+}
+
+}  // extern "C"

@@ -103,8 +103,8 @@ int aic_device_sync(int dev) {
 int aic_prof_enable(int dev, int on) {
     return guarded([&] {
         Device& d = device(dev);
-        if (!on && d.prof_on) d.prof_collect();
-        d.prof_on = on != 0;
+        if (!on && d.prof_mask) d.prof_collect();
+        d.prof_mask = (unsigned)on;   // bit mask of classes; 0 = off, -1 = all
     });
 }
 

@@ -1,0 +1,606 @@
+// tracker.cpp -- TrackerCore / Track lifecycle on the host, numerics on the GPU.
+//
+// Mirrors src/tracker/core/tracker_core.py:11-198, track.py:16-171, linear_assignment.py:19-212
+// and the output formatting of src/tracker/deepsort_tracker.py:126-141.  What runs where:
+//   GPU  (kernels_trk.hip): Kalman predict / update / initiate, squared Mahalanobis gating
+//        distances, 1-IoU, min-over-gallery cosine distance -- the FULL [T,N] matrices once per
+//        frame (the reference recomputes sub-blocks per cascade level with identical values);
+//   host (this file, lsap.cpp): hit/age counters, track states, the age-ordered matching cascade,
+//        thresholding and the linear assignment -- integer decisions that must match the
+//        reference exactly.
+// Per frame: one packed H2D, 5 small kernels, one D2H of the three cost matrices, host matching,
+// one packed H2D, 3 kernels, one D2H of the updated boxes.
+#include "tracker.hpp"
+
+#include <algorithm>
+#include <cmath>
+
+namespace aic {
+
+static const float kInfty = 1e5f;                              // linear_assignment.py:9
+static const float kChi2_4 = (float)9.487729036781154;          // kalman_filter.py:16, compared in fp32
+
+Tracker::Tracker(Device& d, const aic_tracker_params& p) : dev(&d), prm(p) {
+    cap = p.max_tracks > 0 ? p.max_tracks : 512;
+    unlimited = p.nn_budget <= 0;
+    gmax = unlimited ? 256 : p.nn_budget;
+    next_id = p.first_track_id > 0 ? p.first_track_id : 1;
+    d.use();
+    d_mean.alloc((size_t)cap * 8);
+    d_cov.alloc((size_t)cap * 64);
+    for (int s = cap - 1; s >= 0; --s) free_slots.push_back(s);
+    if (p.feature_dim > 0) ensure_dim(p.feature_dim);
+}
+
+void Tracker::ensure_dim(int d) {
+    if (dim == d) return;
+    AIC_REQUIRE(dim == 0, AIC_ERR_INVALID, "feature dimension changed between updates");
+    AIC_REQUIRE(d > 0 && d <= 1024, AIC_ERR_INVALID, "feature dimension must be in 1..1024");
+    dim = d;
+    d_gal.alloc((size_t)cap * gmax * dim);
+}
+
+void Tracker::predict() {   // tracker_core.py:44-49 -> track.py:76-80
+    dev->use();
+    const int T = (int)tracks.size();
+    for (auto& t : tracks) { t.age += 1; t.tsu += 1; }
+    if (!T) return;
+    hipStream_t s = dev->s_trk;
+    // own staging pair: update() rewrites h_stage while this copy may still be in flight
+    HIP_CHECK(hipStreamSynchronize(s));
+    h_slots.ensure((size_t)T);
+    d_slots.ensure((size_t)T);
+    for (int i = 0; i < T; ++i) h_slots.p[i] = tracks[i].slot;
+    HIP_CHECK(hipMemcpyAsync(d_slots.p, h_slots.p, (size_t)T * 4, hipMemcpyHostToDevice, s));
+    {
+        Prof pr(*dev, PROF_TRK, s, 0, (double)T * 72 * 4 * 2);
+        launch_kf_predict(d_mean.p, d_cov.p, d_slots.p, T, s);
+    }
+}
+
+// linear_assignment.py:91-157 + tracker_core.py:83-177 on precomputed full matrices.
+void Tracker::match(int T, int N, const float* app, const float* maha, const float* iou,
+                    std::vector<std::pair<int, int>>& matches, std::vector<int>& unmatched_t,
+                    std::vector<int>& unmatched_d) {
+    matches.clear();
+    unmatched_t.clear();
+    unmatched_d.clear();
+    std::vector<int> confirmed, tentative;
+    for (int i = 0; i < T; ++i) {
+        if (tracks[i].state == TRK_CONFIRMED) confirmed.push_back(i);
+        else if (tracks[i].state == TRK_TENTATIVE) tentative.push_back(i);
+    }
+    for (int j = 0; j < N; ++j) unmatched_d.push_back(j);
+    std::vector<char> got(T, 0);
+    std::vector<float> sub;
+    std::vector<int> mr, mc, rows;
+    // stage 1: cascade over time_since_update = 1 .. max_age, gated appearance cost
+    for (int level = 0; level < prm.max_age; ++level) {
+        if (unmatched_d.empty()) break;
+        rows.clear();
+        for (int i : confirmed)
+            if (tracks[i].tsu == level + 1) rows.push_back(i);
+        if (rows.empty()) continue;
+        const int nr = (int)rows.size(), nc = (int)unmatched_d.size();
+        sub.resize((size_t)nr * nc);
+        for (int r = 0; r < nr; ++r)
+            for (int c = 0; c < nc; ++c) {
+                const size_t k = (size_t)rows[r] * N + unmatched_d[c];
+                sub[(size_t)r * nc + c] = (maha[k] > kChi2_4) ? kInfty : app[k];   // linear_assignment.py:187-210
+            }
+        min_cost_matching(sub.data(), nr, nc, prm.max_cosine_distance, mr, mc);
+        std::vector<char> dead(nc, 0);
+        for (size_t k = 0; k < mr.size(); ++k) {
+            matches.emplace_back(rows[mr[k]], unmatched_d[mc[k]]);
+            got[rows[mr[k]]] = 1;
+            dead[mc[k]] = 1;
+        }
+        std::vector<int> keep;
+        for (int c = 0; c < nc; ++c)
+            if (!dead[c]) keep.push_back(unmatched_d[c]);
+        unmatched_d.swap(keep);
+    }
+    // stage 2: IoU on tentative + confirmed tracks that missed exactly one frame
+    std::vector<int> cand = tentative, stale;
+    for (int i : confirmed) {
+        if (got[i]) continue;
+        if (tracks[i].tsu == 1) cand.push_back(i);
+        else if (tracks[i].tsu > 1) stale.push_back(i);
+        else stale.push_back(i);   // tsu == 0 cannot occur after predict(); kept unmatched like the reference
+    }
+    // NB reference order: tentative first, then confirmed (tracker_core.py:138-141)
+    std::vector<int> un_cand = cand;
+    if (!cand.empty() && !unmatched_d.empty()) {
+        const int nr = (int)cand.size(), nc = (int)unmatched_d.size();
+        sub.resize((size_t)nr * nc);
+        for (int r = 0; r < nr; ++r)
+            for (int c = 0; c < nc; ++c) sub[(size_t)r * nc + c] = iou[(size_t)cand[r] * N + unmatched_d[c]];
+        min_cost_matching(sub.data(), nr, nc, prm.max_iou_distance, mr, mc);
+        std::vector<char> dead(nc, 0), rdead(nr, 0);
+        for (size_t k = 0; k < mr.size(); ++k) {
+            matches.emplace_back(cand[mr[k]], unmatched_d[mc[k]]);
+            dead[mc[k]] = 1;
+            rdead[mr[k]] = 1;
+        }
+        std::vector<int> keep;
+        for (int c = 0; c < nc; ++c)
+            if (!dead[c]) keep.push_back(unmatched_d[c]);
+        unmatched_d.swap(keep);
+        un_cand.clear();
+        for (int r = 0; r < nr; ++r)
+            if (!rdead[r]) un_cand.push_back(cand[r]);
+    }
+    unmatched_t = stale;
+    unmatched_t.insert(unmatched_t.end(), un_cand.begin(), un_cand.end());
+}
+
+static inline int round_half_even(float v) { return (int)std::nearbyintf(v); }
+
+void Tracker::update(const float* det_tlwh, const float* conf, const int32_t* cls, const float* feat, int feat_mem,
+                     const uint8_t* has_feat, int n, int dim_in) {
+    dev->use();
+    hipStream_t s = dev->s_trk;
+    const int T = (int)tracks.size();
+    const bool any_feat = feat != nullptr && n > 0;
+    if (any_feat) ensure_dim(dim_in);
+    AIC_REQUIRE(n >= 0, AIC_ERR_INVALID, "negative detection count");
+    std::vector<uint8_t> hf(n, any_feat ? 1 : 0);
+    if (any_feat && has_feat) std::copy(has_feat, has_feat + n, hf.begin());
+
+    // detection.py:36-47 on the host, fp32
+    std::vector<float> xyah((size_t)n * 4);
+    for (int j = 0; j < n; ++j) {
+        const float x = det_tlwh[j * 4], y = det_tlwh[j * 4 + 1], w = det_tlwh[j * 4 + 2], h = det_tlwh[j * 4 + 3];
+        xyah[j * 4] = x + w / 2.0f;
+        xyah[j * 4 + 1] = y + h / 2.0f;
+        xyah[j * 4 + 2] = h > 0.f ? w / h : 0.f;
+        xyah[j * 4 + 3] = h;
+    }
+
+    // ---- device features
+    const float* d_featp = nullptr;
+    if (any_feat) {
+        if (feat_mem == AIC_DEVICE) d_featp = feat;
+        else {
+            d_feat.ensure((size_t)n * dim);
+            HIP_CHECK(hipMemcpyAsync(d_feat.p, feat, (size_t)n * dim * 4, hipMemcpyHostToDevice, s));
+            d_featp = d_feat.p;
+        }
+    }
+
+    // ---- packed per-frame parameters: slots[T] glen[T] | tlwh[n*4] xyah[n*4] | has[n]
+    const size_t off_slots = 0, off_glen = (size_t)T * 4, off_tlwh = (size_t)T * 8;
+    const size_t off_xyah = off_tlwh + (size_t)n * 16, off_has = off_xyah + (size_t)n * 16;
+    const size_t stage_bytes = ((off_has + n + 15) / 16) * 16;
+    last_t = T, last_n = n;
+    last_app.assign((size_t)T * n, kInfty);
+    last_maha.assign((size_t)T * n, 0.f);
+    last_iou.assign((size_t)T * n, kInfty);
+    if (T > 0 && n > 0) {
+        h_stage.ensure(stage_bytes + 16);
+        d_stage.ensure(stage_bytes + 16);
+        int* hs = reinterpret_cast<int*>(h_stage.p);
+        for (int i = 0; i < T; ++i) { hs[i] = tracks[i].slot; hs[T + i] = tracks[i].glen; }
+        std::memcpy(h_stage.p + off_tlwh, det_tlwh, (size_t)n * 16);
+        std::memcpy(h_stage.p + off_xyah, xyah.data(), (size_t)n * 16);
+        std::memcpy(h_stage.p + off_has, hf.data(), n);
+        HIP_CHECK(hipMemcpyAsync(d_stage.p, h_stage.p, stage_bytes, hipMemcpyHostToDevice, s));
+        const int* d_slots = reinterpret_cast<const int*>(d_stage.p + off_slots);
+        const int* d_glen = reinterpret_cast<const int*>(d_stage.p + off_glen);
+        const float* d_tl = reinterpret_cast<const float*>(d_stage.p + off_tlwh);
+        const float* d_xy = reinterpret_cast<const float*>(d_stage.p + off_xyah);
+        const unsigned char* d_has = reinterpret_cast<const unsigned char*>(d_stage.p + off_has);
+        const size_t tn = (size_t)T * n;
+        d_cost.ensure(3 * tn);
+        h_cost.ensure(3 * tn);
+        {
+            Prof pr(*dev, PROF_TRK, s, any_feat ? 2.0 * T * gmax * (double)n * dim : 0.0,
+                    any_feat ? ((double)T * gmax + n) * dim * 4 : 0.0);
+            launch_fill(d_cost.p, kInfty, tn, s);
+            if (any_feat && dim > 0) {
+                d_detn.ensure((size_t)n * dim);
+                launch_normalize_rows(d_featp, d_detn.p, n, dim, s);
+                launch_cosine_min(d_gal.p, d_slots, d_glen, T, gmax, dim, d_detn.p, d_has, n, d_cost.p, s);
+            }
+            launch_kf_gating(d_mean.p, d_cov.p, d_slots, T, d_xy, n, 1, 0, d_cost.p + tn, s);
+            launch_iou_cost(nullptr, d_mean.p, d_slots, T, d_tl, n, d_cost.p + 2 * tn, s);
+        }
+        HIP_CHECK(hipMemcpyAsync(h_cost.p, d_cost.p, 3 * tn * 4, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        std::copy(h_cost.p, h_cost.p + tn, last_app.begin());
+        std::copy(h_cost.p + tn, h_cost.p + 2 * tn, last_maha.begin());
+        std::copy(h_cost.p + 2 * tn, h_cost.p + 3 * tn, last_iou.begin());
+    }
+
+    // ---- host: association
+    std::vector<std::pair<int, int>> matches;
+    std::vector<int> un_t, un_d;
+    match(T, n, last_app.data(), last_maha.data(), last_iou.data(), matches, un_t, un_d);
+    last_matches.clear();
+    for (auto& m : matches) last_matches.emplace_back(tracks[m.first].id, m.second);
+
+    // ---- host: lifecycle + commit lists
+    const int M = (int)matches.size(), U = (int)un_d.size();
+    AIC_REQUIRE((int)free_slots.size() >= U, AIC_ERR_CAPACITY, "track capacity exhausted (raise max_tracks)");
+    std::vector<int> upd_slot(M), upd_det(M), ini_slot(U), ini_det(U);
+    std::vector<int> ap_slot, ap_pos, ap_det;
+    auto push_feature = [&](TrackRec& t, int det) {   // track.py:70-74 as a ring
+        if (!hf[det]) return;
+        int pos;
+        if (t.glen < gmax) {
+            pos = (t.ghead + t.glen) % gmax;
+            t.glen += 1;
+        } else {
+            AIC_REQUIRE(!unlimited, AIC_ERR_CAPACITY, "unlimited gallery exceeded its 256-row capacity");
+            pos = t.ghead;
+            t.ghead = (t.ghead + 1) % gmax;
+        }
+        ap_slot.push_back(t.slot), ap_pos.push_back(pos), ap_det.push_back(det);
+    };
+    std::vector<int> match_index_of_track(T, -1);
+    for (int k = 0; k < M; ++k) {   // track.py:82-104
+        TrackRec& t = tracks[matches[k].first];
+        const int det = matches[k].second;
+        upd_slot[k] = t.slot, upd_det[k] = det;
+        match_index_of_track[matches[k].first] = k;
+        push_feature(t, det);
+        t.hits += 1;
+        t.tsu = 0;
+        t.conf = conf[det];
+        t.cls = cls[det];
+        if (t.state == TRK_TENTATIVE && t.hits >= prm.n_init) t.state = TRK_CONFIRMED;
+        else if (t.state == TRK_DELETED) t.state = TRK_CONFIRMED;
+    }
+    for (int i : un_t) {            // track.py:106-119
+        TrackRec& t = tracks[i];
+        if (t.state == TRK_TENTATIVE) t.state = TRK_DELETED;
+        else if (t.state == TRK_CONFIRMED && t.tsu > prm.max_age) t.state = TRK_DELETED;
+    }
+    for (int k = 0; k < U; ++k) {   // tracker_core.py:180-194, track.py:23-67
+        TrackRec t{};
+        t.id = next_id++;
+        t.state = TRK_TENTATIVE;
+        t.hits = 1, t.age = 1, t.tsu = 0;
+        t.cls = cls[un_d[k]];
+        t.conf = conf[un_d[k]];
+        t.slot = free_slots.back();
+        free_slots.pop_back();
+        t.glen = 0, t.ghead = 0;
+        ini_slot[k] = t.slot, ini_det[k] = un_d[k];
+        push_feature(t, un_d[k]);
+        tracks.push_back(t);
+    }
+
+    // ---- device: commit
+    const int A = (int)ap_slot.size();
+    if (M + U + A > 0) {
+        const size_t words = (size_t)2 * M + 2 * U + 3 * A;
+        const size_t xy_off = ((words * 4 + 15) / 16) * 16;
+        const size_t bytes = xy_off + (size_t)n * 16;
+        h_stage.ensure(bytes);
+        d_stage.ensure(bytes);
+        int* hs = reinterpret_cast<int*>(h_stage.p);
+        int* p = hs;
+        std::copy(upd_slot.begin(), upd_slot.end(), p); p += M;
+        std::copy(upd_det.begin(), upd_det.end(), p); p += M;
+        std::copy(ini_slot.begin(), ini_slot.end(), p); p += U;
+        std::copy(ini_det.begin(), ini_det.end(), p); p += U;
+        std::copy(ap_slot.begin(), ap_slot.end(), p); p += A;
+        std::copy(ap_pos.begin(), ap_pos.end(), p); p += A;
+        std::copy(ap_det.begin(), ap_det.end(), p); p += A;
+        std::memcpy(h_stage.p + xy_off, xyah.data(), (size_t)n * 16);
+        HIP_CHECK(hipMemcpyAsync(d_stage.p, h_stage.p, bytes, hipMemcpyHostToDevice, s));
+        const int* d = reinterpret_cast<const int*>(d_stage.p);
+        const float* d_xy = reinterpret_cast<const float*>(d_stage.p + xy_off);
+        d_tlwh.ensure((size_t)std::max(M, 1) * 4);
+        h_tlwh.ensure((size_t)std::max(M, 1) * 4);
+        {
+            Prof pr(*dev, PROF_TRK, s, 0, (double)(M + U) * 72 * 4 * 2 + (double)A * dim * 8);
+            launch_kf_update(d_mean.p, d_cov.p, d, d_xy, d + M, M, d_tlwh.p, s);
+            launch_kf_initiate_idx(d_xy, d + 2 * M + U, U, d_mean.p, d_cov.p, d + 2 * M, s);
+            if (A) launch_gallery_append(d_gal.p, gmax, dim, d + 2 * M + 2 * U, d + 2 * M + 2 * U + A,
+                                         d + 2 * M + 2 * U + 2 * A, d_featp, A, s);
+        }
+        if (M) HIP_CHECK(hipMemcpyAsync(h_tlwh.p, d_tlwh.p, (size_t)M * 16, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+    }
+
+    // ---- outputs (deepsort_tracker.py:126-141), before pruning: indices still refer to `tracks`
+    outputs.clear();
+    for (int i = 0; i < T; ++i) {
+        const TrackRec& t = tracks[i];
+        if (t.state != TRK_CONFIRMED || t.tsu != 0) continue;
+        const int k = match_index_of_track[i];
+        if (k < 0) continue;
+        const float* b = h_tlwh.p + (size_t)k * 4;
+        const float x1 = b[0], y1 = b[1];
+        const float w = b[2] > 0.f ? b[2] : 0.f, h = b[3] > 0.f ? b[3] : 0.f;
+        TrackOut o;
+        o.x1 = round_half_even(x1), o.y1 = round_half_even(y1);
+        o.x2 = round_half_even(x1 + w), o.y2 = round_half_even(y1 + h);
+        o.id = t.id, o.cls = t.cls, o.conf = t.conf;
+        outputs.push_back(o);
+    }
+    // ---- prune (tracker_core.py:75)
+    std::vector<TrackRec> alive;
+    alive.reserve(tracks.size());
+    for (auto& t : tracks) {
+        if (t.state == TRK_DELETED) free_slots.push_back(t.slot);
+        else alive.push_back(t);
+    }
+    tracks.swap(alive);
+}
+
+}  // namespace aic
+
+// =================================================================================================
+using namespace aic;
+
+
+namespace {
+
+// Run `fn(d_in..., stream)` on temporary device copies of host arrays (API-level KF / cost calls).
+struct Tmp {
+    Device& d;
+    std::vector<DevBuf<char>> bufs;
+    explicit Tmp(Device& dev) : d(dev) {}
+    template <class T> T* up(const T* host, size_t count) {
+        bufs.emplace_back(count * sizeof(T) + 16);
+        if (count) HIP_CHECK(hipMemcpyAsync(bufs.back().p, host, count * sizeof(T), hipMemcpyHostToDevice, d.s_trk));
+        return reinterpret_cast<T*>(bufs.back().p);
+    }
+    template <class T> T* raw(size_t count) {
+        bufs.emplace_back(count * sizeof(T) + 16);
+        return reinterpret_cast<T*>(bufs.back().p);
+    }
+    template <class T> void down(T* host, const T* dev, size_t count) {
+        if (count) HIP_CHECK(hipMemcpyAsync(host, dev, count * sizeof(T), hipMemcpyDeviceToHost, d.s_trk));
+    }
+    void sync() { HIP_CHECK(hipStreamSynchronize(d.s_trk)); }
+};
+
+}  // namespace
+
+extern "C" {
+
+int aic_kf_initiate(int device_id, const float* z, int n, float* mean, float* cov) {
+    return guarded([&] {
+        AIC_REQUIRE(n >= 0 && (n == 0 || (z && mean && cov)), AIC_ERR_INVALID, "bad argument");
+        Device& d = device(device_id);
+        Tmp t(d);
+        float* dz = t.up(z, (size_t)n * 4);
+        float* dm = t.raw<float>((size_t)n * 8);
+        float* dc = t.raw<float>((size_t)n * 64);
+        launch_kf_initiate(dz, n, dm, dc, nullptr, d.s_trk);
+        t.down(mean, dm, (size_t)n * 8);
+        t.down(cov, dc, (size_t)n * 64);
+        t.sync();
+    });
+}
+
+int aic_kf_predict(int device_id, float* mean, float* cov, int n) {
+    return guarded([&] {
+        AIC_REQUIRE(n >= 0 && (n == 0 || (mean && cov)), AIC_ERR_INVALID, "bad argument");
+        Device& d = device(device_id);
+        Tmp t(d);
+        float* dm = t.up(mean, (size_t)n * 8);
+        float* dc = t.up(cov, (size_t)n * 64);
+        launch_kf_predict(dm, dc, nullptr, n, d.s_trk);
+        t.down(mean, dm, (size_t)n * 8);
+        t.down(cov, dc, (size_t)n * 64);
+        t.sync();
+    });
+}
+
+int aic_kf_project(int device_id, const float* mean, const float* cov, int n, float* pmean, float* pcov) {
+    return guarded([&] {
+        AIC_REQUIRE(n >= 0 && (n == 0 || (mean && cov && pmean && pcov)), AIC_ERR_INVALID, "bad argument");
+        Device& d = device(device_id);
+        Tmp t(d);
+        float* dm = t.up(mean, (size_t)n * 8);
+        float* dc = t.up(cov, (size_t)n * 64);
+        float* pm = t.raw<float>((size_t)n * 4);
+        float* pc = t.raw<float>((size_t)n * 16);
+        launch_kf_project(dm, dc, n, pm, pc, d.s_trk);
+        t.down(pmean, pm, (size_t)n * 4);
+        t.down(pcov, pc, (size_t)n * 16);
+        t.sync();
+    });
+}
+
+int aic_kf_update(int device_id, float* mean, float* cov, const float* z, int n) {
+    return guarded([&] {
+        AIC_REQUIRE(n >= 0 && (n == 0 || (mean && cov && z)), AIC_ERR_INVALID, "bad argument");
+        Device& d = device(device_id);
+        Tmp t(d);
+        float* dm = t.up(mean, (size_t)n * 8);
+        float* dc = t.up(cov, (size_t)n * 64);
+        float* dz = t.up(z, (size_t)n * 4);
+        launch_kf_update(dm, dc, nullptr, dz, nullptr, n, nullptr, d.s_trk);
+        t.down(mean, dm, (size_t)n * 8);
+        t.down(cov, dc, (size_t)n * 64);
+        t.sync();
+    });
+}
+
+int aic_kf_gating(int device_id, const float* mean, const float* cov, int n, const float* zs, int m, int shared_z,
+                  int only_position, float* d2) {
+    return guarded([&] {
+        AIC_REQUIRE(n >= 0 && m >= 0, AIC_ERR_INVALID, "bad argument");
+        if (!n || !m) return;
+        AIC_REQUIRE(mean && cov && zs && d2, AIC_ERR_INVALID, "NULL argument");
+        Device& d = device(device_id);
+        Tmp t(d);
+        float* dm = t.up(mean, (size_t)n * 8);
+        float* dc = t.up(cov, (size_t)n * 64);
+        float* dz = t.up(zs, (size_t)(shared_z ? m : (size_t)n * m) * 4);
+        float* dd = t.raw<float>((size_t)n * m);
+        launch_kf_gating(dm, dc, nullptr, n, dz, m, shared_z, only_position, dd, d.s_trk);
+        t.down(d2, dd, (size_t)n * m);
+        t.sync();
+    });
+}
+
+int aic_iou_cost(int device_id, const float* track_tlwh, int tn, const float* det_tlwh, int n, float* cost) {
+    return guarded([&] {
+        AIC_REQUIRE(tn >= 0 && n >= 0, AIC_ERR_INVALID, "bad argument");
+        if (!tn || !n) return;
+        AIC_REQUIRE(track_tlwh && det_tlwh && cost, AIC_ERR_INVALID, "NULL argument");
+        Device& d = device(device_id);
+        Tmp t(d);
+        float* a = t.up(track_tlwh, (size_t)tn * 4);
+        float* b = t.up(det_tlwh, (size_t)n * 4);
+        float* c = t.raw<float>((size_t)tn * n);
+        launch_iou_cost(a, nullptr, nullptr, tn, b, n, c, d.s_trk);
+        t.down(cost, c, (size_t)tn * n);
+        t.sync();
+    });
+}
+
+int aic_appearance_cost(int device_id, const float* galleries, const int32_t* gallery_len, int tn, int gmax, int dim,
+                        const float* det_feat, const uint8_t* has_feat, int n, float* cost) {
+    return guarded([&] {
+        AIC_REQUIRE(tn >= 0 && n >= 0 && gmax >= 0 && dim > 0, AIC_ERR_INVALID, "bad argument");
+        if (!tn || !n) return;
+        AIC_REQUIRE(gallery_len && det_feat && cost && (gmax == 0 || galleries), AIC_ERR_INVALID, "NULL argument");
+        Device& d = device(device_id);
+        Tmp t(d);
+        std::vector<int> iota(tn);
+        for (int i = 0; i < tn; ++i) iota[i] = i;
+        float* g = t.up(galleries, (size_t)tn * gmax * dim);
+        int* sl = t.up(iota.data(), tn);
+        int* gl = t.up(gallery_len, tn);
+        float* f = t.up(det_feat, (size_t)n * dim);
+        float* fn = t.raw<float>((size_t)n * dim);
+        unsigned char* hf = has_feat ? t.up(has_feat, n) : nullptr;
+        float* c = t.raw<float>((size_t)tn * n);
+        launch_fill(c, kInfty, (size_t)tn * n, d.s_trk);
+        launch_normalize_rows(f, fn, n, dim, d.s_trk);
+        launch_cosine_min(g, sl, gl, tn, gmax, dim, fn, hf, n, c, d.s_trk);
+        t.down(cost, c, (size_t)tn * n);
+        t.sync();
+    });
+}
+
+int aic_tracker_create(int device_id, const aic_tracker_params* p, aic_tracker** out) {
+    return guarded([&] {
+        AIC_REQUIRE(p && out, AIC_ERR_INVALID, "NULL argument");
+        AIC_REQUIRE(p->max_age >= 0 && p->n_init >= 0, AIC_ERR_INVALID, "negative tracker parameter");
+        *out = new aic_tracker(device(device_id), *p);
+    });
+}
+
+int aic_tracker_destroy(aic_tracker* t) {
+    return guarded([&] { delete t; });
+}
+
+int aic_tracker_predict(aic_tracker* t) {
+    return guarded([&] {
+        AIC_REQUIRE(t, AIC_ERR_INVALID, "NULL tracker");
+        t->t.predict();
+    });
+}
+
+int aic_tracker_update(aic_tracker* t, const float* det_tlwh, const float* conf, const int32_t* cls, const float* feat,
+                       int feat_mem, const uint8_t* has_feat, int n, int dim) {
+    return guarded([&] {
+        AIC_REQUIRE(t, AIC_ERR_INVALID, "NULL tracker");
+        AIC_REQUIRE(n == 0 || (det_tlwh && conf && cls), AIC_ERR_INVALID, "NULL detection arrays");
+        t->t.update(det_tlwh, conf, cls, feat, feat_mem, has_feat, n, dim);
+    });
+}
+
+int aic_tracker_outputs(aic_tracker* t, int32_t* out6, float* conf, int cap, int32_t* n_out) {
+    return guarded([&] {
+        AIC_REQUIRE(t && n_out, AIC_ERR_INVALID, "NULL argument");
+        const auto& o = t->t.outputs;
+        *n_out = (int32_t)o.size();
+        AIC_REQUIRE((int)o.size() <= cap, AIC_ERR_CAPACITY, "output capacity too small");
+        for (size_t k = 0; k < o.size(); ++k) {
+            int32_t* r = out6 + k * 6;
+            r[0] = o[k].x1, r[1] = o[k].y1, r[2] = o[k].x2, r[3] = o[k].y2, r[4] = o[k].id, r[5] = o[k].cls;
+            if (conf) conf[k] = o[k].conf;
+        }
+    });
+}
+
+int aic_tracker_num_tracks(const aic_tracker* t, int32_t* n) {
+    return guarded([&] {
+        AIC_REQUIRE(t && n, AIC_ERR_INVALID, "NULL argument");
+        *n = (int32_t)t->t.tracks.size();
+    });
+}
+
+int aic_tracker_export(aic_tracker* t, int cap, int32_t* track_id, int32_t* state, int32_t* hits, int32_t* age,
+                       int32_t* tsu, int32_t* cls, float* conf, int32_t* gallery_len, float* mean, float* cov) {
+    return guarded([&] {
+        AIC_REQUIRE(t, AIC_ERR_INVALID, "NULL tracker");
+        Tracker& k = t->t;
+        const int T = (int)k.tracks.size();
+        AIC_REQUIRE(T <= cap, AIC_ERR_CAPACITY, "export capacity too small");
+        std::vector<float> hm, hc;
+        if (mean || cov) {
+            k.dev->use();
+            hm.resize((size_t)k.cap * 8);
+            hc.resize((size_t)k.cap * 64);
+            HIP_CHECK(hipMemcpyAsync(hm.data(), k.d_mean.p, hm.size() * 4, hipMemcpyDeviceToHost, k.dev->s_trk));
+            HIP_CHECK(hipMemcpyAsync(hc.data(), k.d_cov.p, hc.size() * 4, hipMemcpyDeviceToHost, k.dev->s_trk));
+            HIP_CHECK(hipStreamSynchronize(k.dev->s_trk));
+        }
+        for (int i = 0; i < T; ++i) {
+            const TrackRec& r = k.tracks[i];
+            if (track_id) track_id[i] = r.id;
+            if (state) state[i] = r.state;
+            if (hits) hits[i] = r.hits;
+            if (age) age[i] = r.age;
+            if (tsu) tsu[i] = r.tsu;
+            if (cls) cls[i] = r.cls;
+            if (conf) conf[i] = r.conf;
+            if (gallery_len) gallery_len[i] = r.glen;
+            if (mean) std::copy(hm.begin() + (size_t)r.slot * 8, hm.begin() + (size_t)r.slot * 8 + 8, mean + (size_t)i * 8);
+            if (cov) std::copy(hc.begin() + (size_t)r.slot * 64, hc.begin() + (size_t)r.slot * 64 + 64, cov + (size_t)i * 64);
+        }
+    });
+}
+
+int aic_tracker_export_gallery(aic_tracker* t, int index, float* out, int cap_rows) {
+    return guarded([&] {
+        AIC_REQUIRE(t && out, AIC_ERR_INVALID, "NULL argument");
+        Tracker& k = t->t;
+        AIC_REQUIRE(index >= 0 && index < (int)k.tracks.size(), AIC_ERR_INVALID, "track index out of range");
+        const TrackRec& r = k.tracks[index];
+        AIC_REQUIRE(r.glen <= cap_rows, AIC_ERR_CAPACITY, "gallery capacity too small");
+        k.dev->use();
+        for (int g = 0; g < r.glen; ++g) {
+            const int pos = (r.ghead + g) % k.gmax;
+            HIP_CHECK(hipMemcpyAsync(out + (size_t)g * k.dim, k.d_gal.p + ((size_t)r.slot * k.gmax + pos) * k.dim,
+                                     (size_t)k.dim * 4, hipMemcpyDeviceToHost, k.dev->s_trk));
+        }
+        HIP_CHECK(hipStreamSynchronize(k.dev->s_trk));
+    });
+}
+
+int aic_tracker_last_matches(aic_tracker* t, int32_t* track_id, int32_t* det, int cap, int32_t* n) {
+    return guarded([&] {
+        AIC_REQUIRE(t && n, AIC_ERR_INVALID, "NULL argument");
+        const auto& m = t->t.last_matches;
+        *n = (int32_t)m.size();
+        AIC_REQUIRE((int)m.size() <= cap, AIC_ERR_CAPACITY, "match capacity too small");
+        for (size_t k = 0; k < m.size(); ++k) track_id[k] = m[k].first, det[k] = m[k].second;
+    });
+}
+
+int aic_tracker_last_costs(aic_tracker* t, float* app, float* maha, float* iou, int cap, int32_t* t_n, int32_t* d_n) {
+    return guarded([&] {
+        AIC_REQUIRE(t && t_n && d_n, AIC_ERR_INVALID, "NULL argument");
+        Tracker& k = t->t;
+        *t_n = k.last_t, *d_n = k.last_n;
+        const size_t tn = (size_t)k.last_t * k.last_n;
+        AIC_REQUIRE((long)tn <= cap, AIC_ERR_CAPACITY, "cost capacity too small");
+        if (app) std::copy(k.last_app.begin(), k.last_app.end(), app);
+        if (maha) std::copy(k.last_maha.begin(), k.last_maha.end(), maha);
+        if (iou) std::copy(k.last_iou.begin(), k.last_iou.end(), iou);
+    });
+}
+
+}  // extern "C"

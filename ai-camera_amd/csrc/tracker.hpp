@@ -1,0 +1,59 @@
+// tracker.hpp -- DeepSORT core with Kalman state and galleries in HBM, lifecycle + cascade on host.
+#pragma once
+#include "kernels.hpp"
+
+namespace aic {
+
+void min_cost_matching(const float* cost, int nr, int nc, double max_distance, std::vector<int>& mrow,
+                       std::vector<int>& mcol);
+
+enum { TRK_TENTATIVE = 1, TRK_CONFIRMED = 2, TRK_DELETED = 3 };   // src/tracker/core/track.py:10-14
+
+struct TrackRec {
+    int id, state, hits, age, tsu, cls;
+    float conf;
+    int slot;          // row in the device SoA
+    int glen, ghead;   // gallery ring: oldest row = ghead, length glen
+};
+
+struct TrackOut { int x1, y1, x2, y2, id, cls; float conf; };
+
+struct Tracker {
+    Device* dev = nullptr;
+    aic_tracker_params prm{};
+    int cap = 0, dim = 0, gmax = 0;
+    bool unlimited = false;
+    DevBuf<float> d_mean, d_cov, d_gal;
+    std::vector<TrackRec> tracks;
+    std::vector<int> free_slots;
+    int next_id = 1;
+    // staging
+    PinBuf<char> h_stage;
+    DevBuf<char> d_stage;
+    PinBuf<int> h_slots;
+    DevBuf<int> d_slots;
+    PinBuf<float> h_cost;
+    DevBuf<float> d_cost, d_detn, d_feat, d_tlwh;
+    PinBuf<float> h_tlwh;
+    // last frame
+    std::vector<float> last_app, last_maha, last_iou;
+    int last_t = 0, last_n = 0;
+    std::vector<std::pair<int, int>> last_matches;   // (track id, det)
+    std::vector<TrackOut> outputs;
+
+    Tracker(Device& d, const aic_tracker_params& p);
+    void ensure_dim(int d);
+    void predict();
+    // feat may be host or device memory ([n, dim] fp32)
+    void update(const float* det_tlwh, const float* conf, const int32_t* cls, const float* feat, int feat_mem,
+                const uint8_t* has_feat, int n, int dim_in);
+    void match(int T, int N, const float* app, const float* maha, const float* iou,
+               std::vector<std::pair<int, int>>& matches, std::vector<int>& unmatched_t, std::vector<int>& unmatched_d);
+};
+
+}  // namespace aic
+
+struct aic_tracker {
+    aic::Tracker t;
+    aic_tracker(aic::Device& d, const aic_tracker_params& p) : t(d, p) {}
+};

@@ -12,7 +12,7 @@ Layout of an ``.aicw`` file (little endian):
 
     u32 magic 'AICW', u32 version, i32 kind, i32 in_h, i32 in_w, i32 n_buf, i32 n_op,
     i32 n_w, i32 n_out, i32 meta[8]
-    n_buf x i32[4]   (h, w, c, dtype)          buffer 0 is the input, NHWC, c = 4 (RGB0)
+    n_buf x i32[4]   (h, w, c, dtype)          buffer 0 is the input, NHWC, c = 8 (RGB + 5 zero lanes)
     n_op  x i32[20]  (see OP_* below)
     n_w   x i64[6]   (cout, cin, kh, kw, weight offset, bias offset)   offsets in floats
     n_out x i32[8]   YOLO: (box_buf, cls_buf, stride, h, w, 0,0,0) per level; ReID: (emb_buf, dim,...)
@@ -38,6 +38,7 @@ OP_CONV, OP_SPPF_POOL, OP_UPSAMPLE2X, OP_MAXPOOL3S2, OP_AVGPOOL, OP_L2NORM = 1, 
 ACT_NONE, ACT_SILU, ACT_RELU = 0, 1, 2
 RES_NONE, RES_ADD_THEN_ACT, RES_ACT_THEN_ADD = 0, 1, 2
 OP_WORDS = 20
+IN_C = 8   # input pixels are stored RGB00000 (16 B in fp16) so the 3-channel stems run through the MFMA implicit GEMM
 
 YOLO_SCALES = {  # depth, width, max_channels (Ultralytics yolov8.yaml)
     "n": (0.33, 0.25, 1024), "s": (0.33, 0.50, 1024), "m": (0.67, 0.75, 768),
@@ -70,7 +71,7 @@ class Graph:
         sb, db = self.buffers[src], self.buffers[dst]
         p = k // 2
         assert (sb[0] + 2 * p - k) // s + 1 == db[0] and (sb[1] + 2 * p - k) // s + 1 == db[1], name
-        assert src_coff + cin <= sb[2] + (1 if cin == 3 else 0) and dst_coff + cout <= db[2], name
+        assert src_coff + cin <= sb[2] and dst_coff + cout <= db[2], name
         res_buf, res_coff = (-1, 0) if res is None else res
         self.weights.append(wb)
         self.names.append(name)
@@ -144,7 +145,7 @@ def build_yolov8(scale="n", nc=80, in_hw=(640, 640), seed=0, reg_max=16, calibra
         conv(f"{name}.cv2", cat, dst, (2 + n) * c, c2, 1, 1, dst_coff=dst_coff)
 
     c1, c2_, c3, c4, c5 = ch(64), ch(128), ch(256), ch(512), ch(1024)
-    inp = g.buf(H, W, 4)
+    inp = g.buf(H, W, IN_C)
     b0 = g.buf(H // 2, W // 2, c1)
     conv("0.conv", inp, b0, 3, c1, 3, 2)
     b1 = g.buf(H // 4, W // 4, c2_)
@@ -219,7 +220,7 @@ def build_reid(in_hw=(128, 64), seed=1, dim=512, fc=True, calibrate=True) -> Gra
         gain = kw.pop("gain", 1.0)
         g.conv(name, src, dst, cin, cout, k, s, act, wb=wg(cout, cin, k, act, gain), **kw)
 
-    inp = g.buf(H, W, 4)
+    inp = g.buf(H, W, IN_C)
     a = g.buf(H, W, 64)
     conv("conv0", inp, a, 3, 64, 3, 1, ACT_RELU)
     h, w = H // 2, W // 2
@@ -320,7 +321,7 @@ def calibrate_seeded(g: Graph, seed: int, target_rms: float = 1.0, frame_hw=(720
     x = torch.from_numpy(_calibration_input(g, seed, frame_hw))
     n = x.shape[0]
     bufs = [None] * len(g.buffers)
-    bufs[0] = torch.cat([x, torch.zeros(n, 1, g.in_h, g.in_w)], 1)
+    bufs[0] = torch.cat([x, torch.zeros(n, g.buffers[0][2] - 3, g.in_h, g.in_w)], 1)
     final_cls = {o[1] for o in g.outputs} if g.kind == KIND_YOLO else set()
     final_box = {o[0] for o in g.outputs} if g.kind == KIND_YOLO else set()
 

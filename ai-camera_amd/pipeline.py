@@ -1,0 +1,108 @@
+"""TrackingPipeline: the batched end-to-end path (aic_pipeline_*) -- the loop body of
+src/aicamera_tracker.py:169-207 over frames resident in HBM -- plus helpers shared by bench.py,
+the CLI and the tests."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+from . import config
+from .core.tracker_core import TrackerCore
+from .hip_engine import HipEngine
+
+
+class TrackingPipeline:
+    def __init__(self, yolo_engine, reid_engine, frame_hw, batch=8, ring_frames=None, max_persons=32, device=0,
+                 dtype="fp16", conf_thresh=config.YOLO_CONF_THRESHOLD, iou_thresh=config.YOLO_NMS_THRESHOLD,
+                 max_det=config.YOLO_MAX_DET, min_confidence=config.DEEPSORT_MIN_CONFIDENCE, inject=False,
+                 max_cosine_distance=config.DEEPSORT_MAX_DIST, nn_budget=config.DEEPSORT_NN_BUDGET,
+                 max_iou_distance=config.DEEPSORT_MAX_IOU_DISTANCE, max_age=config.DEEPSORT_MAX_AGE,
+                 n_init=config.DEEPSORT_N_INIT, max_tracks=512):
+        self.frame_h, self.frame_w = int(frame_hw[0]), int(frame_hw[1])
+        self.batch = int(batch)
+        self.ring_frames = int(ring_frames or 4 * batch)
+        self.max_persons, self.max_det = int(max_persons), int(max_det)
+        self.yolo = yolo_engine if isinstance(yolo_engine, HipEngine) else HipEngine(
+            yolo_engine, device=device, dtype=dtype, max_items=self.batch, warm_up=False)
+        self.reid = reid_engine if isinstance(reid_engine, HipEngine) else HipEngine(
+            reid_engine, device=device, dtype=dtype, max_items=self.batch * self.max_persons, warm_up=False)
+        lo, hi = config.track_class_mask()
+        tp = L.TrackerParams(float(max_cosine_distance), float(max_iou_distance), int(nn_budget or 0), int(max_age),
+                             int(n_init), int(max_tracks), int(self.reid.out_dim), 1)
+        self.params = L.PipelineParams(self.frame_h, self.frame_w, self.batch, self.ring_frames, self.max_persons,
+                                       float(conf_thresh), float(iou_thresh), self.max_det, float(min_confidence),
+                                       int(bool(inject)), (C.c_uint64 * 2)(lo, hi), tp)
+        self._h = C.c_void_p()
+        L.call("aic_pipeline_create", self.yolo._h, self.reid._h, C.byref(self.params), C.byref(self._h))
+        th = C.c_void_p()
+        L.call("aic_pipeline_tracker", self._h, C.byref(th))
+        self.tracker_core = TrackerCore._from_handle(th, tp)
+        self.tracker_core._dim = self.reid.out_dim
+
+    def close(self):
+        if getattr(self, "_h", None):
+            L.call("aic_pipeline_destroy", self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload(self, slot, frames_bgr):
+        f = np.ascontiguousarray(frames_bgr, dtype=np.uint8)
+        if f.ndim == 3:
+            f = f[None]
+        assert f.shape[1:] == (self.frame_h, self.frame_w, 3), f.shape
+        L.call("aic_pipeline_upload", self._h, int(slot), L.ptr(f), len(f))
+
+    def inject(self, slot, detections):
+        """detections: list (one per frame) of (boxes_xyxy [n,4], conf [n], class_ids [n])."""
+        k, mp = len(detections), self.max_persons
+        counts = np.zeros(k, np.int32)
+        boxes, conf, cls = np.zeros((k, mp, 4), np.float32), np.zeros((k, mp), np.float32), np.zeros((k, mp), np.int32)
+        for f, (b, c, ids) in enumerate(detections):
+            n = len(b)
+            counts[f] = n
+            boxes[f, :n], conf[f, :n], cls[f, :n] = b, c, ids
+        L.call("aic_pipeline_inject", self._h, int(slot), k, L.ptr(counts), L.ptr(boxes), L.ptr(conf), L.ptr(cls))
+
+    def run(self, slot, count, want_dets=False):
+        """Process ring slots [slot, slot+count): returns (tracks, dets); tracks[f] is the list of
+        (x1, y1, x2, y2, track_id, class_name, conf) tuples of deepsort_tracker.py:126-141."""
+        mp, md = self.max_persons, self.max_det
+        nt = np.zeros(count, np.int32)
+        rows, tconf = np.zeros((count, mp, 6), np.int32), np.zeros((count, mp), np.float32)
+        nd = np.zeros(count, np.int32)
+        db = np.zeros((count, md, 4), np.float32) if want_dets else None
+        ds = np.zeros((count, md), np.float32) if want_dets else None
+        dl = np.zeros((count, md), np.int32) if want_dets else None
+        L.call("aic_pipeline_run", self._h, int(slot), int(count), L.ptr(nt), L.ptr(rows), L.ptr(tconf), L.ptr(nd),
+               L.ptr(db), L.ptr(ds), L.ptr(dl))
+        tracks = [[(int(r[0]), int(r[1]), int(r[2]), int(r[3]), int(r[4]), config.class_name(int(r[5])), float(c))
+                   for r, c in zip(rows[f, :nt[f]], tconf[f, :nt[f]])] for f in range(count)]
+        dets = None
+        if want_dets:
+            dets = [(db[f, :nd[f]], ds[f, :nd[f]], dl[f, :nd[f]]) for f in range(count)]
+        return tracks, (dets if want_dets else nd)
+
+    def run_raw(self, slot, count):
+        """Timed path of bench.py: no Python-side unpacking, outputs stay in preallocated arrays."""
+        if not hasattr(self, "_raw"):
+            mp = self.max_persons
+            self._raw = (np.zeros(self.ring_frames, np.int32), np.zeros((self.ring_frames, mp, 6), np.int32),
+                         np.zeros((self.ring_frames, mp), np.float32), np.zeros(self.ring_frames, np.int32))
+        nt, rows, tconf, nd = self._raw
+        L.call("aic_pipeline_run", self._h, int(slot), int(count), L.ptr(nt), L.ptr(rows), L.ptr(tconf), L.ptr(nd),
+               None, None, None)
+        return nt[:count], rows[:count], nd[:count]
+
+    def last_embeddings(self):
+        n, d = C.c_int32(), C.c_int32()
+        L.call("aic_pipeline_last_embeddings", self._h, None, 1 << 30, C.byref(n), C.byref(d))
+        out = np.zeros((n.value, d.value), np.float32)
+        L.call("aic_pipeline_last_embeddings", self._h, L.ptr(out), max(n.value, 1), C.byref(n), C.byref(d))
+        return out

@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""bench.py -- end-to-end frames/sec of the detect+track hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (BASELINE.json configs[1] / SURVEY.md §8d): one synthetic 1280x720 stream per GPU, 30
+planted persons per frame, YOLOv8n + ReID in fp16 (the reference engines' precision,
+scripts/export_trt_engines.sh:37), seeded weights, conf 0.3 / NMS IoU 0.5 / max_det 300, tracker
+parameters of src/config.py:23-29.  The detector runs in full on every frame; crop/ReID/association
+consume the planted boxes (inject switch) because seeded weights cannot see them.
+
+A STEP = one pass of the hot path over one batch: the 2R frames resident in HBM (R rendered frames
+played forward then backward, so the planted persons move continuously and the tracker stays in
+steady state).  Timed span = the reference's own FPS span (detect + track,
+src/aicamera_tracker.py:175,201-207): frames already in HBM -> track tuples on the host.
+
+One JSON line on rank 0.  `roofline`: the dominant kernel conv_igemm (MFMA implicit GEMM), achieved =
+algorithmic conv FLOPs / its summed launch durations, HIP events on the launch stream, recorded over
+the timed region.  `cpu_baseline`: the oracle chain (torch-CPU fp32 nets + NumPy/SciPy DeepSORT) timed
+on this box's host cores on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+import os
+
+os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")   # DeepSORT oracle: LAPACK 4x4 oversubscribes
+
+import argparse
+import importlib
+import json
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_F16_TFLOPS = 2500.0   # dense fp16 MFMA, MI355X_MICROARCH.md
+PEAK_F32_TFLOPS = 157.3
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--ring", type=int, default=32, help="rendered frames R; a step processes 2R frames")
+    p.add_argument("--batch", type=int, default=16, help="frames per detection/ReID launch group")
+    p.add_argument("--persons", type=int, default=30)
+    p.add_argument("--width", type=int, default=1280)
+    p.add_argument("--height", type=int, default=720)
+    p.add_argument("--model", type=str, default="n", choices=("n", "m"))
+    p.add_argument("--dtype", type=str, default="fp16", choices=("fp16", "fp32"))
+    p.add_argument("--seed", type=int, default=0)
+    p.add_argument("--no-prof", action="store_true", help="do not record HIP events in the timed region")
+    p.add_argument("--cpu-frames", type=int, default=-1, help="frames of the CPU baseline sample (-1 auto, 0 skip)")
+    p.add_argument("--gallery-exchange", type=int, default=0, help="configs[4]: all-gather the ReID gallery every K steps")
+    return p.parse_args()
+
+
+def cpu_baseline(args, ypath, rpath, budget_s=20.0):
+    """Oracle chain on the host cores: bounded sample (about 10-30 s) of the same workload."""
+    import torch
+    syn = importlib.import_module("ai-camera_amd.synthetic")
+    cfg = importlib.import_module("ai-camera_amd.config")
+    from oracle import deepsort_oracle as O, image_oracle as I, nets_oracle as N
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    yo, ro = N.EngineOracle(ypath), N.EngineOracle(rpath)
+    sc = syn.Scene(seed=args.seed, n_targets=args.persons, width=args.width, height=args.height)
+    trk = O.OracleTracker()
+
+    def one(f):
+        frame = sc.render(f)
+        x, ratios, pad = I.preprocess_yolo_input(frame)
+        dfl, cls = yo.yolo_head(torch.from_numpy(x))
+        b, ml, lab = yo.decode(dfl.numpy(), cls.numpy())
+        keep = N.nms(b[0], ml[0], lab[0], 0.3, 0.5, 300)
+        I.scale_bboxes(b[0][keep], frame.shape[:2], ratios, pad)
+        boxes, conf, cids, _ = sc.detections(f)                       # inject: planted boxes downstream
+        crops, valid = I.crops_to_batch(frame, boxes)
+        emb = ro.run(torch.from_numpy(crops))[ro.outputs[0][0]][:, :, 0, 0].numpy()
+        tlwh = np.stack([boxes[:, 0], boxes[:, 1], boxes[:, 2] - boxes[:, 0], boxes[:, 3] - boxes[:, 1]], 1)
+        trk.predict()
+        trk.update(list(tlwh), list(conf), ["person"] * len(boxes), [emb[i] if valid[i] else None for i in range(len(boxes))])
+        return trk.output_tuples()
+
+    frames_pre = [sc.render(0)]   # page in
+    one(0)                         # warm-up (not timed)
+    n = args.cpu_frames
+    t0 = time.perf_counter()
+    done = 0
+    f = 1
+    while True:
+        t_frame = time.perf_counter()
+        # rendering is outside the reference's timed span: subtract it
+        frame_t0 = time.perf_counter()
+        sc.render(f)
+        render_dt = time.perf_counter() - frame_t0
+        one(f)
+        t0 += render_dt * 2       # one render above + the one inside one()
+        done += 1
+        f += 1
+        el = time.perf_counter() - t0
+        if (n > 0 and done >= n) or (n < 0 and (el > budget_s or done >= 64)):
+            break
+    el = time.perf_counter() - t0
+    return {"value": round(done / el, 3), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{done} consecutive frames of the same synthetic stream after 1 warm-up frame "
+                      f"(torch-CPU fp32 YOLOv8{args.model}+ReID on {cores} threads, NumPy/SciPy DeepSORT with BLAS threads=1)"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+    import torch
+    import torch.distributed as dist
+
+    L = importlib.import_module("ai-camera_amd._lib")
+    L.load()                                   # fails loudly if the HIP library is missing
+    ef = importlib.import_module("ai-camera_amd.engine_file")
+    syn = importlib.import_module("ai-camera_amd.synthetic")
+    D = importlib.import_module("ai-camera_amd.distributed")
+    TP = importlib.import_module("ai-camera_amd.pipeline").TrackingPipeline
+
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+    dev = local_rank if torch.cuda.device_count() > local_rank else 0
+    torch.cuda.set_device(dev)
+
+    if rank == 0:
+        ypath, rpath = ef.ensure_seeded_engines(ROOT, scale=args.model)
+    if world > 1:
+        dist.barrier()
+    ypath, rpath = ef.ensure_seeded_engines(ROOT, scale=args.model)
+
+    R = args.ring
+    sc = syn.Scene(seed=D.stream_seed(args.seed, rank), n_targets=args.persons, width=args.width, height=args.height)
+    order = list(range(R)) + list(range(R - 1, -1, -1))          # forward then backward: continuous motion
+    max_persons = max(32, ((args.persons + 7) // 8) * 8)
+    pipe = TP(ypath, rpath, (args.height, args.width), batch=args.batch, ring_frames=2 * R, max_persons=max_persons,
+              device=dev, dtype=args.dtype, inject=True)
+    frames = sc.render_batch(0, R)
+    t_up = time.perf_counter()
+    pipe.upload(0, frames)
+    pipe.upload(R, np.ascontiguousarray(frames[::-1]))
+    L.call("aic_device_sync", dev)
+    h2d_s = time.perf_counter() - t_up
+    dets = [sc.detections(f)[:3] for f in range(R)]
+    pipe.inject(0, [dets[f] for f in order])
+    del frames
+    frames_per_step = 2 * R
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        L.call("aic_device_sync", dev)
+
+    exchange = args.gallery_exchange
+    for _ in range(args.warmup):
+        pipe.run_raw(0, frames_per_step)
+    if not args.no_prof:
+        L.call("aic_prof_reset", dev)
+        L.call("aic_prof_enable", dev, 1)       # class 0 = conv_igemm only
+    sync_all()
+    t0 = time.perf_counter()
+    n_tracks_total = 0
+    for k in range(args.steps):
+        nt, rows, nd = pipe.run_raw(0, frames_per_step)
+        n_tracks_total += int(nt.sum())
+        if exchange and world > 1 and (k + 1) % exchange == 0:
+            a = pipe.tracker_core.export_arrays()
+            conf = a["state"] == 2
+            shard = D.pack_gallery_shard(a["track_id"][conf], np.zeros((int(conf.sum()), pipe.reid.out_dim), np.float32), pipe.reid.out_dim)
+            D.all_gather_gallery(shard, dev)
+    sync_all()
+    dt = time.perf_counter() - t0
+    prof = L.prof_read(dev) if not args.no_prof else None
+    if not args.no_prof:
+        L.call("aic_prof_enable", dev, 0)
+    dt_max = D.reduce_max_time(dt) if world > 1 else dt
+    total_frames = frames_per_step * args.steps * world
+    fps = total_frames / dt_max
+
+    if rank == 0:
+        flops_frame = pipe.yolo.flops_per_item + args.persons * pipe.reid.flops_per_item
+        peak = PEAK_F16_TFLOPS if args.dtype == "fp16" else PEAK_F32_TFLOPS
+        roof = None
+        if prof and prof["conv_igemm"]["ms"] > 0:
+            c = prof["conv_igemm"]
+            ach = c["flops"] / (c["ms"] * 1e-3) / 1e12
+            roof = {"kernel": "conv_igemm_kernel (MFMA implicit GEMM, all conv layers of YOLOv8 + ReID)",
+                    "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                    "traffic": None, "launches": c["launches"], "avg_launch_us": round(1e3 * c["ms"] / max(c["launches"], 1), 2),
+                    "kernel_ms_per_step": round(c["ms"] / args.steps, 3),
+                    "algorithmic_gflop_per_frame": round(flops_frame / 1e9, 3)}
+        cpu = None
+        if world == 1 and args.cpu_frames != 0:
+            try:
+                cpu = cpu_baseline(args, ypath, rpath)
+            except Exception as e:   # the baseline must never hide the GPU number
+                cpu = {"value": None, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
+        out = {
+            "metric": "end-to-end frames/sec @1280x720, 30 persons/frame",
+            "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt_max / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f16" if args.dtype == "fp16" else "f32", "data": "synthetic",
+            "config": {"workload": f"{args.width}x{args.height}, {args.persons} planted persons/frame, YOLOv8{args.model}+ReID(512-d)+DeepSORT, "
+                                   f"1 stream per GPU, seeded weights, inject=planted",
+                       "frames_per_step": frames_per_step, "launch_group_frames": args.batch,
+                       "confirmed_tracks_per_frame": round(n_tracks_total / (frames_per_step * args.steps), 2),
+                       "timed_span": "frames resident in HBM -> track tuples on host (detect+track, reference FPS span)",
+                       "h2d_upload_s_for_ring": round(h2d_s, 4),
+                       "gallery_exchange_every_steps": exchange},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

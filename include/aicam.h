@@ -227,7 +227,8 @@ int aic_pipeline_last_embeddings(aic_pipeline* p, float* emb, int cap_rows, int3
  * Classes: 0 conv_igemm (MFMA), 1 conv_direct (3-channel stems), 2 pool/upsample/misc,
  * 3 letterbox, 4 crop_resize, 5 decode+nms, 6 tracker kernels. */
 #define AIC_PROF_CLASSES 7
-int aic_prof_enable(int device, int on);
+/* class_mask: bit c set = time class c; 0 = off; -1 = all classes */
+int aic_prof_enable(int device, int class_mask);
 int aic_prof_reset(int device);
 /* total ms, launches, algorithmic FLOPs and algorithmic bytes accumulated for a class. */
 int aic_prof_read(int device, int cls, double* ms, int64_t* launches, double* flops, double* bytes);

@@ -54,7 +54,7 @@ class EngineOracle:
         """x: fp32 [N,3,H,W]. Returns the list of buffers (NCHW, channels = buffer width)."""
         n = x_nchw.shape[0]
         bufs = [None] * len(self.buffers)
-        bufs[0] = torch.cat([x_nchw.float(), torch.zeros(n, 1, self.in_h, self.in_w)], 1)
+        bufs[0] = torch.cat([x_nchw.float(), torch.zeros(n, self.buffers[0][2] - 3, self.in_h, self.in_w)], 1)
 
         def get(bi, coff, c):
             return bufs[bi][:, coff:coff + c]

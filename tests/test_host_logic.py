@@ -1,0 +1,134 @@
+"""Host-side product code that runs without a GPU: the C-ABI surface, the C++ LSAP / thresholded
+matching (pinned against SciPy and the reference fixtures), engine files, synthetic scenes."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+from scipy.optimize import linear_sum_assignment as scipy_lsa
+
+from conftest import ROOT, pkg
+from oracle import deepsort_oracle as O
+
+
+def test_abi_exports_every_declared_symbol(lib):
+    header = open(os.path.join(ROOT, "include", "aicam.h")).read()
+    declared = set(re.findall(r"\b(aic_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 40
+    handle = C.CDLL(lib.LIB_PATH)
+    missing = [n for n in sorted(declared) if not hasattr(handle, n)]
+    assert not missing, missing
+    assert declared == set(lib.EXPORTS), declared ^ set(lib.EXPORTS)
+    assert handle.aic_abi_version() == 1
+
+
+def test_no_cpu_fallback(lib):
+    """Without a GPU every compute entry point fails loudly; host logic still works."""
+    if lib.device_count() > 0:
+        pytest.skip("GPU present")
+    z = np.zeros((1, 4), np.float32)
+    with pytest.raises(lib.NoDeviceError):
+        lib.call("aic_kf_initiate", 0, lib.ptr(z), 1, lib.ptr(np.zeros((1, 8), np.float32)), lib.ptr(np.zeros((1, 64), np.float32)))
+    with pytest.raises(lib.NoDeviceError):
+        pkg("core.tracker_core").TrackerCore()
+    with pytest.raises(RuntimeError):
+        pkg("config").resolve_device("cpu")
+
+
+def test_missing_engine_file_raises(lib):
+    he = pkg("hip_engine")
+    with pytest.raises(FileNotFoundError):      # trt_engine.py:46-47
+        he.HipEngine("/nonexistent/engine.aicw")
+    with pytest.raises(FileNotFoundError):      # reid_model.py:57-58
+        pkg("reid_model").ReIDModel("/nonexistent/reid.aicw")
+
+
+def _lsap(lib, m):
+    m = np.ascontiguousarray(m, np.float64)
+    k = min(m.shape)
+    r, c = np.zeros(k, np.int64), np.zeros(k, np.int64)
+    lib.call("aic_lsap", lib.ptr(m), m.shape[0], m.shape[1], lib.ptr(r), lib.ptr(c))
+    return r, c
+
+
+def test_lsap_matches_scipy(lib):
+    rng = np.random.default_rng(7)
+    for it in range(4000):
+        r, c = rng.integers(1, 48, 2)
+        kind = it % 6
+        if kind == 0:
+            m = rng.uniform(0, 1, (r, c))
+        elif kind == 1:
+            m = rng.integers(0, 3, (r, c)).astype(float)
+        elif kind == 2:
+            m = np.round(rng.uniform(0, 0.5, (r, c)), 1)
+        elif kind == 3:
+            m = np.full((r, c), 0.25)
+        elif kind == 4:
+            m = rng.uniform(0, 0.3, (r, c)).astype(np.float32).astype(float)
+            m[m > 0.2] = np.float32(0.20001)
+        else:
+            m = rng.uniform(-5, 5, (r, c))
+            m[rng.uniform(size=(r, c)) < 0.3] = 1e5
+        ri, ci = _lsap(lib, m)
+        sr, sc = scipy_lsa(m)
+        assert np.array_equal(ri, sr) and np.array_equal(ci, sc), (it, m.shape)
+    assert _lsap(lib, np.zeros((0, 5)))[0].size == 0
+    with pytest.raises(lib.AicError):
+        _lsap(lib, np.array([[np.nan, 1.0]]))
+    with pytest.raises(lib.AicError):
+        _lsap(lib, np.array([[np.inf, np.inf]]))       # infeasible, as SciPy raises
+
+
+def test_min_cost_matching_matches_reference_fixtures(lib, golden):
+    g = golden("assign")
+    la = pkg("core.linear_assignment")
+    for k in range(int(g["n_cases"])):
+        m = g[f"c{k}_cost"]
+        rows, cols = list(range(0, 2 * m.shape[0], 2)), list(range(100, 100 + m.shape[1]))
+        for name, thr in (("cos", 0.2), ("iou", 0.7)):
+            mt, ut, ud = la.min_cost_matching(lambda *a, m=m: m.copy(), thr, None, None, list(rows), list(cols))
+            assert np.array_equal(np.array(mt, np.int32).reshape(-1, 2), g[f"c{k}_{name}_m"]), (k, name)
+            assert ut == g[f"c{k}_{name}_ut"].tolist() and ud == g[f"c{k}_{name}_ud"].tolist()
+    # reference self-test scenario (linear_assignment.py:267-276): (0,0),(1,1) matched, track 2 / det 2 left
+    cost = np.array([[0.1, 0.9, 0.9], [0.9, 0.15, 0.9], [0.9, 0.9, 0.9]], np.float32)
+    mt, ut, ud = la.min_cost_matching(lambda *a: cost.copy(), 0.2, None, None, [0, 1, 2], [0, 1, 2])
+    assert mt == [(0, 0), (1, 1)] and ut == [2] and ud == [2]
+    assert la.min_cost_matching(lambda *a: cost, 0.2, None, None, [], [0, 1]) == ([], [], [0, 1])
+
+
+def test_engine_file_graphs():
+    ef = pkg("engine_file")
+    g = ef.build_yolov8("n", calibrate=False)
+    assert len(g.weights) == 63 and g.conv_macs() == 4_371_456_000 and g.meta[2] == 8400
+    assert abs(g.n_params() - 3_151_888) < 10
+    gm = ef.build_yolov8("m", calibrate=False)
+    assert len(gm.weights) == 83 and abs(gm.conv_macs() / 1e9 - 39.468) < 1e-3
+    gr = ef.build_reid(calibrate=False)
+    assert len(gr.weights) == 21 and abs(gr.conv_macs() / 1e9 - 1.1217) < 1e-3           # 20 convs + embed FC
+    blob = ef.serialize(gr)
+    back = ef.parse(blob)
+    assert back.ops == gr.ops and back.buffers == gr.buffers and back.outputs == gr.outputs
+    assert all(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) for a, b in zip(back.weights, gr.weights))
+    from oracle.nets_oracle import EngineOracle
+    eo = EngineOracle(blob)
+    assert eo.ops == gr.ops and [tuple(b) for b in eo.buffers] == gr.buffers
+    # every channel slice is 16-byte aligned in fp16 (what the conv kernel's vector loads need)
+    for o in g.ops + gm.ops + gr.ops:
+        assert o[2] % 8 == 0 and o[5] % 4 == 0
+
+
+def test_synthetic_scene_is_deterministic():
+    syn = pkg("synthetic")
+    a, b = syn.Scene(seed=3, n_targets=5, width=320, height=240), syn.Scene(seed=3, n_targets=5, width=320, height=240)
+    assert np.array_equal(a.render(17), b.render(17))
+    ba, ca, _, ia = a.detections(17)
+    bb, cb, _, ib = b.detections(17)
+    assert np.array_equal(ba, bb) and np.array_equal(ca, cb) and np.array_equal(ia, ib)
+    assert ba.dtype == np.float32 and (ba[:, 2] > ba[:, 0]).all() and ba[:, [0, 2]].max() <= 320
+    f = syn.identity_features([0, 1, 0], 3, dim=64)
+    d = O.cosine_distance(f, f)
+    assert d[0, 2] < 1e-5 and d[0, 1] > 0.5
+    sc = syn.Scene(seed=1, n_targets=4, gaps=[(2, 5, 9)], births={3: 7})
+    assert sc.visible(6).tolist() == [True, True, False, False] and sc.visible(10).all()
