@@ -91,6 +91,8 @@ Model::Model(Device& d, const void* blob, size_t nbytes, int dtype_, int max_ite
         b.p = storage[i].p;
     }
     AIC_REQUIRE(bufs[0].h == in_h && bufs[0].w == in_w && bufs[0].c == 8, AIC_ERR_FORMAT, "input buffer must be HxWx8");
+    d_zero.alloc(256);
+    HIP_CHECK(hipMemsetAsync(d_zero.p, 0, 256, d.s_main));
     // ---- ops
     ops.resize(no);
     for (int i = 0; i < no; ++i) std::memcpy(ops[i].v, otab + (size_t)i * 20, 80);
@@ -187,7 +189,10 @@ void Model::run(int n, hipStream_t s) {
             a.res = nullptr, a.r_cs = 0, a.r_coff = 0, a.res_mode = v[14], a.act = v[11];
             if (v[14]) { a.res = bufs[v[12]].p, a.r_cs = bufs[v[12]].c, a.r_coff = v[13]; }
             a.KH = w.kh, a.KW = w.kw, a.stride = v[9], a.pad = v[10];
-            a.Kp = w.Kp, a.M = n * db.h * db.w, a.out_f32 = db.f32, a.cout_pad = w.cout_pad;
+            a.Kp = w.Kp, a.M = n * db.h * db.w, a.out_f32 = db.f32, a.cout_pad = w.cout_pad, a.zero = d_zero.p;
+            a.tap_rows = 0;
+            for (int kh = 0; kh < w.kh; ++kh) a.tap_rows |= 1u << (kh * w.kw);
+            AIC_REQUIRE(w.kh * w.kw <= 25, AIC_ERR_FORMAT, "kernel window larger than 5x5");
             const double fl = 2.0 * a.M * (double)w.cout * w.cin * w.kh * w.kw;
             const double by = ((double)n * sb.h * sb.w * w.cin + (double)a.M * w.cout) * (dtype == AIC_F16 ? 2 : 4) +
                               (double)w.cout * w.cin * w.kh * w.kw * (dtype == AIC_F16 ? 2 : 4);

@@ -33,6 +33,7 @@ struct Model {
     DevBuf<uint8_t> d_frames;
     DevBuf<float> d_crop_boxes;
     DevBuf<int> d_valid;
+    DevBuf<char> d_zero;   // zero page for the conv kernel's LDS-DMA
 
     Model(Device& d, const void* blob, size_t nbytes, int dtype_, int max_items_);
     void* input() { return bufs[0].p; }

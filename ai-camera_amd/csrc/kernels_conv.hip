@@ -18,6 +18,8 @@
 // zero-padding, image borders and the K tail are resolved per 16-byte chunk at load time.
 #include "kernels.hpp"
 
+#include <cstdlib>
+
 namespace aic {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -231,8 +233,323 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     }
 }
 
+
+// ---- shared by the v2 kernel: cheap index math and a specialised epilogue ------------------------
+// m -> (m / d, m % d) with one reciprocal multiply and a +-1 fix-up (m < 2^26 here).
+__device__ __forceinline__ void fast_divmod(int m, int d, float inv, int& q, int& r) {
+    q = (int)(__int2float_rz(m) * inv);
+    r = m - q * d;
+    if (r >= d) { r -= d; ++q; }
+    if (r < 0) { r += d; --q; }
+}
+
+template <int ACT> __device__ __forceinline__ float act_fast(float v) {
+    if constexpr (ACT == 1) {   // SiLU = v * sigmoid(v); v_exp_f32 + v_rcp_f32 (<= 1 ulp each)
+        return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f));
+    } else if constexpr (ACT == 2) {
+        return fmaxf(v, 0.0f);
+    } else {
+        return v;
+    }
+}
+
+// One lane owns, per (i, j) tile, 4 consecutive output channels of one pixel.
+// ACT / RES / F32OUT are compile-time so the unrolled body carries no branches.
+template <typename T, int MT, int NT, int ACT, int RES, bool F32OUT>
+__device__ __forceinline__ void epilogue_fast(const ConvArgs& a, floatx4 (&acc)[MT][NT], int m_base, int n_base, int r, int q) {
+    const float* __restrict__ bias = a.bias;
+    const T* __restrict__ rg = reinterpret_cast<const T*>(a.res);
+    floatx4 b4[NT];
+    bool ncol[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int n = n_base + j * 16 + 4 * q;
+        ncol[j] = n < a.Cout;                       // Cout % 4 == 0 on this path: all four or none
+        b4[j] = *reinterpret_cast<const floatx4*>(bias + n);   // bias is padded to cout_pad
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int m = m_base + i * 16 + r;
+        if (m >= a.M) continue;
+        const size_t ybase = (size_t)m * a.y_cs + a.y_coff;
+        const size_t rbase = RES ? (size_t)m * a.r_cs + a.r_coff : 0;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            if (!ncol[j]) continue;
+            const int n = n_base + j * 16 + 4 * q;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] + b4[j][e];
+            if constexpr (RES != 0) {
+                float rv[4];
+                if constexpr (sizeof(T) == 2) {
+                    const half4 h = *reinterpret_cast<const half4*>(rg + rbase + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) rv[e] = (float)h[e];
+                } else {
+                    const floatx4 h = *reinterpret_cast<const floatx4*>(rg + rbase + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) rv[e] = h[e];
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = RES == 1 ? act_fast<ACT>(v[e] + rv[e]) : act_fast<ACT>(v[e]) + rv[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = act_fast<ACT>(v[e]);
+            }
+            if constexpr (F32OUT || sizeof(T) == 4) {
+                *reinterpret_cast<floatx4*>(reinterpret_cast<float*>(a.y) + ybase + n) = floatx4{v[0], v[1], v[2], v[3]};
+            } else {
+                const half4 h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+                *reinterpret_cast<half4*>(reinterpret_cast<half_t*>(a.y) + ybase + n) = h;
+            }
+        }
+    }
+}
+
+// Generic (any Cout, any mode) fallback: runtime branches, scalar tail.
+template <typename T, int MT, int NT>
+__device__ __forceinline__ void epilogue_generic(const ConvArgs& a, floatx4 (&acc)[MT][NT], int m_base, int n_base, int r, int q) {
+    // (inlined and fully unrolled on purpose: a call would force `a` and `acc` into scratch memory)
+    const float* __restrict__ bias = a.bias;
+    const T* __restrict__ rg = reinterpret_cast<const T*>(a.res);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int m = m_base + i * 16 + r;
+        if (m >= a.M) continue;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int n = n_base + j * 16 + 4 * q;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (n + e >= a.Cout) continue;
+                float x = acc[i][j][e] + bias[n + e];
+                const float rv = a.res_mode ? (float)rg[(size_t)m * a.r_cs + a.r_coff + n + e] : 0.f;
+                if (a.res_mode == 1) x += rv;
+                x = act_apply(x, a.act);
+                if (a.res_mode == 2) x += rv;
+                const size_t yo = (size_t)m * a.y_cs + a.y_coff + n + e;
+                if (a.out_f32 || sizeof(T) == 4) reinterpret_cast<float*>(a.y)[yo] = x;
+                else reinterpret_cast<half_t*>(a.y)[yo] = (half_t)x;
+            }
+        }
+    }
+}
+
+template <typename T, int MT, int NT>
+__device__ __forceinline__ void epilogue_dispatch(const ConvArgs& a, floatx4 (&acc)[MT][NT], int m_base, int n_base, int r, int q) {
+    const int key = (a.Cout & 3) ? -1 : (a.act | (a.res_mode << 2) | (a.out_f32 << 4));
+    switch (key) {
+        case 1: epilogue_fast<T, MT, NT, 1, 0, false>(a, acc, m_base, n_base, r, q); break;            // SiLU
+        case 1 | (2 << 2): epilogue_fast<T, MT, NT, 1, 2, false>(a, acc, m_base, n_base, r, q); break;  // SiLU then +res (C2f bottleneck)
+        case 2: epilogue_fast<T, MT, NT, 2, 0, false>(a, acc, m_base, n_base, r, q); break;            // ReLU
+        case 2 | (1 << 2): epilogue_fast<T, MT, NT, 2, 1, false>(a, acc, m_base, n_base, r, q); break;  // relu(x + res) (BasicBlock)
+        case 0: epilogue_fast<T, MT, NT, 0, 0, false>(a, acc, m_base, n_base, r, q); break;            // linear (downsample, FC)
+        case 0 | (1 << 4): epilogue_fast<T, MT, NT, 0, 0, true>(a, acc, m_base, n_base, r, q); break;   // linear fp32 (detect head)
+        default: epilogue_generic<T, MT, NT>(a, acc, m_base, n_base, r, q); break;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// v2: same tiling and MFMA mapping, but the operand tiles travel HBM/L2 -> LDS by LDS-DMA
+// (global_load_lds_dwordx4, 1 KiB per wave-instruction, no VGPR staging and no ds_write pass) into an
+// NSTAGE-deep ring, NSTAGE-1 K-steps in flight.  Per K-step: counted s_waitcnt vmcnt (never 0 in
+// the loop) -> one raw s_barrier -> issue the loads of step+NSTAGE-1 -> MFMAs of the current step.
+//  * the LDS image of a wave-instruction must be lane-linear, so the XOR swizzle is applied to the
+//    SOURCE: the thread that fills LDS slot s of row r fetches K-chunk s ^ ((r>>1)&3)
+//    (cdna_hip_programming.md §5.4 rule 21); the ds_read side uses the same involution;
+//  * zero padding / image borders / K tail / rows past M or Cout: the lane's source address is a
+//    64-byte page of zeros in HBM, so every wave issues exactly LPS loads per stage and the vmcnt
+//    arithmetic is uniform (also in the drain iterations, which load zeros nobody reads);
+//  * im2col address = per-row base pointer + one per-thread tap offset; in-bounds is a precomputed
+//    bit per (row, tap).
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if constexpr (N == 15) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+    else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if constexpr (N == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+    else if constexpr (N == 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+    else static_assert(N < 0, "add this vmcnt literal");
+}
+
+template <typename T, int MT, int NT, int WM, int WN, int NSTAGE>
+__global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvArgs a) {
+    constexpr int CH = 16 / (int)sizeof(T);
+    constexpr int BKE = 4 * CH;
+    constexpr int BM = WM * MT * 16;
+    constexpr int BN = WN * NT * 16;
+    constexpr int BNP = (BN + 63) / 64 * 64;   // weight rows padded so every wave issues the same loads
+    constexpr int A_PER = BM / 64;
+    constexpr int B_PER = BNP / 64;
+    constexpr int LPS = A_PER + B_PER;         // LDS-DMA instructions per stage per wave
+    constexpr int STAGE = (BM + BNP) * 64;
+    static_assert(WM * WN == 4 && BM % 64 == 0 && NSTAGE >= 2, "geometry");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wv = t >> 6;
+    const int slot = t & 3, r0 = t >> 2;
+    const int kc = slot ^ ((r0 >> 1) & 3);     // K-chunk this thread fetches (source-side swizzle)
+    const int m0 = blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+
+    const T* __restrict__ xg = reinterpret_cast<const T*>(a.x);
+    const T* __restrict__ wg = reinterpret_cast<const T*>(a.w);
+    const T* zero = reinterpret_cast<const T*>(a.zero);
+
+    const T* rowp[A_PER];
+    unsigned vmask[A_PER];
+    const int HoWo = a.Ho * a.Wo;
+    const int ntap = a.KH * a.KW;
+    const float inv_howo = 1.0f / (float)HoWo, inv_wo = 1.0f / (float)a.Wo;
+#pragma unroll
+    for (int i = 0; i < A_PER; ++i) {
+        const int m = m0 + r0 + 64 * i;
+        unsigned mk = 0;
+        const T* rp = zero;
+        if (m < a.M) {
+            int img, rem, oh, ow;
+            fast_divmod(m, HoWo, inv_howo, img, rem);
+            fast_divmod(rem, a.Wo, inv_wo, oh, ow);
+            const int ih0 = oh * a.stride - a.pad, iw0 = ow * a.stride - a.pad;
+            rp = xg + (((long)img * a.H + ih0) * a.W + iw0) * a.x_cs + a.x_coff;
+            // in-bounds taps, loop-free: columns [lo_w, hi_w) x rows [lo_h, hi_h) of the KH x KW window
+            const int lo_w = max(0, -iw0), hi_w = min(a.KW, a.W - iw0);
+            const int lo_h = max(0, -ih0), hi_h = min(a.KH, a.H - ih0);
+            if (hi_w > lo_w && hi_h > lo_h) {
+                const unsigned vw = ((1u << hi_w) - 1u) & ~((1u << lo_w) - 1u);
+                const unsigned rows = (((1u << (hi_h * a.KW)) - 1u) & ~((1u << (lo_h * a.KW)) - 1u)) & a.tap_rows;
+                mk = vw * rows;                     // replicate the column bits at every valid row
+            }
+        }
+        rowp[i] = rp;
+        vmask[i] = mk;
+    }
+    const T* wp[B_PER];
+#pragma unroll
+    for (int j = 0; j < B_PER; ++j) {
+        const int row = r0 + 64 * j;
+        wp[j] = row < BN ? wg + (size_t)(n0 + row) * a.Kp + kc * CH : nullptr;
+    }
+
+    // K position of this thread's chunk: tap index + channel offset, and the matching element offset
+    int c_in = kc * CH, kw_ = 0, kh_ = 0;
+    while (c_in >= a.Cin) {
+        c_in -= a.Cin;
+        if (++kw_ == a.KW) { kw_ = 0; ++kh_; }
+    }
+    const int nsteps = a.Kp / BKE;
+    int issued = 0;   // K-steps issued so far
+
+    auto issue = [&](int stage) {
+        const int tap = kh_ * a.KW + kw_;
+        const bool in_k = tap < ntap;
+        const long toff = ((long)kh_ * a.W + kw_) * a.x_cs + c_in;
+        char* sbase = smem + stage * STAGE + (16 * wv) * 64;
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) {
+            const bool ok = in_k && ((vmask[i] >> (tap & 31)) & 1u);
+            const T* src = ok ? rowp[i] + toff : zero;
+            asm volatile("" : "+v"(src));   // one select, ONE LDS-DMA instruction per wave: keeps vmcnt counting uniform
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sbase + i * 4096), 16, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < B_PER; ++j) {
+            const T* src = (wp[j] != nullptr && issued < nsteps) ? wp[j] + (size_t)issued * BKE : zero;
+            asm volatile("" : "+v"(src));
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sbase + BM * 64 + j * 4096), 16, 0, 0);
+        }
+        ++issued;
+        c_in += BKE;
+        while (c_in >= a.Cin) {
+            c_in -= a.Cin;
+            if (++kw_ == a.KW) { kw_ = 0; ++kh_; }
+        }
+    };
+
+    const int wm = wv / WN, wn = wv % WN;
+    const int q = lane >> 4, r = lane & 15;
+
+    floatx4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int s = 0; s < NSTAGE - 1; ++s) issue(s);
+
+    typedef typename Frag<T>::type frag_t;
+    int cur = 0;
+    for (int step = 0; step < nsteps; ++step) {
+        wait_vmcnt<(NSTAGE - 2) * LPS>();      // this wave's loads of `step` have landed
+        __builtin_amdgcn_s_barrier();          // ... everyone's have, and everyone finished step-1
+        int nxt = cur + NSTAGE - 1;
+        if (nxt >= NSTAGE) nxt -= NSTAGE;
+        issue(nxt);                            // refills the buffer that step-1 just released
+        const char* base = smem + cur * STAGE;
+        frag_t xf[MT], wf[NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int row = (wm * MT + i) * 16 + r;
+            xf[i] = *reinterpret_cast<const frag_t*>(base + lds_off(row, q));
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int row = (wn * NT + j) * 16 + r;
+            wf[j] = *reinterpret_cast<const frag_t*>(base + BM * 64 + lds_off(row, q));
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = Frag<T>::mma(wf[j], xf[i], acc[i][j]);
+        if (++cur == NSTAGE) cur = 0;
+    }
+    wait_vmcnt<0>();   // drain the zero-page loads of the tail before the LDS goes away
+
+    epilogue_dispatch<T, MT, NT>(a, acc, m0 + wm * MT * 16, n0 + wn * NT * 16, r, q);
+}
+
+static int conv_impl() {   // AICAM_CONV=v1 selects the register-staged kernel (A/B and fallback)
+    static int v = [] { const char* e = getenv("AICAM_CONV"); return (e && e[0] == 'v' && e[1] == '1') ? 1 : 2; }();
+    return v;
+}
+
+template <typename T, int MT, int NT, int WM, int WN, int NSTAGE>
+static void launch_dma(const ConvArgs& a, hipStream_t s) {
+    constexpr int BM = WM * MT * 16, BN = WN * NT * 16, BNP = (BN + 63) / 64 * 64;
+    dim3 grid(ceil_div(a.M, BM), ceil_div(a.Cout, BN));
+    const size_t lds = (size_t)NSTAGE * (BM + BNP) * 64;
+    auto kfn = conv_igemm_dma_kernel<T, MT, NT, WM, WN, NSTAGE>;
+    static bool attr = false;
+    if (!attr && lds > 64 * 1024) {
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = true;
+    }
+    hipLaunchKernelGGL(kfn, grid, dim3(256), lds, s, a);
+    KCHECK();
+}
+
 template <typename T, int MT, int NT, int WM, int WN>
 static void launch_variant(const ConvArgs& a, hipStream_t s) {
+    if (conv_impl() == 2) {
+        launch_dma<T, MT, NT, WM, WN, 4>(a, s);
+        return;
+    }
     constexpr int BM = WM * MT * 16, BN = WN * NT * 16;
     dim3 grid(ceil_div(a.M, BM), ceil_div(a.Cout, BN));
     const size_t lds = 2 * (size_t)(BM + BN) * 64;
