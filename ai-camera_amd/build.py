@@ -61,7 +61,7 @@ def build(force=False, verbose=True):
         raise RuntimeError("hipcc failed")
     objs = [os.path.join(bdir, s + ".o") for s in SOURCES]
     if force or jobs or _stale(OUT, objs):
-        cmd = [cc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", OUT] + objs
+        cmd = [cc, "-shared", "-fPIC", "--offload-arch=gfx950", "-pthread", "-o", OUT] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode:
             raise RuntimeError("link failed:\n" + r.stdout + r.stderr)

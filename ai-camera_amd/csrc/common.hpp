@@ -100,11 +100,13 @@ struct Device {
     int id = 0;
     hipStream_t s_main = nullptr;  // detection + ReID launch groups
     hipStream_t s_trk = nullptr;   // per-frame association chain
+    hipStream_t s_det = nullptr;   // decode + NMS + detection read-back (overlaps the ReID launch group)
     int n_cu = 256;
     unsigned prof_mask = 0;   // bit c set = class c is timed with HIP events
     struct Pair { hipEvent_t a, b; };
     std::vector<Pair> pending[AIC_PROF_CLASSES];
     std::vector<Pair> pool;
+    std::mutex prof_mu;            // launches come from two host threads (pipeline producer / tracker)
     double ms[AIC_PROF_CLASSES] = {0};
     int64_t launches[AIC_PROF_CLASSES] = {0};
     double flops[AIC_PROF_CLASSES] = {0};

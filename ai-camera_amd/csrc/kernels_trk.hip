@@ -331,6 +331,215 @@ __global__ __launch_bounds__(256) void cosine_min_kernel(const float* __restrict
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fused per-frame kernels of the tracker (one stream, three launches per frame).
+//
+// trk_assoc_kernel: block t = one live track. Wave 0 runs the Kalman predict in place
+// (kalman_filter.py:85-120), then all threads walk the detections: squared Mahalanobis distance
+// (kalman_filter.py:206-249), 1-IoU (matching.py:13-106) and the INFTY_COST initialisation of the
+// appearance row (matching.py:173).
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(128) void trk_assoc_kernel(float* mean, float* cov, const int* __restrict__ slots, int do_predict,
+                                                        const float* __restrict__ det_tlwh, const float* __restrict__ det_xyah,
+                                                        int n, float* app, float* d2, float* iouc) {
+    const int t = blockIdx.x;
+    const int slot = slots[t];
+    float* P = cov + (size_t)slot * 64;
+    float* m = mean + (size_t)slot * 8;
+    if (do_predict && threadIdx.x < 64) {
+        const int lane = threadIdx.x, i = lane >> 3, j = lane & 7;
+        const float h = m[3];
+        float t1 = P[i * 8 + j];
+        if (j < 4) t1 = t1 + P[i * 8 + j + 4];
+        float t2 = t1;
+        if (i < 4) {
+            float u = P[(i + 4) * 8 + j];
+            if (j < 4) u = u + P[(i + 4) * 8 + j + 4];
+            t2 = t1 + u;
+        }
+        if (i == j) t2 = t2 + q_diag(i, h);
+        float mi = 0.f;
+        if (j == 0) { mi = m[i]; if (i < 4) mi = mi + m[i + 4]; }
+        P[i * 8 + j] = t2;
+        if (j == 0) m[i] = mi;
+    }
+    __syncthreads();   // the block's own global writes are visible to its other waves after the barrier
+    float S[4][4], L[4][4];
+    innovation_cov(P, m[3], S);
+    const bool ok = cholesky<4>(S, L);
+    float bw = 0.f, bh = m[3];
+    if (bh > 0.f) bw = m[2] * bh; else bh = fmaxf(0.f, bh);
+    const float bx = m[0] - bw / 2.0f, by = m[1] - bh / 2.0f;
+    const float brx = bx + bw, bry = by + bh;
+    for (int j = threadIdx.x; j < n; j += blockDim.x) {
+        const float* z = det_xyah + (size_t)j * 4;
+        float d[4], y[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) d[a] = z[a] - m[a];
+        fwd_solve<4>(L, d, y);
+        float acc = y[0] * y[0];
+        acc = acc + y[1] * y[1];
+        acc = acc + y[2] * y[2];
+        acc = acc + y[3] * y[3];
+        const size_t o = (size_t)t * n + j;
+        d2[o] = ok ? acc : __builtin_inff();
+        const float* c = det_tlwh + (size_t)j * 4;
+        const float crx = c[0] + c[2], cry = c[1] + c[3];
+        const float iw = fmaxf(0.f, fminf(brx, crx) - fmaxf(bx, c[0]));
+        const float ih = fmaxf(0.f, fminf(bry, cry) - fmaxf(by, c[1]));
+        const float inter = iw * ih;
+        const float uni = bw * bh + c[2] * c[3] - inter;
+        iouc[o] = 1.0f - inter / fmaxf(uni, 1e-7f);
+        app[o] = 1e5f;
+    }
+}
+
+// cosine_min on the matrix cores: cost[t][n] = min_g max(0, 1 - <gal_n[t][g], det_n[n]>) with both
+// operands ALREADY normalised (gallery rows at append time, detections once per launch group).
+// v_mfma_f32_16x16x4_f32: exact fp32 fmaf chain. One wave = 16 gallery rows x up to 32 detections;
+// lane (r, q) streams 16 bytes of its row per 16-deep K slice and MFMA i consumes element i of both
+// operands (k = 16*kb + 4*q + i on both sides, so the contraction index matches).
+__global__ __launch_bounds__(256) void cosine_min_mfma_kernel(const float* __restrict__ gal_n, const int* __restrict__ slots,
+                                                              const int* __restrict__ glen, int gmax, int dim,
+                                                              const float* __restrict__ det_n, const unsigned char* __restrict__ has_feat,
+                                                              int n, float* cost) {
+    const int t = blockIdx.x;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    const int g0 = (blockIdx.y * 4 + wv) * 16;
+    const int len = glen[t];
+    if (g0 >= len) return;
+    const float* grow = gal_n + ((size_t)slots[t] * gmax + g0 + r) * dim;
+    const bool grow_ok = g0 + r < len;
+    const bool vec_ok = (dim & 15) == 0;
+    unsigned int* out = reinterpret_cast<unsigned int*>(cost) + (size_t)t * n;
+    for (int d0 = 0; d0 < n; d0 += 32) {
+        const int da = d0 + r, db = d0 + 16 + r;
+        const float* pa = det_n + (size_t)da * dim;
+        const float* pb = det_n + (size_t)db * dim;
+        const bool oka = da < n, okb = db < n;
+        floatx4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        for (int k0 = 0; k0 < dim; k0 += 16) {
+            const int k = k0 + 4 * q;
+            floatx4 a = {0.f, 0.f, 0.f, 0.f}, b0 = a, b1 = a;
+            if (vec_ok) {
+                if (grow_ok) a = *reinterpret_cast<const floatx4*>(grow + k);
+                if (oka) b0 = *reinterpret_cast<const floatx4*>(pa + k);
+                if (okb) b1 = *reinterpret_cast<const floatx4*>(pb + k);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (k + e < dim) {
+                        if (grow_ok) a[e] = grow[k + e];
+                        if (oka) b0[e] = pa[k + e];
+                        if (okb) b1[e] = pb[k + e];
+                    }
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b0[e], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b1[e], acc1, 0, 0, 0);
+            }
+        }
+        // D[row = gallery 4q+e][col = detection r]: min over the valid gallery rows of this tile
+        float m0 = 3.0e38f, m1 = 3.0e38f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (g0 + 4 * q + e < len) {
+                float x0 = 1.0f - acc0[e], x1 = 1.0f - acc1[e];
+                x0 = x0 > 0.f ? x0 : 0.f;
+                x1 = x1 > 0.f ? x1 : 0.f;
+                m0 = fminf(m0, x0);
+                m1 = fminf(m1, x1);
+            }
+        }
+        m0 = fminf(m0, __shfl_xor(m0, 16)); m0 = fminf(m0, __shfl_xor(m0, 32));
+        m1 = fminf(m1, __shfl_xor(m1, 16)); m1 = fminf(m1, __shfl_xor(m1, 32));
+        if (q == 0) {
+            if (oka && (!has_feat || has_feat[da])) atomicMin(out + da, __float_as_uint(m0));
+            if (okb && (!has_feat || has_feat[db])) atomicMin(out + db, __float_as_uint(m1));
+        }
+    }
+}
+
+// trk_commit_kernel: one wavefront-sized block per work item, three roles by block index:
+//   [0, M)        Kalman update of a matched track (kalman_filter.py:153-204) + its new tlwh
+//   [M, M+U)      initiate a new track (kalman_filter.py:55-83)
+//   [M+U, M+U+A)  append a feature to a gallery ring (track.py:70-74): raw row + normalised row
+__global__ __launch_bounds__(64) void trk_commit_kernel(float* mean, float* cov, const int* __restrict__ lists, int M, int U, int A,
+                                                        const float* __restrict__ xyah, float* out_tlwh, float* gal_raw, float* gal_n,
+                                                        int gmax, int dim, const float* __restrict__ feat, const float* __restrict__ feat_n) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int* upd_slot = lists;
+    const int* upd_det = lists + M;
+    const int* ini_slot = lists + 2 * M;
+    const int* ini_det = lists + 2 * M + U;
+    const int* ap_slot = lists + 2 * M + 2 * U;
+    const int* ap_pos = ap_slot + A;
+    const int* ap_det = ap_pos + A;
+    if (b < M) {
+        const int i = lane >> 3, j = lane & 7;
+        float* P = cov + (size_t)upd_slot[b] * 64;
+        float* m = mean + (size_t)upd_slot[b] * 8;
+        const float* zz = xyah + (size_t)upd_det[b] * 4;
+        float S[4][4], L[4][4];
+        innovation_cov(P, m[3], S);
+        cholesky<4>(S, L);
+        float bi[4], bj[4], y[4], Ki[4], Kj[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) { bi[a] = P[i * 8 + a]; bj[a] = P[j * 8 + a]; }
+        fwd_solve<4>(L, bi, y); bwd_solve(L, y, Ki);
+        fwd_solve<4>(L, bj, y); bwd_solve(L, y, Kj);
+        float acc = 0.f;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            float u = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) u = u + S[a][c] * Kj[c];
+            acc = acc + Ki[a] * u;
+        }
+        const float pij = P[i * 8 + j] - acc;
+        float mi = m[i];
+        {
+            float dot = 0.f;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) dot = dot + Ki[a] * (zz[a] - m[a]);
+            mi = mi + dot;
+        }
+        P[i * 8 + j] = pij;
+        if (j == 0) m[i] = mi;
+        const float cx = __shfl(mi, 0), cy = __shfl(mi, 8), ar = __shfl(mi, 16), hh = __shfl(mi, 24);
+        if (lane == 0) {
+            float w = 0.f, h2 = hh;
+            if (hh > 0.f) w = ar * hh; else h2 = fmaxf(0.f, hh);
+            float* o = out_tlwh + (size_t)b * 4;
+            o[0] = cx - w / 2.0f; o[1] = cy - h2 / 2.0f; o[2] = w; o[3] = h2;
+        }
+    } else if (b < M + U) {
+        const int k = b - M, i = lane >> 3, j = lane & 7;
+        const int slot = ini_slot[k];
+        const float* zz = xyah + (size_t)ini_det[k] * 4;
+        const float h = zz[3];
+        float v = 0.f;
+        if (i == j) {
+            if (i == 2) v = (float)(1e-2 * 1e-2);
+            else if (i == 6) v = (float)(1e-5 * 1e-5);
+            else v = sq64((i < 4 ? 0.1f : 0.0625f) * h);
+        }
+        cov[(size_t)slot * 64 + lane] = v;
+        if (j == 0) mean[(size_t)slot * 8 + i] = i < 4 ? zz[i] : 0.f;
+    } else {
+        const int k = b - M - U;
+        const size_t dst = ((size_t)ap_slot[k] * gmax + ap_pos[k]) * dim;
+        const size_t src = (size_t)ap_det[k] * dim;
+        for (int c = lane; c < dim; c += 64) {
+            gal_raw[dst + c] = feat[src + c];
+            gal_n[dst + c] = feat_n[src + c];
+        }
+    }
+}
+
 // gallery[slot][pos] <- feat[det]   (track.py:70-74; FIFO realised as a ring, the host keeps heads)
 __global__ void gallery_append_kernel(float* gal, int gmax, int dim, const int* __restrict__ slot, const int* __restrict__ pos,
                                       const int* __restrict__ det, const float* __restrict__ feat, int count) {
@@ -406,6 +615,25 @@ void launch_gallery_append(float* gal, int gmax, int dim, const int* slot, const
                            int count, hipStream_t s) {
     if (count <= 0) return;
     hipLaunchKernelGGL(gallery_append_kernel, dim3(count), dim3(128), 0, s, gal, gmax, dim, slot, pos, det, feat, count);
+    KCHECK();
+}
+
+void launch_trk_assoc(float* mean, float* cov, const int* slots, int t, int do_predict, const float* det_tlwh,
+                      const float* det_xyah, int n, float* app, float* d2, float* iouc, hipStream_t s) {
+    if (t <= 0) return;
+    hipLaunchKernelGGL(trk_assoc_kernel, dim3(t), dim3(128), 0, s, mean, cov, slots, do_predict, det_tlwh, det_xyah, n, app, d2, iouc);
+    KCHECK();
+}
+void launch_cosine_min_mfma(const float* gal_n, const int* slots, const int* glen, int t, int gmax, int dim, const float* det_n,
+                            const unsigned char* has_feat, int n, float* cost, hipStream_t s) {
+    if (t <= 0 || n <= 0 || gmax <= 0) return;
+    hipLaunchKernelGGL(cosine_min_mfma_kernel, dim3(t, ceil_div(gmax, 64)), dim3(256), 0, s, gal_n, slots, glen, gmax, dim, det_n, has_feat, n, cost);
+    KCHECK();
+}
+void launch_trk_commit(float* mean, float* cov, const int* lists, int M, int U, int A, const float* xyah, float* out_tlwh,
+                       float* gal_raw, float* gal_n, int gmax, int dim, const float* feat, const float* feat_n, hipStream_t s) {
+    if (M + U + A <= 0) return;
+    hipLaunchKernelGGL(trk_commit_kernel, dim3(M + U + A), dim3(64), 0, s, mean, cov, lists, M, U, A, xyah, out_tlwh, gal_raw, gal_n, gmax, dim, feat, feat_n);
     KCHECK();
 }
 

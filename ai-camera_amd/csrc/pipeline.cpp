@@ -16,6 +16,10 @@
 #include "tracker.hpp"
 
 #include <algorithm>
+#include <condition_variable>
+#include <exception>
+#include <mutex>
+#include <thread>
 
 namespace aic {
 
@@ -29,12 +33,12 @@ struct Chunk {
     int frames = 0, first_slot = 0, n_crops = 0;
     PinBuf<float> h_boxes;
     PinBuf<int> h_frame_of, h_valid;
-    DevBuf<float> d_boxes, d_emb;
+    DevBuf<float> d_boxes, d_emb, d_emb_n;
     DevBuf<int> d_frame_of, d_valid;
     PinBuf<int> h_numdets, h_labels;
     PinBuf<float> h_detboxes, h_scores;
     std::vector<FrameDets> dets;
-    hipEvent_t done = nullptr;
+    hipEvent_t done = nullptr, ev_yolo = nullptr, ev_det = nullptr;
 };
 
 struct Pipeline {
@@ -76,16 +80,21 @@ struct Pipeline {
         const size_t maxc = (size_t)p.batch * p.max_persons;
         for (Chunk& c : ck) {
             c.h_boxes.alloc(maxc * 4), c.h_frame_of.alloc(maxc), c.h_valid.alloc(maxc);
-            c.d_boxes.alloc(maxc * 4), c.d_frame_of.alloc(maxc), c.d_valid.alloc(maxc), c.d_emb.alloc(maxc * dim);
+            c.d_boxes.alloc(maxc * 4), c.d_frame_of.alloc(maxc), c.d_valid.alloc(maxc), c.d_emb.alloc(maxc * dim), c.d_emb_n.alloc(maxc * dim);
             c.h_numdets.alloc(p.batch), c.h_labels.alloc((size_t)p.batch * p.max_det);
             c.h_detboxes.alloc((size_t)p.batch * p.max_det * 4), c.h_scores.alloc((size_t)p.batch * p.max_det);
             c.dets.resize(p.batch);
             HIP_CHECK(hipEventCreateWithFlags(&c.done, hipEventDisableTiming));
+            HIP_CHECK(hipEventCreateWithFlags(&c.ev_yolo, hipEventDisableTiming));
+            HIP_CHECK(hipEventCreateWithFlags(&c.ev_det, hipEventDisableTiming));
         }
     }
     ~Pipeline() {
-        for (Chunk& c : ck)
+        for (Chunk& c : ck) {
             if (c.done) (void)hipEventDestroy(c.done);
+            if (c.ev_yolo) (void)hipEventDestroy(c.ev_yolo);
+            if (c.ev_det) (void)hipEventDestroy(c.ev_det);
+        }
     }
 
     bool tracked_class(int c) const { return c >= 0 && c < 128 && ((prm.track_class_mask[c >> 6] >> (c & 63)) & 1ull); }
@@ -114,12 +123,18 @@ struct Pipeline {
             launch_letterbox(f0, frames, geom, 1, yolo->dtype, yolo->input(), s);
         }
         yolo->run(frames, s);
-        yolo->decode_nms(frames, prm.conf_thresh, prm.iou_thresh, prm.max_det, &geom, s);
-        HIP_CHECK(hipMemcpyAsync(c.h_numdets.p, yolo->d_numdets.p, (size_t)frames * 4, hipMemcpyDeviceToHost, s));
-        HIP_CHECK(hipMemcpyAsync(c.h_detboxes.p, yolo->d_out_boxes_orig.p, (size_t)frames * prm.max_det * 16, hipMemcpyDeviceToHost, s));
-        HIP_CHECK(hipMemcpyAsync(c.h_scores.p, yolo->d_out_scores.p, (size_t)frames * prm.max_det * 4, hipMemcpyDeviceToHost, s));
-        HIP_CHECK(hipMemcpyAsync(c.h_labels.p, yolo->d_out_labels.p, (size_t)frames * prm.max_det * 4, hipMemcpyDeviceToHost, s));
-        if (!prm.inject) HIP_CHECK(hipStreamSynchronize(s));
+        // decode + NMS + read-back on the side stream: a few latency-bound blocks that overlap the
+        // (CU-filling) ReID launch group instead of serialising the main stream
+        hipStream_t sd = dev->s_det;
+        HIP_CHECK(hipEventRecord(c.ev_yolo, s));
+        HIP_CHECK(hipStreamWaitEvent(sd, c.ev_yolo, 0));
+        yolo->decode_nms(frames, prm.conf_thresh, prm.iou_thresh, prm.max_det, &geom, sd);
+        HIP_CHECK(hipMemcpyAsync(c.h_numdets.p, yolo->d_numdets.p, (size_t)frames * 4, hipMemcpyDeviceToHost, sd));
+        HIP_CHECK(hipMemcpyAsync(c.h_detboxes.p, yolo->d_out_boxes_orig.p, (size_t)frames * prm.max_det * 16, hipMemcpyDeviceToHost, sd));
+        HIP_CHECK(hipMemcpyAsync(c.h_scores.p, yolo->d_out_scores.p, (size_t)frames * prm.max_det * 4, hipMemcpyDeviceToHost, sd));
+        HIP_CHECK(hipMemcpyAsync(c.h_labels.p, yolo->d_out_labels.p, (size_t)frames * prm.max_det * 4, hipMemcpyDeviceToHost, sd));
+        HIP_CHECK(hipEventRecord(c.ev_det, sd));
+        if (!prm.inject) HIP_CHECK(hipEventSynchronize(c.ev_det));
         // detection set handed to ReID + association
         int nc = 0;
         for (int f = 0; f < frames; ++f) {
@@ -151,8 +166,13 @@ struct Pipeline {
             }
             reid->run(nc, s);
             HIP_CHECK(hipMemcpyAsync(c.d_emb.p, reid->embeddings(), (size_t)nc * dim * 4, hipMemcpyDeviceToDevice, s));
+            {   // matching.py:126-130 for every detection of the launch group at once
+                Prof pr(*dev, PROF_TRK, s, 0, (double)nc * dim * 8);
+                launch_normalize_rows(c.d_emb.p, c.d_emb_n.p, nc, dim, s);
+            }
             HIP_CHECK(hipMemcpyAsync(c.h_valid.p, c.d_valid.p, (size_t)nc * 4, hipMemcpyDeviceToHost, s));
         }
+        HIP_CHECK(hipStreamWaitEvent(s, c.ev_det, 0));   // join: the next chunk's YOLO reuses the head buffers
         HIP_CHECK(hipEventRecord(c.done, s));
     }
 
@@ -166,7 +186,7 @@ struct Pipeline {
             for (int i = 0; i < fd.n; ++i) has[i] = c.h_valid.p[fd.crop0 + i] ? 1 : 0;   // empty crop -> feature None
             trk.predict();
             trk.update(fd.tlwh.data(), fd.conf.data(), fd.cls.data(), fd.n ? c.d_emb.p + (size_t)fd.crop0 * dim : nullptr,
-                       AIC_DEVICE, has.data(), fd.n, dim);
+                       AIC_DEVICE, has.data(), fd.n, dim, fd.n ? c.d_emb_n.p + (size_t)fd.crop0 * dim : nullptr);
             const int o = out_base + f;
             if (n_tracks) n_tracks[o] = (int32_t)trk.outputs.size();
             for (size_t k = 0; k < trk.outputs.size() && (int)k < prm.max_persons; ++k) {
@@ -199,11 +219,61 @@ struct Pipeline {
         const int nchunks = ceil_div(count, prm.batch);
         if (!nchunks) return;
         auto span = [&](int k) { return std::min(prm.batch, count - k * prm.batch); };
-        stage_a(ck[0], slot, span(0));
-        for (int k = 0; k < nchunks; ++k) {
-            if (k + 1 < nchunks) stage_a(ck[(k + 1) & 1], slot + (k + 1) * prm.batch, span(k + 1));
-            stage_b(ck[k & 1], k * prm.batch, n_tracks, tracks6, track_conf, n_dets, det_boxes, det_scores, det_labels);
+        // Two host threads: the producer issues the detection/ReID launch groups (stage A, ~100 launches
+        // per group), this thread walks the frames of each finished group through the tracker (stage B:
+        // small launches + syncs). A chunk context is reissued only after stage B released it.
+        std::mutex mu;
+        std::condition_variable cv;
+        int issued = 0, consumed = 0;
+        std::exception_ptr perr;
+        std::thread producer([&] {
+            try {
+                dev->use();
+                for (int k = 0; k < nchunks; ++k) {
+                    {
+                        std::unique_lock<std::mutex> lk(mu);
+                        cv.wait(lk, [&] { return k < consumed + 2; });
+                    }
+                    stage_a(ck[k & 1], slot + k * prm.batch, span(k));
+                    {
+                        std::lock_guard<std::mutex> lk(mu);
+                        issued = k + 1;
+                    }
+                    cv.notify_all();
+                }
+            } catch (...) {
+                std::lock_guard<std::mutex> lk(mu);
+                perr = std::current_exception();
+                issued = nchunks;
+                cv.notify_all();
+            }
+        });
+        std::exception_ptr cerr;
+        try {
+            for (int k = 0; k < nchunks; ++k) {
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return issued > k; });
+                    if (perr) break;
+                }
+                stage_b(ck[k & 1], k * prm.batch, n_tracks, tracks6, track_conf, n_dets, det_boxes, det_scores, det_labels);
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    consumed = k + 1;
+                }
+                cv.notify_all();
+            }
+        } catch (...) {
+            cerr = std::current_exception();
         }
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            consumed = nchunks + 2;   // never block the producer again
+        }
+        cv.notify_all();
+        producer.join();
+        if (perr) std::rethrow_exception(perr);
+        if (cerr) std::rethrow_exception(cerr);
     }
 };
 

@@ -34,6 +34,7 @@ Device& device(int id) {
         d->n_cu = prop.multiProcessorCount;
         HIP_CHECK(hipStreamCreateWithFlags(&d->s_main, hipStreamNonBlocking));
         HIP_CHECK(hipStreamCreateWithFlags(&d->s_trk, hipStreamNonBlocking));
+        HIP_CHECK(hipStreamCreateWithFlags(&d->s_det, hipStreamNonBlocking));
         g_devs[id] = std::move(d);
     }
     HIP_CHECK(hipSetDevice(id));
@@ -41,6 +42,7 @@ Device& device(int id) {
 }
 
 void Device::prof_begin(int cls, hipStream_t s, double fl, double by) {
+    std::lock_guard<std::mutex> lk(prof_mu);
     Pair p;
     if (!pool.empty()) {
         p = pool.back();
@@ -56,12 +58,14 @@ void Device::prof_begin(int cls, hipStream_t s, double fl, double by) {
 }
 
 void Device::prof_end(int cls, hipStream_t s) {
+    std::lock_guard<std::mutex> lk(prof_mu);
     if (pending[cls].empty()) return;
     (void)hipEventRecord(pending[cls].back().b, s);
 }
 
 void Device::prof_collect() {
     (void)hipDeviceSynchronize();
+    std::lock_guard<std::mutex> lk(prof_mu);
     for (int c = 0; c < AIC_PROF_CLASSES; ++c) {
         for (auto& p : pending[c]) {
             float t = 0.f;

@@ -37,25 +37,30 @@ void Tracker::ensure_dim(int d) {
     AIC_REQUIRE(dim == 0, AIC_ERR_INVALID, "feature dimension changed between updates");
     AIC_REQUIRE(d > 0 && d <= 1024, AIC_ERR_INVALID, "feature dimension must be in 1..1024");
     dim = d;
-    d_gal.alloc((size_t)cap * gmax * dim);
+    d_gal_raw.alloc((size_t)cap * gmax * dim);
+    d_gal_n.alloc((size_t)cap * gmax * dim);
 }
 
 void Tracker::predict() {   // tracker_core.py:44-49 -> track.py:76-80
+    if (pending_predict) flush_predict();      // two predicts in a row: run the first one now
+    for (auto& t : tracks) { t.age += 1; t.tsu += 1; }
+    pending_predict = !tracks.empty();         // the kernel runs fused into the next association launch
+}
+
+void Tracker::flush_predict() {
+    if (!pending_predict) return;
+    pending_predict = false;
     dev->use();
     const int T = (int)tracks.size();
-    for (auto& t : tracks) { t.age += 1; t.tsu += 1; }
     if (!T) return;
     hipStream_t s = dev->s_trk;
-    // own staging pair: update() rewrites h_stage while this copy may still be in flight
-    HIP_CHECK(hipStreamSynchronize(s));
+    HIP_CHECK(hipStreamSynchronize(s));        // h_slots may still be the source of an earlier copy
     h_slots.ensure((size_t)T);
     d_slots.ensure((size_t)T);
     for (int i = 0; i < T; ++i) h_slots.p[i] = tracks[i].slot;
     HIP_CHECK(hipMemcpyAsync(d_slots.p, h_slots.p, (size_t)T * 4, hipMemcpyHostToDevice, s));
-    {
-        Prof pr(*dev, PROF_TRK, s, 0, (double)T * 72 * 4 * 2);
-        launch_kf_predict(d_mean.p, d_cov.p, d_slots.p, T, s);
-    }
+    Prof pr(*dev, PROF_TRK, s, 0, (double)T * 72 * 4 * 2);
+    launch_kf_predict(d_mean.p, d_cov.p, d_slots.p, T, s);
 }
 
 // linear_assignment.py:91-157 + tracker_core.py:83-177 on precomputed full matrices.
@@ -137,7 +142,7 @@ void Tracker::match(int T, int N, const float* app, const float* maha, const flo
 static inline int round_half_even(float v) { return (int)std::nearbyintf(v); }
 
 void Tracker::update(const float* det_tlwh, const float* conf, const int32_t* cls, const float* feat, int feat_mem,
-                     const uint8_t* has_feat, int n, int dim_in) {
+                     const uint8_t* has_feat, int n, int dim_in, const float* feat_n) {
     dev->use();
     hipStream_t s = dev->s_trk;
     const int T = (int)tracks.size();
@@ -167,11 +172,18 @@ void Tracker::update(const float* det_tlwh, const float* conf, const int32_t* cl
             d_featp = d_feat.p;
         }
     }
+    const float* d_featn = feat_n;
+    if (any_feat && !d_featn) {                 // rows / max(||row||, 1e-7)  (matching.py:126-130), once per frame
+        d_detn.ensure((size_t)n * dim);
+        launch_normalize_rows(d_featp, d_detn.p, n, dim, s);
+        d_featn = d_detn.p;
+    }
 
     // ---- packed per-frame parameters: slots[T] glen[T] | tlwh[n*4] xyah[n*4] | has[n]
     const size_t off_slots = 0, off_glen = (size_t)T * 4, off_tlwh = (size_t)T * 8;
     const size_t off_xyah = off_tlwh + (size_t)n * 16, off_has = off_xyah + (size_t)n * 16;
     const size_t stage_bytes = ((off_has + n + 15) / 16) * 16;
+    if (pending_predict && !(T > 0 && n > 0)) flush_predict();   // nothing to fuse it into
     last_t = T, last_n = n;
     last_app.assign((size_t)T * n, kInfty);
     last_maha.assign((size_t)T * n, 0.f);
@@ -196,14 +208,11 @@ void Tracker::update(const float* det_tlwh, const float* conf, const int32_t* cl
         {
             Prof pr(*dev, PROF_TRK, s, any_feat ? 2.0 * T * gmax * (double)n * dim : 0.0,
                     any_feat ? ((double)T * gmax + n) * dim * 4 : 0.0);
-            launch_fill(d_cost.p, kInfty, tn, s);
-            if (any_feat && dim > 0) {
-                d_detn.ensure((size_t)n * dim);
-                launch_normalize_rows(d_featp, d_detn.p, n, dim, s);
-                launch_cosine_min(d_gal.p, d_slots, d_glen, T, gmax, dim, d_detn.p, d_has, n, d_cost.p, s);
-            }
-            launch_kf_gating(d_mean.p, d_cov.p, d_slots, T, d_xy, n, 1, 0, d_cost.p + tn, s);
-            launch_iou_cost(nullptr, d_mean.p, d_slots, T, d_tl, n, d_cost.p + 2 * tn, s);
+            launch_trk_assoc(d_mean.p, d_cov.p, d_slots, T, pending_predict ? 1 : 0, d_tl, d_xy, n, d_cost.p, d_cost.p + tn,
+                             d_cost.p + 2 * tn, s);
+            pending_predict = false;
+            if (any_feat && dim > 0)
+                launch_cosine_min_mfma(d_gal_n.p, d_slots, d_glen, T, gmax, dim, d_featn, d_has, n, d_cost.p, s);
         }
         HIP_CHECK(hipMemcpyAsync(h_cost.p, d_cost.p, 3 * tn * 4, hipMemcpyDeviceToHost, s));
         HIP_CHECK(hipStreamSynchronize(s));
@@ -296,10 +305,7 @@ void Tracker::update(const float* det_tlwh, const float* conf, const int32_t* cl
         h_tlwh.ensure((size_t)std::max(M, 1) * 4);
         {
             Prof pr(*dev, PROF_TRK, s, 0, (double)(M + U) * 72 * 4 * 2 + (double)A * dim * 8);
-            launch_kf_update(d_mean.p, d_cov.p, d, d_xy, d + M, M, d_tlwh.p, s);
-            launch_kf_initiate_idx(d_xy, d + 2 * M + U, U, d_mean.p, d_cov.p, d + 2 * M, s);
-            if (A) launch_gallery_append(d_gal.p, gmax, dim, d + 2 * M + 2 * U, d + 2 * M + 2 * U + A,
-                                         d + 2 * M + 2 * U + 2 * A, d_featp, A, s);
+            launch_trk_commit(d_mean.p, d_cov.p, d, M, U, A, d_xy, d_tlwh.p, d_gal_raw.p, d_gal_n.p, gmax, dim, d_featp, d_featn, s);
         }
         if (M) HIP_CHECK(hipMemcpyAsync(h_tlwh.p, d_tlwh.p, (size_t)M * 16, hipMemcpyDeviceToHost, s));
         HIP_CHECK(hipStreamSynchronize(s));
@@ -472,11 +478,13 @@ int aic_appearance_cost(int device_id, const float* galleries, const int32_t* ga
         int* gl = t.up(gallery_len, tn);
         float* f = t.up(det_feat, (size_t)n * dim);
         float* fn = t.raw<float>((size_t)n * dim);
+        float* gn = t.raw<float>((size_t)tn * gmax * dim);
         unsigned char* hf = has_feat ? t.up(has_feat, n) : nullptr;
         float* c = t.raw<float>((size_t)tn * n);
         launch_fill(c, kInfty, (size_t)tn * n, d.s_trk);
         launch_normalize_rows(f, fn, n, dim, d.s_trk);
-        launch_cosine_min(g, sl, gl, tn, gmax, dim, fn, hf, n, c, d.s_trk);
+        launch_normalize_rows(g, gn, tn * gmax, dim, d.s_trk);
+        launch_cosine_min_mfma(gn, sl, gl, tn, gmax, dim, fn, hf, n, c, d.s_trk);
         t.down(cost, c, (size_t)tn * n);
         t.sync();
     });
@@ -541,6 +549,7 @@ int aic_tracker_export(aic_tracker* t, int cap, int32_t* track_id, int32_t* stat
         std::vector<float> hm, hc;
         if (mean || cov) {
             k.dev->use();
+            k.flush_predict();
             hm.resize((size_t)k.cap * 8);
             hc.resize((size_t)k.cap * 64);
             HIP_CHECK(hipMemcpyAsync(hm.data(), k.d_mean.p, hm.size() * 4, hipMemcpyDeviceToHost, k.dev->s_trk));
@@ -573,7 +582,7 @@ int aic_tracker_export_gallery(aic_tracker* t, int index, float* out, int cap_ro
         k.dev->use();
         for (int g = 0; g < r.glen; ++g) {
             const int pos = (r.ghead + g) % k.gmax;
-            HIP_CHECK(hipMemcpyAsync(out + (size_t)g * k.dim, k.d_gal.p + ((size_t)r.slot * k.gmax + pos) * k.dim,
+            HIP_CHECK(hipMemcpyAsync(out + (size_t)g * k.dim, k.d_gal_raw.p + ((size_t)r.slot * k.gmax + pos) * k.dim,
                                      (size_t)k.dim * 4, hipMemcpyDeviceToHost, k.dev->s_trk));
         }
         HIP_CHECK(hipStreamSynchronize(k.dev->s_trk));

@@ -23,7 +23,8 @@ struct Tracker {
     aic_tracker_params prm{};
     int cap = 0, dim = 0, gmax = 0;
     bool unlimited = false;
-    DevBuf<float> d_mean, d_cov, d_gal;
+    DevBuf<float> d_mean, d_cov, d_gal_raw, d_gal_n;   // galleries: raw rows (export) + unit rows (cost kernel)
+    bool pending_predict = false;                       // Kalman predict is folded into the next association launch
     std::vector<TrackRec> tracks;
     std::vector<int> free_slots;
     int next_id = 1;
@@ -45,8 +46,10 @@ struct Tracker {
     void ensure_dim(int d);
     void predict();
     // feat may be host or device memory ([n, dim] fp32)
+    void flush_predict();
+    // feat_n: the same rows already normalised on the device (rows / max(||row||, 1e-7)), or NULL
     void update(const float* det_tlwh, const float* conf, const int32_t* cls, const float* feat, int feat_mem,
-                const uint8_t* has_feat, int n, int dim_in);
+                const uint8_t* has_feat, int n, int dim_in, const float* feat_n = nullptr);
     void match(int T, int N, const float* app, const float* maha, const float* iou,
                std::vector<std::pair<int, int>>& matches, std::vector<int>& unmatched_t, std::vector<int>& unmatched_d);
 };

@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Summarise a rocprofv3 --kernel-trace run of bench.py: per-kernel totals and a per-layer table of the
+conv launches (dispatch order within a launch group = graph order: YOLO convs, then ReID convs)."""
+import collections
+import csv
+import glob
+import importlib
+import os
+import re
+import statistics
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+ef = importlib.import_module("ai-camera_amd.engine_file")
+
+
+def main(d, frames=16, crops=480, top=30):
+    trace = glob.glob(os.path.join(d, "*kernel_trace.csv"))[0]
+    rows = list(csv.DictReader(open(trace)))
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    tot = collections.defaultdict(lambda: [0, 0.0])
+    for r in rows:
+        n = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "")
+        n = re.sub(r"<.*", "", n)
+        m = re.search(r"aic(\d+)([a-z_0-9]+?)(I|E)", n)
+        if n.startswith("_ZN3aic"):
+            n = re.sub(r"^_ZN3aic\d+", "", n)
+            n = re.sub(r"(IDF16_|If|EvN|EEv|Ev).*", "", n)
+        t = tot[n]
+        t[0] += 1
+        t[1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    all_us = sum(v[1] for v in tot.values())
+    print(f"{'kernel':42s} {'calls':>7s} {'total ms':>9s} {'%':>6s} {'avg us':>8s}")
+    for n, (c, us) in sorted(tot.items(), key=lambda kv: -kv[1][1])[:24]:
+        print(f"{n[:42]:42s} {c:7d} {us / 1e3:9.2f} {100 * us / all_us:6.1f} {us / c:8.1f}")
+    conv = [r for r in rows if "conv_igemm" in r["Kernel_Name"]]
+    layers = []
+    for name, g, n in (("yolo", ef.build_yolov8("n", calibrate=False), frames), ("reid", ef.build_reid(calibrate=False), crops)):
+        for o in g.ops:
+            if o[0] == 1:
+                h, w, _, _ = g.buffers[o[4]]
+                layers.append((name, g.names[o[15]], n * h * w, o[6], o[3] * o[7] * o[8]))
+    per = len(layers)
+    groups = len(conv) // per
+    conv = conv[len(conv) - groups * per:]
+    dur = [[] for _ in range(per)]
+    for i, r in enumerate(conv):
+        dur[i % per].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    out = []
+    for (name, ln, m, co, k), ts in zip(layers, dur):
+        t = statistics.median(ts)
+        out.append((t, name, ln, m, co, k, 2.0 * m * co * k / t / 1e6))
+    total = sum(o[0] for o in out)
+    print(f"\nconv launches per group {per}, groups {groups}, conv us per group {total:.0f} "
+          f"(yolo {sum(o[0] for o in out if o[1] == 'yolo'):.0f}, reid {sum(o[0] for o in out if o[1] == 'reid'):.0f}); "
+          f"overall {sum(2.0 * o[3] * o[4] * o[5] for o in out) / total / 1e6:.0f} TFLOP/s")
+    for t, name, ln, m, co, k, tf in sorted(out, reverse=True)[:top]:
+        print(f"{t:8.1f} us {100 * t / total:5.1f}%  {name} {ln:18s} M={m:8d} N={co:4d} K={k:5d} {tf:7.1f} TF")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], *(int(v) for v in sys.argv[2:]))
