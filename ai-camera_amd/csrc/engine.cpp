@@ -10,6 +10,7 @@
 #include "engine.hpp"
 
 #include <cmath>
+#include <cstdlib>
 #include <fstream>
 
 namespace aic {
@@ -155,6 +156,22 @@ Model::Model(Device& d, const void* blob, size_t nbytes, int dtype_, int max_ite
             ++n_convs;
         }
     }
+    // ---- fusion: conv3x3/1 (3->64)+ReLU followed by max-pool 3x3/2 of exactly that tensor (ReID stem)
+    if (dtype == AIC_F16 && !getenv("AICAM_NO_FUSE")) {
+        for (size_t i = 0; i + 1 < ops.size(); ++i) {
+            const int* c = ops[i].v;
+            const int* p = ops[i + 1].v;
+            if (c[0] != OP_CONV || p[0] != OP_MAXPOOL3S2) continue;
+            const BufDesc& cb = bufs[c[4]];
+            const bool conv_ok = c[3] == 3 && c[6] == 64 && c[7] == 3 && c[8] == 3 && c[9] == 1 && c[10] == 1 && c[11] == 2 &&
+                                 c[14] == 0 && c[5] == 0 && cb.c == 64 && !cb.f32 && cb.w == 64 && cb.h % 8 == 0 && c[2] == 0;
+            const bool pool_ok = p[1] == c[4] && p[2] == 0 && p[3] == 64 && !bufs[p[4]].f32;
+            bool other_reader = false;
+            for (size_t j = 0; j < ops.size(); ++j)
+                if (j != i + 1 && (ops[j].v[1] == c[4] || (ops[j].v[0] == OP_CONV && ops[j].v[14] && ops[j].v[12] == c[4]))) other_reader = true;
+            if (conv_ok && pool_ok && !other_reader) { ops[i].fuse = 1; ops[i + 1].fuse = 2; }
+        }
+    }
     if (kind == KIND_YOLO) {
         AIC_REQUIRE(nout <= 4, AIC_ERR_FORMAT, "at most 4 detection levels");
         n_anchors = 0;
@@ -176,10 +193,21 @@ Model::Model(Device& d, const void* blob, size_t nbytes, int dtype_, int max_ite
 void Model::run(int n, hipStream_t s) {
     AIC_REQUIRE(n >= 0 && n <= max_items, AIC_ERR_CAPACITY, "batch exceeds the engine's max_items");
     if (n == 0) return;
-    for (const OpDesc& o : ops) {
+    for (size_t oi = 0; oi < ops.size(); ++oi) {
+        const OpDesc& o = ops[oi];
         const int* v = o.v;
         const BufDesc& sb = bufs[v[1]];
         const BufDesc& db = bufs[v[4]];
+        if (o.fuse == 2) continue;
+        if (o.fuse == 1) {
+            const ConvWeights& w = weights[v[15]];
+            const int* pv = ops[oi + 1].v;
+            const BufDesc& pb = bufs[pv[4]];
+            const double fl = 2.0 * n * sb.h * sb.w * 64.0 * 27.0;
+            Prof pr(*dev, PROF_CONV_DIRECT, s, fl, (double)n * (sb.h * sb.w * 16.0 + pb.h * pb.w * 128.0));
+            launch_reid_stem_pool(sb.p, w.w.p, w.bias.p, pb.p, n, sb.h, sb.w, w.Kp, pb.c, pv[5], s);
+            continue;
+        }
         if (v[0] == OP_CONV) {
             const ConvWeights& w = weights[v[15]];
             ConvArgs a{};

@@ -9,7 +9,7 @@ enum { KIND_YOLO = 1, KIND_REID = 2 };
 
 struct BufDesc { int h, w, c, f32; void* p; size_t per_item; int esize; };
 struct ConvWeights { DevBuf<char> w; DevBuf<float> bias; int cout, cin, cin_eff, kh, kw, K, Kp, cout_pad; };
-struct OpDesc { int v[20]; };
+struct OpDesc { int v[20]; int fuse = 0; };   // fuse: 1 = conv fused with the max-pool that follows, 2 = skipped (absorbed)
 struct OutDesc { int v[8]; };
 
 struct Model {

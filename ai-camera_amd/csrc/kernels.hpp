@@ -27,6 +27,10 @@ struct ConvArgs {
 // dtype: AIC_F16 or AIC_F32 (type of x / w / res and, unless out_f32, y)
 void launch_conv_igemm(int dtype, const ConvArgs& a, hipStream_t s);
 
+// conv 3x3/1 (3->64) + ReLU + max-pool 3x3/2 fused (fp16, W == 64, H % 8 == 0): ReID stem
+void launch_reid_stem_pool(const void* x, const void* w, const float* bias, void* y, int n, int H, int W, int Kp, int y_cs,
+                           int y_coff, hipStream_t s);
+
 struct EltArgs {
     const void* src; void* dst;
     int n, h, w, c;            // source extent, channels processed

@@ -585,6 +585,115 @@ void launch_conv_igemm(int dtype, const ConvArgs& a, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Fused ReID stem: conv 3x3/1 (3 -> 64) + bias + ReLU + max-pool 3x3/2 (pad 1) in one kernel, fp16.
+// The unfused pair writes and re-reads a [N,128,64,64] tensor (1 MB per crop) for 14 MMAC of work;
+// here a block owns 4 pooled rows of one crop: the 11x66 input patch (RGB0) and the 9x64x64 conv
+// tile live in LDS only, K = 27 is padded to one v_mfma_f32_16x16x32_f16 per 16 px x 16 ch tile
+// (the im2col fragment is gathered from the patch), and only the pooled [N,64,32,64] tensor
+// reaches HBM.  PyTorch semantics: conv zero-pads its input, the pool ignores out-of-image taps.
+struct StemArgs {
+    const void* x; const void* w; const float* bias; void* y;
+    int n, H, W, Kp, y_cs, y_coff;   // input [n][H][W][8]; output [n][H/2][W/2][y_cs]
+};
+
+__global__ __launch_bounds__(256) void reid_stem_pool_kernel(const StemArgs a) {
+    constexpr int PT = 4, CR = 2 * PT + 1, IR = 2 * PT + 3, CW = 64, PW = CW + 2, CO = 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint2* patch = reinterpret_cast<uint2*>(smem);                        // [IR][PW] pixels x 4 halves
+    char* convbuf = smem + ((IR * PW * 8 + 15) / 16) * 16;               // [CR][CW] pixels x 128 B (swizzled chunks)
+    const half_t* patch_h = reinterpret_cast<const half_t*>(smem);
+
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, r = lane & 15, q = lane >> 4;
+    const int Hp = a.H / 2, Wp = a.W / 2;
+    const int groups = Hp / PT;
+    const int img = blockIdx.x / groups, rg = blockIdx.x - img * groups;
+    const int oy0 = rg * PT, cr0 = 2 * oy0 - 1, ir0 = cr0 - 1;
+    const half_t* xg = reinterpret_cast<const half_t*>(a.x) + (size_t)img * a.H * a.W * 8;
+
+    for (int idx = t; idx < IR * PW; idx += 256) {
+        const int iy = idx / PW, ix = idx - iy * PW;
+        const int gy = ir0 + iy, gx = ix - 1;
+        uint2 v = make_uint2(0u, 0u);
+        if ((unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W)
+            v = *reinterpret_cast<const uint2*>(xg + ((size_t)gy * a.W + gx) * 8);
+        patch[idx] = v;
+    }
+    // weight fragments (A operand): lane (r, q) of channel tile ct holds w[16ct + r][k = 8q .. 8q+7]
+    const half_t* wg = reinterpret_cast<const half_t*>(a.w);
+    half8 wf[4];
+    int poff[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = 8 * q + j;
+        const int tap = k / 3, ci = k - 3 * tap, kh = tap / 3, kw = tap - 3 * kh;
+        poff[j] = k < 27 ? (kh * PW + kw) * 4 + ci : -1;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+            wf[ct][j] = k < 27 ? wg[(size_t)(16 * ct + r) * a.Kp + tap * 8 + ci] : (half_t)0.f;
+    }
+    floatx4 b4[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) b4[ct] = *reinterpret_cast<const floatx4*>(a.bias + 16 * ct + 4 * q);
+    __syncthreads();
+
+    for (int tile = wv; tile < CR * (CW / 16); tile += 4) {
+        const int cr = tile / (CW / 16), cx = (tile - cr * (CW / 16)) * 16 + r;
+        const int base = (cr * PW + cx) * 4;
+        half8 xf;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xf[j] = poff[j] >= 0 ? patch_h[base + poff[j]] : (half_t)0.f;
+        char* dst = convbuf + (size_t)(cr * CW + cx) * 128 + (q & 1) * 8;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ct], xf, acc, 0, 0, 0);
+            half4 h;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) h[e] = (half_t)fmaxf(acc[e] + b4[ct][e], 0.f);
+            const int chunk = 2 * ct + (q >> 1);                         // 16-byte chunk of the pixel's 64 channels
+            *reinterpret_cast<half4*>(dst + ((chunk ^ (cx & 7)) * 16)) = h;
+        }
+    }
+    __syncthreads();
+
+    half_t* yg = reinterpret_cast<half_t*>(a.y);
+    for (int o = t; o < PT * Wp * (CO / 8); o += 256) {
+        const int g = o & 7, px = (o >> 3) % Wp, py = (o >> 3) / Wp;
+        half8 m;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = (half_t)0.f;                  // post-ReLU values are >= 0
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int cr = 2 * py + dy;
+            if ((unsigned)(cr0 + cr) >= (unsigned)a.H) continue;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int cc = 2 * px - 1 + dx;
+                if ((unsigned)cc >= (unsigned)a.W) continue;
+                const half8 v = *reinterpret_cast<const half8*>(convbuf + (size_t)(cr * CW + cc) * 128 + ((g ^ (cc & 7)) * 16));
+#pragma unroll
+                for (int e = 0; e < 8; ++e) m[e] = v[e] > m[e] ? v[e] : m[e];
+            }
+        }
+        *reinterpret_cast<half8*>(yg + ((size_t)(img * Hp + oy0 + py) * Wp + px) * a.y_cs + a.y_coff + g * 8) = m;
+    }
+}
+
+void launch_reid_stem_pool(const void* x, const void* w, const float* bias, void* y, int n, int H, int W, int Kp, int y_cs,
+                           int y_coff, hipStream_t s) {
+    if (n <= 0) return;
+    StemArgs a{x, w, bias, y, n, H, W, Kp, y_cs, y_coff};
+    const size_t lds = ((11 * 66 * 8 + 15) / 16) * 16 + (size_t)9 * 64 * 128;
+    static bool attr = false;
+    if (!attr) {
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(reid_stem_pool_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = true;
+    }
+    hipLaunchKernelGGL(reid_stem_pool_kernel, dim3(n * (H / 2 / 4)), dim3(256), lds, s, a);
+    KCHECK();
+}
+
+// ------------------------------------------------------------------------------------------------
 // Small NHWC ops. One thread per 16-byte channel chunk (8 halves / 4 floats); HBM/L2-bound.
 template <typename T> struct Vec;
 template <> struct Vec<half_t> { typedef half8 type; static constexpr int N = 8; };

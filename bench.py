@@ -43,10 +43,10 @@ PEAK_F32_TFLOPS = 157.3
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--steps", type=int, default=12)
     p.add_argument("--warmup", type=int, default=3)
-    p.add_argument("--ring", type=int, default=32, help="rendered frames R; a step processes 2R frames")
-    p.add_argument("--batch", type=int, default=16, help="frames per detection/ReID launch group")
+    p.add_argument("--ring", type=int, default=64, help="rendered frames R; a step processes 2R frames")
+    p.add_argument("--batch", type=int, default=32, help="frames per detection/ReID launch group")
     p.add_argument("--persons", type=int, default=30)
     p.add_argument("--width", type=int, default=1280)
     p.add_argument("--height", type=int, default=720)
