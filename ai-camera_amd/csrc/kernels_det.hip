@@ -29,17 +29,37 @@ __global__ void decode_kernel(const DetArgs a) {
     const size_t pix = (size_t)img * L.h * L.w + cell;
     const float* d = L.box + pix * (4 * a.reg_max);
     float dist[4];
-    for (int sd = 0; sd < 4; ++sd) {
-        const float* v = d + sd * a.reg_max;
-        float mx = v[0];
-        for (int k = 1; k < a.reg_max; ++k) mx = fmaxf(mx, v[k]);
-        float sum = 0.f, ex = 0.f;
-        for (int k = 0; k < a.reg_max; ++k) {
-            const float e = expf(v[k] - mx);
-            sum += e;
-            ex += e * (float)k;
+    if (a.reg_max == 16) {   // the common case: 16-byte loads, bins in registers
+        for (int sd = 0; sd < 4; ++sd) {
+            const float4* v4 = reinterpret_cast<const float4*>(d + sd * 16);
+            float v[16];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const float4 x = v4[k]; v[4 * k] = x.x; v[4 * k + 1] = x.y; v[4 * k + 2] = x.z; v[4 * k + 3] = x.w; }
+            float mx = v[0];
+#pragma unroll
+            for (int k = 1; k < 16; ++k) mx = fmaxf(mx, v[k]);
+            float sum = 0.f, ex = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const float e = expf(v[k] - mx);
+                sum += e;
+                ex += e * (float)k;
+            }
+            dist[sd] = ex / sum;
         }
-        dist[sd] = ex / sum;
+    } else {
+        for (int sd = 0; sd < 4; ++sd) {
+            const float* v = d + sd * a.reg_max;
+            float mx = v[0];
+            for (int k = 1; k < a.reg_max; ++k) mx = fmaxf(mx, v[k]);
+            float sum = 0.f, ex = 0.f;
+            for (int k = 0; k < a.reg_max; ++k) {
+                const float e = expf(v[k] - mx);
+                sum += e;
+                ex += e * (float)k;
+            }
+            dist[sd] = ex / sum;
+        }
     }
     const float cx = (float)gx + 0.5f, cy = (float)gy + 0.5f, st = (float)L.stride;
     float* b = a.boxes + idx * 4;
@@ -50,9 +70,20 @@ __global__ void decode_kernel(const DetArgs a) {
     const float* c = L.cls + pix * a.nc;
     float best = c[0];
     int arg = 0;
-    for (int k = 1; k < a.nc; ++k) {
-        const float v = c[k];
-        if (v > best) { best = v; arg = k; }   // first maximum wins, as np.argmax
+    if ((a.nc & 3) == 0) {
+        const float4* c4 = reinterpret_cast<const float4*>(c);
+        for (int k = 0; k < a.nc / 4; ++k) {
+            const float4 x = c4[k];
+            if (x.x > best) { best = x.x; arg = 4 * k; }       // first maximum wins, as np.argmax
+            if (x.y > best) { best = x.y; arg = 4 * k + 1; }
+            if (x.z > best) { best = x.z; arg = 4 * k + 2; }
+            if (x.w > best) { best = x.w; arg = 4 * k + 3; }
+        }
+    } else {
+        for (int k = 1; k < a.nc; ++k) {
+            const float v = c[k];
+            if (v > best) { best = v; arg = k; }
+        }
     }
     a.max_logit[idx] = best;
     a.labels[idx] = arg;

@@ -136,16 +136,20 @@ __global__ void letterbox_kernel(const uint8_t* __restrict__ frames, int n, Lett
     }
 }
 
+// One block = 16 output rows of one crop. The tap tables (fp64 coordinate math of the cv2 spec) are
+// computed once per block into LDS -- 64 + 16 entries instead of once per output pixel.
 template <typename T>
-__global__ void crop_resize_kernel(const uint8_t* __restrict__ frames, int fh, int fw, const float* __restrict__ boxes,
-                                   const int* __restrict__ frame_of, int n, const int* __restrict__ n_dev, int oh, int ow,
-                                   int mode, void* out, int* __restrict__ valid) {
+__global__ __launch_bounds__(256) void crop_resize_kernel(const uint8_t* __restrict__ frames, int fh, int fw, const float* __restrict__ boxes,
+                                                          const int* __restrict__ frame_of, int n, const int* __restrict__ n_dev, int oh, int ow,
+                                                          int mode, void* out, int* __restrict__ valid) {
+    constexpr int ROWS = 16, MAXW = 256;
+    __shared__ Taps xt[MAXW];
+    __shared__ Taps yt[ROWS];
     const int crop = blockIdx.y;
+    const int row0 = blockIdx.x * ROWS;
     const int live = n_dev ? min(*n_dev, n) : n;
-    const int per = oh * ow;
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= per) return;
-    // deepsort_tracker.py:148-153: int() truncation towards zero, then clamp
+    const int t = threadIdx.x;
+    // deepsort_tracker.py:148-153: int() truncation towards zero, then clamp (block-uniform)
     int x1 = 0, y1 = 0, x2 = 0, y2 = 0;
     if (crop < live) {
         const float* b = boxes + (size_t)crop * 4;
@@ -155,27 +159,53 @@ __global__ void crop_resize_kernel(const uint8_t* __restrict__ frames, int fh, i
         x1 = max(0, x1); y1 = max(0, y1); x2 = min(fw, x2); y2 = min(fh, y2);
     }
     const bool ok = crop < live && x1 < x2 && y1 < y2;
-    if (p == 0 && valid) valid[crop] = ok ? 1 : 0;
-    const int oy = p / ow, ox = p - oy * ow;
-    float v[3] = {0.f, 0.f, 0.f};
-    if (ok) {
-        const int fi = frame_of ? frame_of[crop] : 0;
-        const uint8_t* f = frames + (size_t)fi * fh * fw * 3;
-        const int sw = x2 - x1, sh = y2 - y1;
-        const double sx = 1.0 / ((double)ow / (double)sw);
-        const double sy = 1.0 / ((double)oh / (double)sh);
-        int px[3];
-        sample_px(f, fw * 3, x1, y1, sw, sh, ox, oy, ow, oh, is_area2(sw, sh, ow, oh), sx, sy, px);
-        // image_processing.py:126-131: BGR->RGB, (x/255 - mean)/std in fp32
-        const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
-#pragma unroll
-        for (int c = 0; c < 3; ++c) v[c] = ((float)px[2 - c] / 255.0f - mean[c]) / stdv[c];
+    if (t == 0 && blockIdx.x == 0 && valid) valid[crop] = ok ? 1 : 0;
+    const int sw = x2 - x1, sh = y2 - y1;
+    const bool area2 = ok && is_area2(sw, sh, ow, oh);
+    if (ok && !area2) {
+        if (t < ow) xt[t] = taps_x(t, 1.0 / ((double)ow / (double)sw), sw);
+        else if (t >= MAXW - ROWS && row0 + (t - (MAXW - ROWS)) < oh)
+            yt[t - (MAXW - ROWS)] = taps_y(row0 + t - (MAXW - ROWS), 1.0 / ((double)oh / (double)sh), sh);
     }
-    if (mode == 0) {
-        float* o = reinterpret_cast<float*>(out) + (size_t)crop * 3 * per + p;
-        o[0] = v[0]; o[per] = v[1]; o[2 * per] = v[2];
-    } else {
-        store_nhwc8<T>(reinterpret_cast<T*>(out) + ((size_t)crop * per + p) * 8, v[0], v[1], v[2]);
+    __syncthreads();
+    const int per = oh * ow;
+    const int fi = (ok && frame_of) ? frame_of[crop] : 0;
+    const uint8_t* f = frames + (size_t)fi * fh * fw * 3;
+    const int pitch = fw * 3;
+    const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+    for (int idx = t; idx < ROWS * ow; idx += 256) {
+        const int ry = idx / ow, ox = idx - ry * ow, oy = row0 + ry;
+        if (oy >= oh) break;
+        float v[3] = {0.f, 0.f, 0.f};
+        if (ok) {
+            int px[3];
+            if (area2) {
+                const uint8_t* p0 = f + (size_t)(y1 + 2 * oy) * pitch + (size_t)(x1 + 2 * ox) * 3;
+                const uint8_t* p1 = p0 + pitch;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) px[c] = ((int)p0[c] + (int)p0[3 + c] + (int)p1[c] + (int)p1[3 + c] + 2) >> 2;
+            } else {
+                const Taps tx = xt[ox], ty = yt[ry];
+                const uint8_t* r0 = f + (size_t)(y1 + ty.i0) * pitch + (size_t)x1 * 3;
+                const uint8_t* r1 = f + (size_t)(y1 + ty.i1) * pitch + (size_t)x1 * 3;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const int h0 = (int)r0[tx.i0 * 3 + c] * tx.w0 + (int)r0[tx.i1 * 3 + c] * tx.w1;
+                    const int h1 = (int)r1[tx.i0 * 3 + c] * tx.w0 + (int)r1[tx.i1 * 3 + c] * tx.w1;
+                    px[c] = (((ty.w0 * (h0 >> 4)) >> 16) + ((ty.w1 * (h1 >> 4)) >> 16) + 2) >> 2;
+                }
+            }
+            // image_processing.py:126-131: BGR->RGB, (x/255 - mean)/std in fp32
+#pragma unroll
+            for (int c = 0; c < 3; ++c) v[c] = ((float)px[2 - c] / 255.0f - mean[c]) / stdv[c];
+        }
+        const int p = oy * ow + ox;
+        if (mode == 0) {
+            float* o = reinterpret_cast<float*>(out) + (size_t)crop * 3 * per + p;
+            o[0] = v[0]; o[per] = v[1]; o[2 * per] = v[2];
+        } else {
+            store_nhwc8<T>(reinterpret_cast<T*>(out) + ((size_t)crop * per + p) * 8, v[0], v[1], v[2]);
+        }
     }
 }
 
@@ -190,7 +220,8 @@ void launch_letterbox(const uint8_t* frames, int n, const LetterboxGeom& g, int 
 void launch_crop_resize(const uint8_t* frames, int h, int w, const float* boxes, const int* frame_of, int n,
                         const int* n_dev, int out_h, int out_w, int mode, int dtype, void* out, int* valid, hipStream_t s) {
     if (n <= 0) return;
-    dim3 grid(ceil_div((long)out_h * out_w, 256), n);
+    AIC_REQUIRE(out_w <= 240, AIC_ERR_CAPACITY, "crop width above 240 is not supported");
+    dim3 grid(ceil_div(out_h, 16), n);
     if (dtype == AIC_F16)
         hipLaunchKernelGGL(crop_resize_kernel<half_t>, grid, dim3(256), 0, s, frames, h, w, boxes, frame_of, n, n_dev, out_h, out_w, mode, out, valid);
     else

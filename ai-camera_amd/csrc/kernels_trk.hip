@@ -419,6 +419,7 @@ __global__ __launch_bounds__(256) void cosine_min_mfma_kernel(const float* __res
         const float* pb = det_n + (size_t)db * dim;
         const bool oka = da < n, okb = db < n;
         floatx4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8   // 8 K-slices of loads in flight: the loop is latency-bound otherwise
         for (int k0 = 0; k0 < dim; k0 += 16) {
             const int k = k0 + 4 * q;
             floatx4 a = {0.f, 0.f, 0.f, 0.f}, b0 = a, b1 = a;
