@@ -204,9 +204,16 @@ def main():
         if prof and prof["conv_igemm"]["ms"] > 0:
             c = prof["conv_igemm"]
             ach = c["flops"] / (c["ms"] * 1e-3) / 1e12
-            roof = {"kernel": "conv_igemm_kernel (MFMA implicit GEMM, all conv layers of YOLOv8 + ReID)",
+            traffic, tsrc = None, None
+            try:   # PMC counters need rocprofv3 (separate passes); the committed measurement is reported with its provenance
+                pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+                traffic, tsrc = pm["hbm_bytes_per_launch"], pm["method"]
+            except Exception:
+                pass
+            roof = {"kernel": "conv_igemm_dma_kernel (MFMA implicit GEMM: every conv of YOLOv8 + ReID except the fused 3-channel ReID stem)",
                     "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                    "traffic": None, "launches": c["launches"], "avg_launch_us": round(1e3 * c["ms"] / max(c["launches"], 1), 2),
+                    "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": tsrc,
+                    "algorithmic_bytes_per_launch": round(c["bytes"] / max(c["launches"], 1)), "launches": c["launches"], "avg_launch_us": round(1e3 * c["ms"] / max(c["launches"], 1), 2),
                     "kernel_ms_per_step": round(c["ms"] / args.steps, 3),
                     "algorithmic_gflop_per_frame": round(flops_frame / 1e9, 3)}
         cpu = None
