@@ -386,17 +386,19 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 }
 
 template <typename T, int MT, int NT, int WM, int WN, int NSTAGE>
-__global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const ConvArgs a) {
     constexpr int CH = 16 / (int)sizeof(T);
     constexpr int BKE = 4 * CH;
+    constexpr int NTHR = 64 * WM * WN;         // 4 or 8 waves
+    constexpr int RP = NTHR / 4;               // tile rows staged per pass (one 16-byte chunk per thread)
     constexpr int BM = WM * MT * 16;
     constexpr int BN = WN * NT * 16;
-    constexpr int BNP = (BN + 63) / 64 * 64;   // weight rows padded so every wave issues the same loads
-    constexpr int A_PER = BM / 64;
-    constexpr int B_PER = BNP / 64;
+    constexpr int BNP = (BN + RP - 1) / RP * RP;   // weight rows padded so every wave issues the same loads
+    constexpr int A_PER = BM / RP;
+    constexpr int B_PER = BNP / RP;
     constexpr int LPS = A_PER + B_PER;         // LDS-DMA instructions per stage per wave
     constexpr int STAGE = (BM + BNP) * 64;
-    static_assert(WM * WN == 4 && BM % 64 == 0 && NSTAGE >= 2, "geometry");
+    static_assert((WM * WN == 4 || WM * WN == 8) && BM % RP == 0 && NSTAGE >= 2, "geometry");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -418,7 +420,7 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvArgs a) {
     const float inv_howo = 1.0f / (float)HoWo, inv_wo = 1.0f / (float)a.Wo;
 #pragma unroll
     for (int i = 0; i < A_PER; ++i) {
-        const int m = m0 + r0 + 64 * i;
+        const int m = m0 + r0 + RP * i;
         unsigned mk = 0;
         const T* rp = zero;
         if (m < a.M) {
@@ -442,7 +444,7 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvArgs a) {
     const T* wp[B_PER];
 #pragma unroll
     for (int j = 0; j < B_PER; ++j) {
-        const int row = r0 + 64 * j;
+        const int row = r0 + RP * j;
         wp[j] = row < BN ? wg + (size_t)(n0 + row) * a.Kp + kc * CH : nullptr;
     }
 
@@ -465,13 +467,13 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvArgs a) {
             const bool ok = in_k && ((vmask[i] >> (tap & 31)) & 1u);
             const T* src = ok ? rowp[i] + toff : zero;
             asm volatile("" : "+v"(src));   // one select, ONE LDS-DMA instruction per wave: keeps vmcnt counting uniform
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sbase + i * 4096), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sbase + i * (RP * 64)), 16, 0, 0);
         }
 #pragma unroll
         for (int j = 0; j < B_PER; ++j) {
             const T* src = (wp[j] != nullptr && issued < nsteps) ? wp[j] + (size_t)issued * BKE : zero;
             asm volatile("" : "+v"(src));
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sbase + BM * 64 + j * 4096), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sbase + BM * 64 + j * (RP * 64)), 16, 0, 0);
         }
         ++issued;
         c_in += BKE;
@@ -531,7 +533,8 @@ static int conv_impl() {   // AICAM_CONV=v1 selects the register-staged kernel (
 
 template <typename T, int MT, int NT, int WM, int WN, int NSTAGE>
 static void launch_dma(const ConvArgs& a, hipStream_t s) {
-    constexpr int BM = WM * MT * 16, BN = WN * NT * 16, BNP = (BN + 63) / 64 * 64;
+    constexpr int RP = 16 * WM * WN;
+    constexpr int BM = WM * MT * 16, BN = WN * NT * 16, BNP = (BN + RP - 1) / RP * RP;
     dim3 grid(ceil_div(a.M, BM), ceil_div(a.Cout, BN));
     const size_t lds = (size_t)NSTAGE * (BM + BNP) * 64;
     auto kfn = conv_igemm_dma_kernel<T, MT, NT, WM, WN, NSTAGE>;
@@ -540,7 +543,7 @@ static void launch_dma(const ConvArgs& a, hipStream_t s) {
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr = true;
     }
-    hipLaunchKernelGGL(kfn, grid, dim3(256), lds, s, a);
+    hipLaunchKernelGGL(kfn, grid, dim3(64 * WM * WN), lds, s, a);
     KCHECK();
 }
 
@@ -562,7 +565,8 @@ static void launch_conv_t(const ConvArgs& a, hipStream_t s) {
     const int c = a.Cout;
     const long blocks128 = (long)ceil_div(a.M, 128);
     if (c % 128 == 0 || c > 160) {
-        if (blocks128 * ceil_div(c, 128) >= 128) launch_variant<T, 4, 4, 2, 2>(a, s);   // 128 px x 128 ch
+        if (conv_impl() == 2 && (blocks128 / 2) * ceil_div(c, 128) >= 384) launch_dma<T, 4, 4, 4, 2, 3>(a, s);   // 8 waves: 256 px x 128 ch
+        else if (blocks128 * ceil_div(c, 128) >= 128) launch_variant<T, 4, 4, 2, 2>(a, s);   // 128 px x 128 ch
         else launch_variant<T, 2, 2, 2, 2>(a, s);                                       // 64 px x 64 ch (small maps)
     } else if (c % 80 == 0) {
         launch_variant<T, 2, 5, 4, 1>(a, s);                                            // 128 px x 80 ch

@@ -409,33 +409,40 @@ __global__ __launch_bounds__(256) void cosine_min_mfma_kernel(const float* __res
     const int g0 = (blockIdx.y * 4 + wv) * 16;
     const int len = glen[t];
     if (g0 >= len) return;
-    const float* grow = gal_n + ((size_t)slots[t] * gmax + g0 + r) * dim;
-    const bool grow_ok = g0 + r < len;
-    const bool vec_ok = (dim & 15) == 0;
+    // rows / detections past the end are CLAMPED to a valid row instead of zero-filled: their products
+    // are never read (the min below and the atomics are guarded), and the loads stay branch-free
+    const float* grow = gal_n + ((size_t)slots[t] * gmax + min(g0 + r, len - 1)) * dim;
     unsigned int* out = reinterpret_cast<unsigned int*>(cost) + (size_t)t * n;
     for (int d0 = 0; d0 < n; d0 += 32) {
         const int da = d0 + r, db = d0 + 16 + r;
-        const float* pa = det_n + (size_t)da * dim;
-        const float* pb = det_n + (size_t)db * dim;
+        const float* pa = det_n + (size_t)min(da, n - 1) * dim;
+        const float* pb = det_n + (size_t)min(db, n - 1) * dim;
         const bool oka = da < n, okb = db < n;
         floatx4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8   // 8 K-slices of loads in flight: the loop is latency-bound otherwise
-        for (int k0 = 0; k0 < dim; k0 += 16) {
-            const int k = k0 + 4 * q;
-            floatx4 a = {0.f, 0.f, 0.f, 0.f}, b0 = a, b1 = a;
-            if (vec_ok) {
-                if (grow_ok) a = *reinterpret_cast<const floatx4*>(grow + k);
-                if (oka) b0 = *reinterpret_cast<const floatx4*>(pa + k);
-                if (okb) b1 = *reinterpret_cast<const floatx4*>(pb + k);
-            } else {
+        int k0 = 0;
+        for (; k0 + 64 <= dim; k0 += 64) {          // 12 independent 16-byte loads in flight per lane
+            floatx4 a[4], b0[4], b1[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = k0 + 16 * u + 4 * q;
+                a[u] = *reinterpret_cast<const floatx4*>(grow + k);
+                b0[u] = *reinterpret_cast<const floatx4*>(pa + k);
+                b1[u] = *reinterpret_cast<const floatx4*>(pb + k);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    if (k + e < dim) {
-                        if (grow_ok) a[e] = grow[k + e];
-                        if (oka) b0[e] = pa[k + e];
-                        if (okb) b1[e] = pb[k + e];
-                    }
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][e], b0[u][e], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][e], b1[u][e], acc1, 0, 0, 0);
                 }
+        }
+        for (; k0 < dim; k0 += 16) {                 // tail: any dimension, element-guarded
+            const int k = k0 + 4 * q;
+            floatx4 a = {0.f, 0.f, 0.f, 0.f}, b0 = a, b1 = a;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (k + e < dim) { a[e] = grow[k + e]; b0[e] = pa[k + e]; b1[e] = pb[k + e]; }
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
