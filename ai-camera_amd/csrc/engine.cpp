@@ -9,6 +9,7 @@
 // the MFMA K-step and zero rows up to cout_pad, so the conv kernel needs no bounds checks on them.
 #include "engine.hpp"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <fstream>
@@ -172,6 +173,21 @@ Model::Model(Device& d, const void* blob, size_t nbytes, int dtype_, int max_ite
             if (conv_ok && pool_ok && !other_reader) { ops[i].fuse = 1; ops[i + 1].fuse = 2; }
         }
     }
+    {   // sub-batching plan: the maximal prefix of ops whose outputs are >= min_kb per item
+        const char* e_items = getenv("AICAM_SB_ITEMS");
+        const char* e_kb = getenv("AICAM_SB_MINKB");
+        sub_items = e_items ? atoi(e_items) : 0;   // off by default: measured no gain on MI355X (profiles/)
+        const size_t min_bytes = (size_t)(e_kb ? atoi(e_kb) : 200) * 1024;
+        lead_ops = 0;
+        if (sub_items > 0) {
+            while (lead_ops < ops.size()) {
+                const OpDesc& o = ops[lead_ops];
+                const BufDesc& db = bufs[o.fuse == 1 ? ops[lead_ops + 1].v[4] : o.v[4]];
+                if (o.fuse != 2 && db.per_item < min_bytes) break;
+                ++lead_ops;
+            }
+        }
+    }
     if (kind == KIND_YOLO) {
         AIC_REQUIRE(nout <= 4, AIC_ERR_FORMAT, "at most 4 detection levels");
         n_anchors = 0;
@@ -193,16 +209,30 @@ Model::Model(Device& d, const void* blob, size_t nbytes, int dtype_, int max_ite
 void Model::run(int n, hipStream_t s) {
     AIC_REQUIRE(n >= 0 && n <= max_items, AIC_ERR_CAPACITY, "batch exceeds the engine's max_items");
     if (n == 0) return;
-    for (size_t oi = 0; oi < ops.size(); ++oi) {
+    if (lead_ops > 0 && sub_items > 0 && n > sub_items + sub_items / 2) {
+        // producer -> consumer tensors of the first layers exceed the 256 MiB Infinity Cache at full batch:
+        // walk them in sub-batches so each layer reads what the previous one just wrote from cache, not HBM
+        for (int i0 = 0; i0 < n; i0 += sub_items) run_range(0, lead_ops, i0, std::min(sub_items, n - i0), s);
+        run_range(lead_ops, ops.size(), 0, n, s);
+    } else {
+        run_range(0, ops.size(), 0, n, s);
+    }
+}
+
+void Model::run_range(size_t op0, size_t op1, int i0, int n, hipStream_t s) {
+    auto at = [&](const BufDesc& b) { return static_cast<char*>(b.p) + (size_t)i0 * b.per_item; };
+    for (size_t oi = op0; oi < op1; ++oi) {
         const OpDesc& o = ops[oi];
         const int* v = o.v;
-        const BufDesc& sb = bufs[v[1]];
-        const BufDesc& db = bufs[v[4]];
+        BufDesc sb = bufs[v[1]];
+        BufDesc db = bufs[v[4]];
+        sb.p = at(sb), db.p = at(db);
         if (o.fuse == 2) continue;
         if (o.fuse == 1) {
             const ConvWeights& w = weights[v[15]];
             const int* pv = ops[oi + 1].v;
-            const BufDesc& pb = bufs[pv[4]];
+            BufDesc pb = bufs[pv[4]];
+            pb.p = at(pb);
             const double fl = 2.0 * n * sb.h * sb.w * 64.0 * 27.0;
             Prof pr(*dev, PROF_CONV_DIRECT, s, fl, (double)n * (sb.h * sb.w * 16.0 + pb.h * pb.w * 128.0));
             launch_reid_stem_pool(sb.p, w.w.p, w.bias.p, pb.p, n, sb.h, sb.w, w.Kp, pb.c, pv[5], s);
@@ -215,7 +245,7 @@ void Model::run(int n, hipStream_t s) {
             a.x_cs = sb.c, a.x_coff = v[2], a.H = sb.h, a.W = sb.w, a.Cin = w.cin_eff;
             a.y_cs = db.c, a.y_coff = v[5], a.Ho = db.h, a.Wo = db.w, a.Cout = w.cout;
             a.res = nullptr, a.r_cs = 0, a.r_coff = 0, a.res_mode = v[14], a.act = v[11];
-            if (v[14]) { a.res = bufs[v[12]].p, a.r_cs = bufs[v[12]].c, a.r_coff = v[13]; }
+            if (v[14]) { a.res = at(bufs[v[12]]), a.r_cs = bufs[v[12]].c, a.r_coff = v[13]; }
             a.KH = w.kh, a.KW = w.kw, a.stride = v[9], a.pad = v[10];
             a.Kp = w.Kp, a.M = n * db.h * db.w, a.out_f32 = db.f32, a.cout_pad = w.cout_pad, a.zero = d_zero.p;
             a.tap_rows = 0;

@@ -38,6 +38,9 @@ struct Model {
     Model(Device& d, const void* blob, size_t nbytes, int dtype_, int max_items_);
     void* input() { return bufs[0].p; }
     void run(int n_items, hipStream_t s);
+    void run_range(size_t op0, size_t op1, int i0, int n, hipStream_t s);
+    size_t lead_ops = 0;   // leading ops whose activations are large: run in sub-batches (Infinity-Cache residency)
+    int sub_items = 0;
     // YOLO post-processing on the buffers left by run()
     DetArgs det_args(int batch, float conf, float iou, int max_det, const LetterboxGeom* g);
     void decode_nms(int batch, float conf, float iou, int max_det, const LetterboxGeom* g, hipStream_t s);

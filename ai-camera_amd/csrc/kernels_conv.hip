@@ -256,7 +256,7 @@ template <int ACT> __device__ __forceinline__ float act_fast(float v) {
 // One lane owns, per (i, j) tile, 4 consecutive output channels of one pixel.
 // ACT / RES / F32OUT are compile-time so the unrolled body carries no branches.
 template <typename T, int MT, int NT, int ACT, int RES, bool F32OUT>
-__device__ __forceinline__ void epilogue_fast(const ConvArgs& a, floatx4 (&acc)[MT][NT], int m_base, int n_base, int r, int q) {
+__device__ __forceinline__ void epilogue_fast(const ConvArgs& a, floatx4 (&acc)[MT][NT], const int (&mrow)[MT], int n_base, int q) {
     const float* __restrict__ bias = a.bias;
     const T* __restrict__ rg = reinterpret_cast<const T*>(a.res);
     floatx4 b4[NT];
@@ -269,8 +269,8 @@ __device__ __forceinline__ void epilogue_fast(const ConvArgs& a, floatx4 (&acc)[
     }
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-        const int m = m_base + i * 16 + r;
-        if (m >= a.M) continue;
+        const int m = mrow[i];
+        if (m < 0) continue;
         const size_t ybase = (size_t)m * a.y_cs + a.y_coff;
         const size_t rbase = RES ? (size_t)m * a.r_cs + a.r_coff : 0;
 #pragma unroll
@@ -309,14 +309,14 @@ __device__ __forceinline__ void epilogue_fast(const ConvArgs& a, floatx4 (&acc)[
 
 // Generic (any Cout, any mode) fallback: runtime branches, scalar tail.
 template <typename T, int MT, int NT>
-__device__ __forceinline__ void epilogue_generic(const ConvArgs& a, floatx4 (&acc)[MT][NT], int m_base, int n_base, int r, int q) {
+__device__ __forceinline__ void epilogue_generic(const ConvArgs& a, floatx4 (&acc)[MT][NT], const int (&mrow)[MT], int n_base, int q) {
     // (inlined and fully unrolled on purpose: a call would force `a` and `acc` into scratch memory)
     const float* __restrict__ bias = a.bias;
     const T* __restrict__ rg = reinterpret_cast<const T*>(a.res);
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-        const int m = m_base + i * 16 + r;
-        if (m >= a.M) continue;
+        const int m = mrow[i];
+        if (m < 0) continue;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const int n = n_base + j * 16 + 4 * q;
@@ -337,16 +337,16 @@ __device__ __forceinline__ void epilogue_generic(const ConvArgs& a, floatx4 (&ac
 }
 
 template <typename T, int MT, int NT>
-__device__ __forceinline__ void epilogue_dispatch(const ConvArgs& a, floatx4 (&acc)[MT][NT], int m_base, int n_base, int r, int q) {
+__device__ __forceinline__ void epilogue_dispatch(const ConvArgs& a, floatx4 (&acc)[MT][NT], const int (&mrow)[MT], int n_base, int q) {
     const int key = (a.Cout & 3) ? -1 : (a.act | (a.res_mode << 2) | (a.out_f32 << 4));
     switch (key) {
-        case 1: epilogue_fast<T, MT, NT, 1, 0, false>(a, acc, m_base, n_base, r, q); break;            // SiLU
-        case 1 | (2 << 2): epilogue_fast<T, MT, NT, 1, 2, false>(a, acc, m_base, n_base, r, q); break;  // SiLU then +res (C2f bottleneck)
-        case 2: epilogue_fast<T, MT, NT, 2, 0, false>(a, acc, m_base, n_base, r, q); break;            // ReLU
-        case 2 | (1 << 2): epilogue_fast<T, MT, NT, 2, 1, false>(a, acc, m_base, n_base, r, q); break;  // relu(x + res) (BasicBlock)
-        case 0: epilogue_fast<T, MT, NT, 0, 0, false>(a, acc, m_base, n_base, r, q); break;            // linear (downsample, FC)
-        case 0 | (1 << 4): epilogue_fast<T, MT, NT, 0, 0, true>(a, acc, m_base, n_base, r, q); break;   // linear fp32 (detect head)
-        default: epilogue_generic<T, MT, NT>(a, acc, m_base, n_base, r, q); break;
+        case 1: epilogue_fast<T, MT, NT, 1, 0, false>(a, acc, mrow, n_base, q); break;            // SiLU
+        case 1 | (2 << 2): epilogue_fast<T, MT, NT, 1, 2, false>(a, acc, mrow, n_base, q); break;  // SiLU then +res (C2f bottleneck)
+        case 2: epilogue_fast<T, MT, NT, 2, 0, false>(a, acc, mrow, n_base, q); break;            // ReLU
+        case 2 | (1 << 2): epilogue_fast<T, MT, NT, 2, 1, false>(a, acc, mrow, n_base, q); break;  // relu(x + res) (BasicBlock)
+        case 0: epilogue_fast<T, MT, NT, 0, 0, false>(a, acc, mrow, n_base, q); break;            // linear (downsample, FC)
+        case 0 | (1 << 4): epilogue_fast<T, MT, NT, 0, 0, true>(a, acc, mrow, n_base, q); break;   // linear fp32 (detect head)
+        default: epilogue_generic<T, MT, NT>(a, acc, mrow, n_base, q); break;
     }
 }
 
@@ -523,12 +523,201 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const Conv
     }
     wait_vmcnt<0>();   // drain the zero-page loads of the tail before the LDS goes away
 
-    epilogue_dispatch<T, MT, NT>(a, acc, m0 + wm * MT * 16, n0 + wn * NT * 16, r, q);
+    int mrow[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int m = m0 + (wm * MT + i) * 16 + r;
+        mrow[i] = m < a.M ? m : -1;
+    }
+    epilogue_dispatch<T, MT, NT>(a, acc, mrow, n0 + wn * NT * 16, q);
 }
 
 static int conv_impl() {   // AICAM_CONV=v1 selects the register-staged kernel (A/B and fallback)
     static int v = [] { const char* e = getenv("AICAM_CONV"); return (e && e[0] == 'v' && e[1] == '1') ? 1 : 2; }();
     return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// v3 for 3x3 / stride 1 / pad 1: the im2col gather of v2 fetches every input chunk 9 times (once per
+// tap) through L2 -> LDS.  Here a block owns a TH x TW tile of output pixels of ONE image; the
+// (TH+2) x (TW+2) x Cin input patch (with its halo; zero page outside the image) is pulled into LDS
+// once by LDS-DMA and the nine taps are generated from LDS at shifted addresses.  Only the weights
+// stream through the NSTAGE ring.  K order = tap-major, Cin/BKE steps per tap (needs Cin % BKE == 0).
+// Patch image: pixel p, 16-byte chunk j stored at chunk slot j ^ swz(p) (source-side swizzle again);
+// swz(p) = p & (CPP-1) (CPP = chunks per pixel >= 8) or (p>>1)&3 (CPP == 4): conflict-free /
+// <= 2-way for the ds_read_b128 lane groups (16 consecutive pixels x 4 consecutive chunks).
+template <int CPP> __device__ __forceinline__ int patch_swz(int p) { return CPP == 4 ? ((p >> 1) & 3) : (p & (CPP - 1)); }
+
+// Everything the hot loop needs is a compile-time constant or a precomputed register:
+//  * LGCPP: log2 of the 16-byte chunks per pixel (Cin fixed per instantiation), CSTEPS = CPP/4 K-steps per tap;
+//  * patch rows are padded to PWP pixels, a multiple of max(8, CPP): the swizzle term of a patch pixel
+//    then depends on its column only, so the LDS address of (tile i, tap column kw, chunk cc) is one of
+//    3*CSTEPS*MT precomputed VGPRs and the tap row kh is a ds_read immediate;
+//  * taps, chunks and ring stages are fully unrolled; the weight stream is a pointer increment.
+// VALU per MFMA drops from ~12 to <1 (SQ_INSTS_VALU / SQ_INSTS_MFMA, profiles/).
+template <typename T, int MT, int NT, int WM, int WN, int TH, int TW, int NSTAGE, int LGCPP>
+__global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(const ConvArgs a, int tiles_x, int tiles_y) {
+    constexpr int CH = 16 / (int)sizeof(T);
+    constexpr int BKE = 4 * CH;
+    constexpr int NTHR = 64 * WM * WN;
+    constexpr int RP = NTHR / 4;
+    constexpr int BM = WM * MT * 16;
+    constexpr int BN = WN * NT * 16;
+    constexpr int BNP = (BN + RP - 1) / RP * RP;
+    constexpr int B_PER = BNP / RP;
+    constexpr int WSTAGE = BNP * 64;
+    constexpr int CPP = 1 << LGCPP, CSTEPS = CPP / 4, NSTEPS = 9 * CSTEPS;
+    constexpr int PAL = CPP >= 8 ? CPP : 8;
+    constexpr int PH = TH + 2, PWP = (TW + 2 + PAL - 1) / PAL * PAL;
+    constexpr int TOTAL = PH * PWP * CPP;
+    constexpr int PATCH_BYTES = (TOTAL + NTHR - 1) / NTHR * NTHR * 16;
+    constexpr int ROWB = PWP * CPP * 16;                    // bytes per patch row
+    static_assert(BM == TH * TW && TW % 16 == 0 && (TW & (TW - 1)) == 0 && B_PER == 1, "tile geometry");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* ring = smem + PATCH_BYTES;
+
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    int bx = blockIdx.x;
+    const int tx = bx % tiles_x; bx /= tiles_x;
+    const int ty = bx % tiles_y;
+    const int img = bx / tiles_y;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int n0 = blockIdx.y * BN;
+
+    const T* __restrict__ wg = reinterpret_cast<const T*>(a.w);
+    const T* zero = reinterpret_cast<const T*>(a.zero);
+    const T* ximg = reinterpret_cast<const T*>(a.x) + (size_t)img * a.H * a.W * a.x_cs + a.x_coff;
+
+    // ---- the input patch, once (pad columns and out-of-image pixels come from the zero page)
+#pragma unroll 2
+    for (int base = 0; base < TOTAL; base += NTHR) {
+        const int L = base + t;
+        const int p = L >> LGCPP, sl = L & (CPP - 1);
+        const int j = sl ^ patch_swz<CPP>(p);
+        const int py = p / PWP, px = p - py * PWP;
+        const int iy = oy0 + py - 1, ix = ox0 + px - 1;
+        const bool ok = L < TOTAL && px < TW + 2 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        const T* src = ok ? ximg + ((size_t)iy * a.W + ix) * a.x_cs + j * CH : zero;
+        asm volatile("" : "+v"(src));
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + (size_t)(base + 64 * wv) * 16), 16, 0, 0);
+    }
+
+    // ---- weight stream: one 16-byte chunk per thread per K-step; rows past Cout read the zero page with stride 0
+    const int slot = t & 3, r0 = t >> 2;
+    const int kc = slot ^ ((r0 >> 1) & 3);
+    const bool wrow_ok = r0 < BN;
+    const T* wptr = wrow_ok ? wg + (size_t)(n0 + r0) * a.Kp + kc * CH : zero;
+    const int winc = wrow_ok ? BKE : 0;
+    char* wdst = ring + (16 * wv) * 64;
+#pragma unroll
+    for (int st = 0; st < NSTAGE - 1; ++st) {
+        __builtin_amdgcn_global_load_lds((gptr_t)wptr, (lptr_t)(wdst + st * WSTAGE), 16, 0, 0);
+        wptr += winc;
+    }
+
+    const int wm = wv / WN, wn = wv % WN;
+    const int q = lane >> 4, r = lane & 15;
+    // LDS byte address of this lane's 16-byte operand chunk for (tap column kw, K-chunk cc, pixel tile i), tap row 0
+    int xaddr[3][CSTEPS][MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int pt = (wm * MT + i) * 16 + r;
+        const int ly = pt / TW, lx = pt % TW;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int p0 = ly * PWP + lx + kw;
+            const int sw = patch_swz<CPP>(p0);
+#pragma unroll
+            for (int cc = 0; cc < CSTEPS; ++cc) xaddr[kw][cc][i] = (p0 * CPP + ((cc * 4 + q) ^ sw)) * 16;
+        }
+    }
+    int woff[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) woff[j] = PATCH_BYTES + lds_off((wn * NT + j) * 16 + r, q);
+
+    floatx4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    typedef typename Frag<T>::type frag_t;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+#pragma unroll
+            for (int cc = 0; cc < CSTEPS; ++cc) {
+                constexpr int dummy = 0; (void)dummy;
+                const int step = (kh * 3 + kw) * CSTEPS + cc;       // compile-time after unrolling
+                const int cur = step % NSTAGE, nxt = (step + NSTAGE - 1) % NSTAGE;
+                wait_vmcnt<(NSTAGE - 2) * B_PER>();
+                __builtin_amdgcn_s_barrier();
+                {   // refill the stage that step-1 released (zero page once the real K-steps are exhausted)
+                    const T* src = (step + NSTAGE - 1 < NSTEPS) ? wptr : zero;
+                    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(wdst + nxt * WSTAGE), 16, 0, 0);
+                    wptr += winc;
+                }
+                frag_t xf[MT], wf[NT];
+#pragma unroll
+                for (int i = 0; i < MT; ++i) xf[i] = *reinterpret_cast<const frag_t*>(smem + xaddr[kw][cc][i] + kh * ROWB);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) wf[j] = *reinterpret_cast<const frag_t*>(smem + woff[j] + cur * WSTAGE);
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc[i][j] = Frag<T>::mma(wf[j], xf[i], acc[i][j]);
+            }
+        }
+    }
+    wait_vmcnt<0>();
+
+    int mrow[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int pt = (wm * MT + i) * 16 + r;
+        const int oy = oy0 + pt / TW, ox = ox0 + pt % TW;
+        mrow[i] = (oy < a.Ho && ox < a.Wo) ? (img * a.Ho + oy) * a.Wo + ox : -1;
+    }
+    epilogue_dispatch<T, MT, NT>(a, acc, mrow, n0 + wn * NT * 16, q);
+}
+
+template <typename T, int MT, int NT, int WM, int WN, int TH, int TW, int NSTAGE, int LGCPP>
+static bool launch_patch(const ConvArgs& a, hipStream_t s) {
+    constexpr int CH = 16 / (int)sizeof(T), NTHR = 64 * WM * WN, RP = NTHR / 4;
+    constexpr int BN = WN * NT * 16, BNP = (BN + RP - 1) / RP * RP;
+    constexpr int CPP = 1 << LGCPP, PAL = CPP >= 8 ? CPP : 8, PWP = (TW + 2 + PAL - 1) / PAL * PAL;
+    constexpr int TOTAL = (TH + 2) * PWP * CPP;
+    constexpr size_t lds = (size_t)(TOTAL + NTHR - 1) / NTHR * NTHR * 16 + (size_t)NSTAGE * BNP * 64;
+    static_assert(lds <= 160 * 1024, "patch does not fit the LDS");
+    if (a.Cin != CPP * CH) return false;
+    const int tiles_x = ceil_div(a.Wo, TW), tiles_y = ceil_div(a.Ho, TH);
+    const int n_img = a.M / (a.Ho * a.Wo);
+    auto kfn = conv3x3_patch_kernel<T, MT, NT, WM, WN, TH, TW, NSTAGE, LGCPP>;
+    static bool attr = false;
+    if (lds > 64 * 1024 && !attr) {
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = true;
+    }
+    dim3 grid(n_img * tiles_x * tiles_y, ceil_div(a.Cout, BN));
+    hipLaunchKernelGGL(kfn, grid, dim3(NTHR), lds, s, a, tiles_x, tiles_y);
+    KCHECK();
+    return true;
+}
+
+// 3x3/s1/p1 with Cin a multiple of the K-step: tile shape by output width.
+template <typename T>
+static bool try_patch(const ConvArgs& a, hipStream_t s) {
+    // Measured on MI355X (profiles/): the patch form wins where Cout is small and M is large (ReID layer1);
+    // for Cout >= 128 the 8-wave im2col tile is faster, and small maps are launch-bound either way.
+    static const bool off = getenv("AICAM_NO_PATCH") != nullptr;
+    static const bool all = getenv("AICAM_PATCH_ALL") != nullptr;
+    if (off || a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.Wo < 16 || a.Ho < 8 || a.Cout != 64) return false;
+    if (a.M < 400000 && !all) return false;
+    constexpr int LG64 = sizeof(T) == 2 ? 3 : 4;    // Cin = 64: 8 chunks (fp16) / 16 chunks (fp32) per pixel
+    if (a.Wo >= 32) return launch_patch<T, 4, 4, 4, 1, 8, 32, 3, LG64>(a, s);
+    return launch_patch<T, 4, 4, 4, 1, 16, 16, 3, LG64>(a, s);
 }
 
 template <typename T, int MT, int NT, int WM, int WN, int NSTAGE>
@@ -563,6 +752,7 @@ static void launch_variant(const ConvArgs& a, hipStream_t s) {
 template <typename T>
 static void launch_conv_t(const ConvArgs& a, hipStream_t s) {
     const int c = a.Cout;
+    if (conv_impl() == 2 && try_patch<T>(a, s)) return;
     const long blocks128 = (long)ceil_div(a.M, 128);
     if (c % 128 == 0 || c > 160) {
         if (conv_impl() == 2 && (blocks128 / 2) * ceil_div(c, 128) >= 384) launch_dma<T, 4, 4, 4, 2, 3>(a, s);   // 8 waves: 256 px x 128 ch
