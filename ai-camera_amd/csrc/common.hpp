@@ -115,6 +115,7 @@ struct Device {
     void use() const { HIP_CHECK(hipSetDevice(id)); }
     void prof_begin(int cls, hipStream_t s, double fl, double by);
     void prof_end(int cls, hipStream_t s);
+    void prof_account(int cls, double fl, double by);   // one more launch inside the open bracket
     void prof_collect();
     void prof_reset();
 };

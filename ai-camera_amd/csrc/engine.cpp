@@ -221,6 +221,12 @@ void Model::run(int n, hipStream_t s) {
 
 void Model::run_range(size_t op0, size_t op1, int i0, int n, hipStream_t s) {
     auto at = [&](const BufDesc& b) { return static_cast<char*>(b.p) + (size_t)i0 * b.per_item; };
+    // HIP-event timing of the conv kernel brackets RUNS of consecutive conv launches (one event pair per
+    // run, not per launch: two event records per launch cost 13 % of end-to-end throughput); the summed
+    // time therefore includes the ~1-2 us dependent-launch gaps inside a run (a conservative `achieved`).
+    const bool prof_conv = (dev->prof_mask >> PROF_CONV) & 1u;
+    bool span_open = false;
+    auto span_close = [&] { if (span_open) { dev->prof_end(PROF_CONV, s); span_open = false; } };
     for (size_t oi = op0; oi < op1; ++oi) {
         const OpDesc& o = ops[oi];
         const int* v = o.v;
@@ -228,6 +234,7 @@ void Model::run_range(size_t op0, size_t op1, int i0, int n, hipStream_t s) {
         BufDesc db = bufs[v[4]];
         sb.p = at(sb), db.p = at(db);
         if (o.fuse == 2) continue;
+        if (o.fuse == 1 || v[0] != OP_CONV) span_close();
         if (o.fuse == 1) {
             const ConvWeights& w = weights[v[15]];
             const int* pv = ops[oi + 1].v;
@@ -254,7 +261,10 @@ void Model::run_range(size_t op0, size_t op1, int i0, int n, hipStream_t s) {
             const double fl = 2.0 * a.M * (double)w.cout * w.cin * w.kh * w.kw;
             const double by = ((double)n * sb.h * sb.w * w.cin + (double)a.M * w.cout) * (dtype == AIC_F16 ? 2 : 4) +
                               (double)w.cout * w.cin * w.kh * w.kw * (dtype == AIC_F16 ? 2 : 4);
-            Prof pr(*dev, PROF_CONV, s, fl, by);
+            if (prof_conv) {
+                if (!span_open) { dev->prof_begin(PROF_CONV, s, 0, 0); span_open = true; }
+                dev->prof_account(PROF_CONV, fl, by);
+            }
             launch_conv_igemm(dtype, a, s);
         } else {
             EltArgs a{};
@@ -271,6 +281,7 @@ void Model::run_range(size_t op0, size_t op1, int i0, int n, hipStream_t s) {
             }
         }
     }
+    span_close();
 }
 
 DetArgs Model::det_args(int batch, float conf, float iou, int max_det, const LetterboxGeom* g) {

@@ -52,6 +52,15 @@ void Device::prof_begin(int cls, hipStream_t s, double fl, double by) {
     }
     (void)hipEventRecord(p.a, s);
     pending[cls].push_back(p);
+    if (fl != 0 || by != 0 || cls != PROF_CONV) {   // conv launches are accounted one by one (prof_account)
+        launches[cls] += 1;
+        flops[cls] += fl;
+        bytes[cls] += by;
+    }
+}
+
+void Device::prof_account(int cls, double fl, double by) {
+    std::lock_guard<std::mutex> lk(prof_mu);
     launches[cls] += 1;
     flops[cls] += fl;
     bytes[cls] += by;
