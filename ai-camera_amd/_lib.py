@@ -89,6 +89,7 @@ _SIGS = {
     "aic_pipeline_inject": (_I, [_P, _I, _I, _P, _P, _P, _P]),
     "aic_pipeline_run": (_I, [_P, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "aic_pipeline_tracker": (_I, [_P, _P]),
+    "aic_pipeline_stats": (_I, [_P, _P, _P, _P, _P, _I]),
     "aic_pipeline_last_embeddings": (_I, [_P, _P, _I, _P, _P]),
     "aic_prof_enable": (_I, [_I, _I]),
     "aic_prof_reset": (_I, [_I]),

@@ -115,7 +115,8 @@ Model::Model(Device& d, const void* blob, size_t nbytes, int dtype_, int max_ite
         w.Kp = round_up(w.K, bke);
         w.cout_pad = round_up(w.cout, 128) + 128;
         const float* src = payload + woff;
-        std::vector<char> packed((size_t)w.cout_pad * w.Kp * esz, 0);
+        // + 8 K-steps of zero slack: the conv kernel's drain iterations step the weight pointer past the last row
+        std::vector<char> packed(((size_t)w.cout_pad * w.Kp + 8 * bke) * esz, 0);
         for (int co = 0; co < w.cout; ++co)
             for (int ci = 0; ci < w.cin; ++ci)
                 for (int ky = 0; ky < w.kh; ++ky)

@@ -441,48 +441,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const Conv
         rowp[i] = rp;
         vmask[i] = mk;
     }
-    const T* wp[B_PER];
-#pragma unroll
-    for (int j = 0; j < B_PER; ++j) {
-        const int row = r0 + RP * j;
-        wp[j] = row < BN ? wg + (size_t)(n0 + row) * a.Kp + kc * CH : nullptr;
-    }
-
-    // K position of this thread's chunk: tap index + channel offset, and the matching element offset
-    int c_in = kc * CH, kw_ = 0, kh_ = 0;
-    while (c_in >= a.Cin) {
-        c_in -= a.Cin;
-        if (++kw_ == a.KW) { kw_ = 0; ++kh_; }
-    }
     const int nsteps = a.Kp / BKE;
-    int issued = 0;   // K-steps issued so far
-
-    auto issue = [&](int stage) {
-        const int tap = kh_ * a.KW + kw_;
-        const bool in_k = tap < ntap;
-        const long toff = ((long)kh_ * a.W + kw_) * a.x_cs + c_in;
-        char* sbase = smem + stage * STAGE + (16 * wv) * 64;
-#pragma unroll
-        for (int i = 0; i < A_PER; ++i) {
-            const bool ok = in_k && ((vmask[i] >> (tap & 31)) & 1u);
-            const T* src = ok ? rowp[i] + toff : zero;
-            asm volatile("" : "+v"(src));   // one select, ONE LDS-DMA instruction per wave: keeps vmcnt counting uniform
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sbase + i * (RP * 64)), 16, 0, 0);
-        }
-#pragma unroll
-        for (int j = 0; j < B_PER; ++j) {
-            const T* src = (wp[j] != nullptr && issued < nsteps) ? wp[j] + (size_t)issued * BKE : zero;
-            asm volatile("" : "+v"(src));
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sbase + BM * 64 + j * (RP * 64)), 16, 0, 0);
-        }
-        ++issued;
-        c_in += BKE;
-        while (c_in >= a.Cin) {
-            c_in -= a.Cin;
-            if (++kw_ == a.KW) { kw_ = 0; ++kh_; }
-        }
-    };
-
     const int wm = wv / WN, wn = wv % WN;
     const int q = lane >> 4, r = lane & 15;
 
@@ -492,34 +451,135 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const Conv
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
 
+    // LDS offsets of this lane's operand chunks inside a stage (stage base added as an immediate below)
+    int xoff[MT], woff[NT];
 #pragma unroll
-    for (int s = 0; s < NSTAGE - 1; ++s) issue(s);
-
+    for (int i = 0; i < MT; ++i) xoff[i] = lds_off((wm * MT + i) * 16 + r, q);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) woff[j] = BM * 64 + lds_off((wn * NT + j) * 16 + r, q);
     typedef typename Frag<T>::type frag_t;
-    int cur = 0;
-    for (int step = 0; step < nsteps; ++step) {
-        wait_vmcnt<(NSTAGE - 2) * LPS>();      // this wave's loads of `step` have landed
-        __builtin_amdgcn_s_barrier();          // ... everyone's have, and everyone finished step-1
-        int nxt = cur + NSTAGE - 1;
-        if (nxt >= NSTAGE) nxt -= NSTAGE;
-        issue(nxt);                            // refills the buffer that step-1 just released
-        const char* base = smem + cur * STAGE;
+    auto compute = [&](int stage) {
+        const char* base = smem + stage * STAGE;
         frag_t xf[MT], wf[NT];
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const int row = (wm * MT + i) * 16 + r;
-            xf[i] = *reinterpret_cast<const frag_t*>(base + lds_off(row, q));
-        }
+        for (int i = 0; i < MT; ++i) xf[i] = *reinterpret_cast<const frag_t*>(base + xoff[i]);
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int row = (wn * NT + j) * 16 + r;
-            wf[j] = *reinterpret_cast<const frag_t*>(base + BM * 64 + lds_off(row, q));
-        }
+        for (int j = 0; j < NT; ++j) wf[j] = *reinterpret_cast<const frag_t*>(base + woff[j]);
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int j = 0; j < NT; ++j) acc[i][j] = Frag<T>::mma(wf[j], xf[i], acc[i][j]);
-        if (++cur == NSTAGE) cur = 0;
+    };
+    char* const sdst = smem + (16 * wv) * 64;   // this wave's 16 rows inside a staging pass
+
+    if (a.Cin % BKE == 0) {
+        // ---- fast path: a K-step never straddles a tap, so the tap is uniform. Source pointers are set up
+        // once per tap (validity bit, tap offset) and then only incremented: ~2 VALU per LDS-DMA instead of ~12.
+        const int csteps = a.Cin / BKE;
+        const T* aptr[A_PER];
+        int ainc[A_PER];
+        const T* wptr[B_PER];
+        int winc[B_PER];
+#pragma unroll
+        for (int j = 0; j < B_PER; ++j) {
+            const bool okr = r0 + RP * j < BN;
+            wptr[j] = okr ? wg + (size_t)(n0 + r0 + RP * j) * a.Kp + kc * CH : zero;   // weights carry NSTAGE K-steps of slack
+            winc[j] = okr ? BKE : 0;
+        }
+        int tap = 0, kh = 0, kw = 0, cc = 0;
+        auto set_tap = [&] {
+            const long toff = ((long)kh * a.W + kw) * a.x_cs + kc * CH;
+#pragma unroll
+            for (int i = 0; i < A_PER; ++i) {
+                const bool ok = tap < ntap && ((vmask[i] >> (tap & 31)) & 1u);
+                aptr[i] = ok ? rowp[i] + toff : zero;
+                ainc[i] = ok ? BKE : 0;
+            }
+        };
+        set_tap();
+        auto issue_fast = [&](int stage) {
+            char* sbase = sdst + stage * STAGE;
+#pragma unroll
+            for (int i = 0; i < A_PER; ++i) {
+                __builtin_amdgcn_global_load_lds((gptr_t)aptr[i], (lptr_t)(sbase + i * (RP * 64)), 16, 0, 0);
+                aptr[i] += ainc[i];
+            }
+#pragma unroll
+            for (int j = 0; j < B_PER; ++j) {
+                __builtin_amdgcn_global_load_lds((gptr_t)wptr[j], (lptr_t)(sbase + BM * 64 + j * (RP * 64)), 16, 0, 0);
+                wptr[j] += winc[j];
+            }
+            if (++cc == csteps) {                      // uniform: next tap
+                cc = 0;
+                ++tap;
+                if (++kw == a.KW) { kw = 0; ++kh; }
+                set_tap();
+            }
+        };
+#pragma unroll
+        for (int st = 0; st < NSTAGE - 1; ++st) issue_fast(st);
+        for (int step0 = 0; step0 < nsteps; step0 += NSTAGE) {
+#pragma unroll
+            for (int u = 0; u < NSTAGE; ++u) {         // stage index is a compile-time constant inside the body
+                if (step0 + u < nsteps) {
+                    wait_vmcnt<(NSTAGE - 2) * LPS>();
+                    __builtin_amdgcn_s_barrier();
+                    issue_fast((u + NSTAGE - 1) % NSTAGE);
+                    compute(u);
+                }
+            }
+        }
+    } else {
+        // ---- generic path (Cin < K-step or not a multiple of it: 3-channel stems, 16/48/80-channel layers)
+        const T* wp[B_PER];
+#pragma unroll
+        for (int j = 0; j < B_PER; ++j) {
+            const int row = r0 + RP * j;
+            wp[j] = row < BN ? wg + (size_t)(n0 + row) * a.Kp + kc * CH : nullptr;
+        }
+        int c_in = kc * CH, kw_ = 0, kh_ = 0;
+        while (c_in >= a.Cin) {
+            c_in -= a.Cin;
+            if (++kw_ == a.KW) { kw_ = 0; ++kh_; }
+        }
+        int issued = 0;
+        auto issue = [&](int stage) {
+            const int tap = kh_ * a.KW + kw_;
+            const bool in_k = tap < ntap;
+            const long toff = ((long)kh_ * a.W + kw_) * a.x_cs + c_in;
+            char* sbase = sdst + stage * STAGE;
+#pragma unroll
+            for (int i = 0; i < A_PER; ++i) {
+                const bool ok = in_k && ((vmask[i] >> (tap & 31)) & 1u);
+                const T* src = ok ? rowp[i] + toff : zero;
+                asm volatile("" : "+v"(src));   // one select, ONE LDS-DMA instruction per wave: keeps vmcnt counting uniform
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sbase + i * (RP * 64)), 16, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < B_PER; ++j) {
+                const T* src = (wp[j] != nullptr && issued < nsteps) ? wp[j] + (size_t)issued * BKE : zero;
+                asm volatile("" : "+v"(src));
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sbase + BM * 64 + j * (RP * 64)), 16, 0, 0);
+            }
+            ++issued;
+            c_in += BKE;
+            while (c_in >= a.Cin) {
+                c_in -= a.Cin;
+                if (++kw_ == a.KW) { kw_ = 0; ++kh_; }
+            }
+        };
+#pragma unroll
+        for (int st = 0; st < NSTAGE - 1; ++st) issue(st);
+        int cur = 0;
+        for (int step = 0; step < nsteps; ++step) {
+            wait_vmcnt<(NSTAGE - 2) * LPS>();      // this wave's loads of `step` have landed
+            __builtin_amdgcn_s_barrier();          // ... everyone's have, and everyone finished step-1
+            int nxt = cur + NSTAGE - 1;
+            if (nxt >= NSTAGE) nxt -= NSTAGE;
+            issue(nxt);                            // refills the buffer that step-1 just released
+            compute(cur);
+            if (++cur == NSTAGE) cur = 0;
+        }
     }
     wait_vmcnt<0>();   // drain the zero-page loads of the tail before the LDS goes away
 

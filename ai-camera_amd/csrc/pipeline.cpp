@@ -16,6 +16,7 @@
 #include "tracker.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <exception>
 #include <mutex>
@@ -57,6 +58,9 @@ struct Pipeline {
     int dim;
     std::vector<float> last_emb;
     int last_emb_n = 0;
+    // host-side wall time (seconds): issuing launch groups, waiting for a group, walking frames through the tracker
+    double t_issue = 0, t_wait = 0, t_track = 0;
+    long n_frames_done = 0;
 
     Pipeline(Model* y, Model* r, const aic_pipeline_params& p)
         : dev(y->dev), yolo(y), reid(r), prm(p), trk_handle(new aic_tracker(*y->dev, p.tracker)), trk(trk_handle->t) {
@@ -114,7 +118,10 @@ struct Pipeline {
         }
     }
 
+    static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
     void stage_a(Chunk& c, int slot, int frames) {
+        const double t0 = now();
         hipStream_t s = dev->s_main;
         c.frames = frames, c.first_slot = slot;
         const uint8_t* f0 = ring.p + (size_t)slot * frame_bytes;
@@ -174,11 +181,15 @@ struct Pipeline {
         }
         HIP_CHECK(hipStreamWaitEvent(s, c.ev_det, 0));   // join: the next chunk's YOLO reuses the head buffers
         HIP_CHECK(hipEventRecord(c.done, s));
+        t_issue += now() - t0;
     }
 
     void stage_b(Chunk& c, int out_base, int32_t* n_tracks, int32_t* tracks6, float* track_conf, int32_t* n_dets,
                  float* det_boxes, float* det_scores, int32_t* det_labels) {
+        const double t0 = now();
         HIP_CHECK(hipEventSynchronize(c.done));
+        const double t1 = now();
+        t_wait += t1 - t0;
         std::vector<uint8_t> has;
         for (int f = 0; f < c.frames; ++f) {
             FrameDets& fd = c.dets[f];
@@ -210,6 +221,8 @@ struct Pipeline {
                 }
             }
         }
+        t_track += now() - t1;
+        n_frames_done += c.frames;
     }
 
     void run(int slot, int count, int32_t* n_tracks, int32_t* tracks6, float* track_conf, int32_t* n_dets, float* det_boxes,
@@ -338,6 +351,17 @@ int aic_pipeline_tracker(aic_pipeline* p, aic_tracker** out) {
     return guarded([&] {
         AIC_REQUIRE(p && out, AIC_ERR_INVALID, "NULL argument");
         *out = p->p.trk_handle.get();   // owned by the pipeline: do not destroy
+    });
+}
+
+int aic_pipeline_stats(aic_pipeline* p, double* issue_s, double* wait_s, double* track_s, int64_t* frames, int reset) {
+    return guarded([&] {
+        AIC_REQUIRE(p, AIC_ERR_INVALID, "NULL pipeline");
+        if (issue_s) *issue_s = p->p.t_issue;
+        if (wait_s) *wait_s = p->p.t_wait;
+        if (track_s) *track_s = p->p.t_track;
+        if (frames) *frames = p->p.n_frames_done;
+        if (reset) p->p.t_issue = p->p.t_wait = p->p.t_track = 0, p->p.n_frames_done = 0;
     });
 }
 

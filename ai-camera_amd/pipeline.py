@@ -100,6 +100,12 @@ class TrackingPipeline:
                None, None, None)
         return nt[:count], rows[:count], nd[:count]
 
+    def stats(self, reset=False):
+        """Host wall-clock split (seconds) since the last reset: launch-group issue, waiting for the GPU, tracker."""
+        a, b, c, n = C.c_double(), C.c_double(), C.c_double(), C.c_int64()
+        L.call("aic_pipeline_stats", self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(n), int(reset))
+        return dict(issue_s=a.value, wait_s=b.value, track_s=c.value, frames=n.value)
+
     def last_embeddings(self):
         n, d = C.c_int32(), C.c_int32()
         L.call("aic_pipeline_last_embeddings", self._h, None, 1 << 30, C.byref(n), C.byref(d))

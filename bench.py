@@ -177,6 +177,7 @@ def main():
     if not args.no_prof:
         L.call("aic_prof_reset", dev)
         L.call("aic_prof_enable", dev, 1)       # class 0 = conv_igemm only
+    pipe.stats(reset=True)
     sync_all()
     t0 = time.perf_counter()
     n_tracks_total = 0
@@ -190,6 +191,7 @@ def main():
             D.all_gather_gallery(shard, dev)
     sync_all()
     dt = time.perf_counter() - t0
+    host = pipe.stats()
     prof = L.prof_read(dev) if not args.no_prof else None
     if not args.no_prof:
         L.call("aic_prof_enable", dev, 0)
@@ -233,7 +235,10 @@ def main():
                        "confirmed_tracks_per_frame": round(n_tracks_total / (frames_per_step * args.steps), 2),
                        "timed_span": "frames resident in HBM -> track tuples on host (detect+track, reference FPS span)",
                        "h2d_upload_s_for_ring": round(h2d_s, 4),
-                       "gallery_exchange_every_steps": exchange},
+                       "gallery_exchange_every_steps": exchange,
+                       "host_us_per_frame": {"issue_launch_groups(producer thread)": round(1e6 * host["issue_s"] / max(host["frames"], 1), 1),
+                                             "wait_for_gpu": round(1e6 * host["wait_s"] / max(host["frames"], 1), 1),
+                                             "tracker_chain": round(1e6 * host["track_s"] / max(host["frames"], 1), 1)}},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)

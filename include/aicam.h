@@ -219,6 +219,9 @@ int aic_pipeline_run(aic_pipeline* p, int slot, int count, int32_t* n_tracks, in
                      float* track_conf, int32_t* n_dets, float* det_boxes, float* det_scores,
                      int32_t* det_labels);
 int aic_pipeline_tracker(aic_pipeline* p, aic_tracker** out);
+/* Host wall-clock split since the last reset (seconds): issuing launch groups (producer thread), waiting for
+ * a group's GPU work, walking its frames through the tracker (association recurrence). */
+int aic_pipeline_stats(aic_pipeline* p, double* issue_s, double* wait_s, double* track_s, int64_t* frames, int reset);
 /* Embeddings of the last processed frame (parity tests): emb[n,dim] host. */
 int aic_pipeline_last_embeddings(aic_pipeline* p, float* emb, int cap_rows, int32_t* n, int32_t* dim);
 
