@@ -100,6 +100,7 @@ struct Device {
     int id = 0;
     hipStream_t s_main = nullptr;  // detection + ReID launch groups
     hipStream_t s_trk = nullptr;   // per-frame association chain
+    hipStream_t s_reid = nullptr;  // crop + ReID launch group (runs beside YOLO's thin layers, which leave CUs idle)
     hipStream_t s_det = nullptr;   // decode + NMS + detection read-back (overlaps the ReID launch group)
     int n_cu = 256;
     unsigned prof_mask = 0;   // bit c set = class c is timed with HIP events

@@ -17,6 +17,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cstdlib>
 #include <condition_variable>
 #include <exception>
 #include <mutex>
@@ -39,7 +40,7 @@ struct Chunk {
     PinBuf<int> h_numdets, h_labels;
     PinBuf<float> h_detboxes, h_scores;
     std::vector<FrameDets> dets;
-    hipEvent_t done = nullptr, ev_yolo = nullptr, ev_det = nullptr;
+    hipEvent_t done = nullptr, ev_yolo = nullptr, ev_det = nullptr, ev_reid = nullptr;
 };
 
 struct Pipeline {
@@ -61,6 +62,11 @@ struct Pipeline {
     // host-side wall time (seconds): issuing launch groups, waiting for a group, walking frames through the tracker
     double t_issue = 0, t_wait = 0, t_track = 0;
     long n_frames_done = 0;
+    bool split_streams = getenv("AICAM_SPLIT_STREAMS") != nullptr;   // measured: no gain on MI355X
+    const uint8_t* host_frames = nullptr;   // run_from_host: frames of the current call in (pinned) host memory
+    hipStream_t s_copy = nullptr;
+    hipEvent_t ev_copy[2] = {nullptr, nullptr};
+    int host_slot0 = 0;
 
     Pipeline(Model* y, Model* r, const aic_pipeline_params& p)
         : dev(y->dev), yolo(y), reid(r), prm(p), trk_handle(new aic_tracker(*y->dev, p.tracker)), trk(trk_handle->t) {
@@ -81,6 +87,8 @@ struct Pipeline {
         inj_boxes.assign((size_t)p.ring_frames * p.max_persons * 4, 0.f);
         inj_conf.assign((size_t)p.ring_frames * p.max_persons, 0.f);
         inj_cls.assign((size_t)p.ring_frames * p.max_persons, 0);
+        HIP_CHECK(hipStreamCreateWithFlags(&s_copy, hipStreamNonBlocking));
+        for (auto& e : ev_copy) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         const size_t maxc = (size_t)p.batch * p.max_persons;
         for (Chunk& c : ck) {
             c.h_boxes.alloc(maxc * 4), c.h_frame_of.alloc(maxc), c.h_valid.alloc(maxc);
@@ -91,13 +99,17 @@ struct Pipeline {
             HIP_CHECK(hipEventCreateWithFlags(&c.done, hipEventDisableTiming));
             HIP_CHECK(hipEventCreateWithFlags(&c.ev_yolo, hipEventDisableTiming));
             HIP_CHECK(hipEventCreateWithFlags(&c.ev_det, hipEventDisableTiming));
+            HIP_CHECK(hipEventCreateWithFlags(&c.ev_reid, hipEventDisableTiming));
         }
     }
     ~Pipeline() {
+        for (auto& e : ev_copy) if (e) (void)hipEventDestroy(e);
+        if (s_copy) (void)hipStreamDestroy(s_copy);
         for (Chunk& c : ck) {
             if (c.done) (void)hipEventDestroy(c.done);
             if (c.ev_yolo) (void)hipEventDestroy(c.ev_yolo);
             if (c.ev_det) (void)hipEventDestroy(c.ev_det);
+            if (c.ev_reid) (void)hipEventDestroy(c.ev_reid);
         }
     }
 
@@ -124,6 +136,14 @@ struct Pipeline {
         const double t0 = now();
         hipStream_t s = dev->s_main;
         c.frames = frames, c.first_slot = slot;
+        if (host_frames) {   // PCIe-inclusive path: H2D of this group's frames on the copy stream, overlapped with the previous group's compute
+            const int ci = &c == &ck[0] ? 0 : 1;
+            HIP_CHECK(hipMemcpyAsync(ring.p + (size_t)slot * frame_bytes, host_frames + (size_t)(slot - host_slot0) * frame_bytes,
+                                     (size_t)frames * frame_bytes, hipMemcpyHostToDevice, s_copy));
+            HIP_CHECK(hipEventRecord(ev_copy[ci], s_copy));
+            HIP_CHECK(hipStreamWaitEvent(s, ev_copy[ci], 0));
+            if (split_streams) HIP_CHECK(hipStreamWaitEvent(dev->s_reid, ev_copy[ci], 0));
+        }
         const uint8_t* f0 = ring.p + (size_t)slot * frame_bytes;
         {
             Prof pr(*dev, PROF_LETTERBOX, s, 0, (double)frames * ((double)frame_bytes + 16.0 * yolo->in_h * yolo->in_w));
@@ -163,21 +183,28 @@ struct Pipeline {
             nc += fd.n;
         }
         c.n_crops = nc;
+        // crop + ReID on their own stream: in inject mode they do not depend on the detector, and their CU-filling
+        // launches backfill the CUs that YOLO's thin layers (50-400 blocks per launch) leave idle
+        hipStream_t sr = split_streams ? dev->s_reid : s;
         if (nc) {
-            HIP_CHECK(hipMemcpyAsync(c.d_boxes.p, c.h_boxes.p, (size_t)nc * 16, hipMemcpyHostToDevice, s));
-            HIP_CHECK(hipMemcpyAsync(c.d_frame_of.p, c.h_frame_of.p, (size_t)nc * 4, hipMemcpyHostToDevice, s));
+            HIP_CHECK(hipMemcpyAsync(c.d_boxes.p, c.h_boxes.p, (size_t)nc * 16, hipMemcpyHostToDevice, sr));
+            HIP_CHECK(hipMemcpyAsync(c.d_frame_of.p, c.h_frame_of.p, (size_t)nc * 4, hipMemcpyHostToDevice, sr));
             {
-                Prof pr(*dev, PROF_CROP, s, 0, (double)nc * reid->in_h * reid->in_w * 19);
+                Prof pr(*dev, PROF_CROP, sr, 0, (double)nc * reid->in_h * reid->in_w * 19);
                 launch_crop_resize(f0, prm.frame_h, prm.frame_w, c.d_boxes.p, c.d_frame_of.p, nc, nullptr, reid->in_h,
-                                   reid->in_w, 1, reid->dtype, reid->input(), c.d_valid.p, s);
+                                   reid->in_w, 1, reid->dtype, reid->input(), c.d_valid.p, sr);
             }
-            reid->run(nc, s);
-            HIP_CHECK(hipMemcpyAsync(c.d_emb.p, reid->embeddings(), (size_t)nc * dim * 4, hipMemcpyDeviceToDevice, s));
+            reid->run(nc, sr);
+            HIP_CHECK(hipMemcpyAsync(c.d_emb.p, reid->embeddings(), (size_t)nc * dim * 4, hipMemcpyDeviceToDevice, sr));
             {   // matching.py:126-130 for every detection of the launch group at once
-                Prof pr(*dev, PROF_TRK, s, 0, (double)nc * dim * 8);
-                launch_normalize_rows(c.d_emb.p, c.d_emb_n.p, nc, dim, s);
+                Prof pr(*dev, PROF_TRK, sr, 0, (double)nc * dim * 8);
+                launch_normalize_rows(c.d_emb.p, c.d_emb_n.p, nc, dim, sr);
             }
-            HIP_CHECK(hipMemcpyAsync(c.h_valid.p, c.d_valid.p, (size_t)nc * 4, hipMemcpyDeviceToHost, s));
+            HIP_CHECK(hipMemcpyAsync(c.h_valid.p, c.d_valid.p, (size_t)nc * 4, hipMemcpyDeviceToHost, sr));
+        }
+        if (split_streams) {
+            HIP_CHECK(hipEventRecord(c.ev_reid, sr));
+            HIP_CHECK(hipStreamWaitEvent(s, c.ev_reid, 0));
         }
         HIP_CHECK(hipStreamWaitEvent(s, c.ev_det, 0));   // join: the next chunk's YOLO reuses the head buffers
         HIP_CHECK(hipEventRecord(c.done, s));
@@ -344,6 +371,37 @@ int aic_pipeline_run(aic_pipeline* p, int slot, int count, int32_t* n_tracks, in
     return guarded([&] {
         AIC_REQUIRE(p, AIC_ERR_INVALID, "NULL pipeline");
         p->p.run(slot, count, n_tracks, tracks6, track_conf, n_dets, det_boxes, det_scores, det_labels);
+    });
+}
+
+int aic_pipeline_run_from_host(aic_pipeline* p, const uint8_t* frames_bgr, int slot, int count, int32_t* n_tracks,
+                               int32_t* tracks6, float* track_conf, int32_t* n_dets) {
+    return guarded([&] {
+        AIC_REQUIRE(p && frames_bgr, AIC_ERR_INVALID, "NULL argument");
+        Pipeline& q = p->p;
+        q.host_frames = frames_bgr;
+        q.host_slot0 = slot;
+        try {
+            q.run(slot, count, n_tracks, tracks6, track_conf, n_dets, nullptr, nullptr, nullptr);
+        } catch (...) {
+            q.host_frames = nullptr;
+            throw;
+        }
+        q.host_frames = nullptr;
+    });
+}
+
+int aic_host_register(void* ptr, size_t bytes) {
+    return guarded([&] {
+        AIC_REQUIRE(ptr && bytes, AIC_ERR_INVALID, "NULL argument");
+        HIP_CHECK(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+    });
+}
+
+int aic_host_unregister(void* ptr) {
+    return guarded([&] {
+        AIC_REQUIRE(ptr, AIC_ERR_INVALID, "NULL argument");
+        HIP_CHECK(hipHostUnregister(ptr));
     });
 }
 

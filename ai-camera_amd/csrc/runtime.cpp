@@ -35,6 +35,7 @@ Device& device(int id) {
         HIP_CHECK(hipStreamCreateWithFlags(&d->s_main, hipStreamNonBlocking));
         HIP_CHECK(hipStreamCreateWithFlags(&d->s_trk, hipStreamNonBlocking));
         HIP_CHECK(hipStreamCreateWithFlags(&d->s_det, hipStreamNonBlocking));
+        HIP_CHECK(hipStreamCreateWithFlags(&d->s_reid, hipStreamNonBlocking));
         g_devs[id] = std::move(d);
     }
     HIP_CHECK(hipSetDevice(id));

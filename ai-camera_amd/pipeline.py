@@ -89,13 +89,16 @@ class TrackingPipeline:
             dets = [(db[f, :nd[f]], ds[f, :nd[f]], dl[f, :nd[f]]) for f in range(count)]
         return tracks, (dets if want_dets else nd)
 
-    def run_raw(self, slot, count):
-        """Timed path of bench.py: no Python-side unpacking, outputs stay in preallocated arrays."""
+    def _raw_bufs(self):
         if not hasattr(self, "_raw"):
             mp = self.max_persons
             self._raw = (np.zeros(self.ring_frames, np.int32), np.zeros((self.ring_frames, mp, 6), np.int32),
                          np.zeros((self.ring_frames, mp), np.float32), np.zeros(self.ring_frames, np.int32))
-        nt, rows, tconf, nd = self._raw
+        return self._raw
+
+    def run_raw(self, slot, count):
+        """Timed path of bench.py: no Python-side unpacking, outputs stay in preallocated arrays."""
+        nt, rows, tconf, nd = self._raw_bufs()
         L.call("aic_pipeline_run", self._h, int(slot), int(count), L.ptr(nt), L.ptr(rows), L.ptr(tconf), L.ptr(nd),
                None, None, None)
         return nt[:count], rows[:count], nd[:count]
@@ -105,6 +108,26 @@ class TrackingPipeline:
         a, b, c, n = C.c_double(), C.c_double(), C.c_double(), C.c_int64()
         L.call("aic_pipeline_stats", self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(n), int(reset))
         return dict(issue_s=a.value, wait_s=b.value, track_s=c.value, frames=n.value)
+
+    def run_raw_from_host(self, frames_bgr, slot=0):
+        """PCIe-inclusive timed path: frames (uint8 [n,H,W,3], ideally pinned via pin()) stream host -> HBM per launch
+        group on a copy stream, overlapped with compute."""
+        f = frames_bgr
+        assert f.dtype == np.uint8 and f.flags["C_CONTIGUOUS"] and f.shape[1:] == (self.frame_h, self.frame_w, 3)
+        count = len(f)
+        nt, rows, tconf, nd = self._raw_bufs()
+        L.call("aic_pipeline_run_from_host", self._h, L.ptr(f), int(slot), count, L.ptr(nt), L.ptr(rows), L.ptr(tconf), L.ptr(nd))
+        return nt[:count], rows[:count], nd[:count]
+
+    @staticmethod
+    def pin(array):
+        """Page-lock a NumPy buffer (hipHostRegister) so H2D runs at PCIe rate and truly asynchronously."""
+        L.call("aic_host_register", L.ptr(array), array.nbytes)
+        return array
+
+    @staticmethod
+    def unpin(array):
+        L.call("aic_host_unregister", L.ptr(array))
 
     def last_embeddings(self):
         n, d = C.c_int32(), C.c_int32()

@@ -218,6 +218,13 @@ int aic_pipeline_inject(aic_pipeline* p, int slot, int count, const int32_t* cou
 int aic_pipeline_run(aic_pipeline* p, int slot, int count, int32_t* n_tracks, int32_t* tracks6,
                      float* track_conf, int32_t* n_dets, float* det_boxes, float* det_scores,
                      int32_t* det_labels);
+/* Same, but the frames of this call come from HOST memory (the reference's cap.read() buffers,
+ * src/aicamera_tracker.py:170): each launch group's frames are copied into ring slots [slot, slot+count) on a copy
+ * stream while the previous group computes. Pin the buffer once with aic_host_register for full PCIe rate. */
+int aic_pipeline_run_from_host(aic_pipeline* p, const uint8_t* frames_bgr, int slot, int count, int32_t* n_tracks,
+                               int32_t* tracks6, float* track_conf, int32_t* n_dets);
+int aic_host_register(void* ptr, size_t bytes);   /* hipHostRegister: page-lock caller memory */
+int aic_host_unregister(void* ptr);
 int aic_pipeline_tracker(aic_pipeline* p, aic_tracker** out);
 /* Host wall-clock split since the last reset (seconds): issuing launch groups (producer thread), waiting for
  * a group's GPU work, walking its frames through the tracker (association recurrence). */

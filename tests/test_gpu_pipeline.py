@@ -91,3 +91,31 @@ def test_plugin_path_and_pipeline_detections_fp32(gpu, engines):
     finally:
         config.CLASSES_TO_TRACK.clear()
         config.CLASSES_TO_TRACK.update(old)
+
+
+def test_run_from_host_equals_resident_run(gpu, engines):
+    """Frames streamed from host memory group by group (pageable, then page-locked) give the very same rows as the
+    upload-then-run path (src/aicamera_tracker.py:170 hands over host frames)."""
+    n_frames = 20
+    sc = syn.Scene(seed=5, n_targets=10)
+    frames = np.ascontiguousarray(sc.render_batch(0, n_frames))
+    TP = pkg("pipeline").TrackingPipeline
+    kw = dict(batch=8, ring_frames=24, max_persons=32, dtype="fp16", inject=False, n_init=2)
+    a = TP(engines[0], engines[1], (720, 1280), **kw)
+    a.upload(0, frames)
+    nt0, rows0, nd0 = (x.copy() for x in a.run_raw(0, n_frames))
+    a.close()
+    for pinned in (False, True):
+        b = TP(engines[0], engines[1], (720, 1280), **kw)
+        if pinned:
+            TP.pin(frames)
+        try:
+            nt1, rows1, nd1 = b.run_raw_from_host(frames)
+        finally:
+            if pinned:
+                TP.unpin(frames)
+        assert np.array_equal(nd0, nd1) and np.array_equal(nt0, nt1)
+        for f in range(n_frames):
+            assert np.array_equal(rows0[f][:nt0[f]], rows1[f][:nt1[f]])
+        b.close()
+    assert nd0.sum() > 0
