@@ -592,6 +592,198 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const Conv
     epilogue_dispatch<T, MT, NT>(a, acc, mrow, n0 + wn * NT * 16, q);
 }
 
+// ------------------------------------------------------------------------------------------------
+// v4 "ping-pong": the v2 tile, operand ring and source-side swizzle, but every K-step is split into a LOAD
+// segment (issue the LDS-DMA of step k+NSTAGE-2, ds_read the fragments of step k) and a COMPUTE segment (the
+// MFMAs of step k), each closed by a raw s_barrier, and waves 4..7 run ONE barrier behind waves 0..3.  Each SIMD
+// hosts one wave of either half, so while one half's MFMAs own the matrix pipe the other half is reading LDS
+// and issuing DMA (MI355X_MICROARCH.md "Two waves per SIMD", cdna_hip_programming.md T3/T5).  In v2 all eight
+// waves leave the barrier together, read together and then fight for the pipe together.
+// Hazards, in program segments (L_k = 2k, C_k = 2k+1; a wave of the late half executes segment s one global
+// barrier after the early half):
+//   RAW  step j is waited for (counted vmcnt) in L_{j-1} and read in L_j: two barriers later, so the late half's
+//        waits have also passed a barrier every reader has passed;
+//   WAR  the ring slot read in L_k (data in registers by C_k) is re-filled by the DMA issued in L_{k+2}: three
+//        segments after the read was issued, hence after the late half's C_k.
+// Needs Cin % K-step == 0 (uniform tap per K-step) and 8 waves; one block per CU (LDS: NSTAGE stages).
+template <typename T, int MT, int NT, int WM, int WN, int NSTAGE>
+__global__ __launch_bounds__(512) void conv_igemm_pp_kernel(const ConvArgs a) {
+    constexpr int CH = 16 / (int)sizeof(T);
+    constexpr int BKE = 4 * CH;
+    constexpr int NTHR = 512;
+    constexpr int RP = NTHR / 4;
+    constexpr int BM = WM * MT * 16;
+    constexpr int BN = WN * NT * 16;
+    constexpr int BNP = (BN + RP - 1) / RP * RP;
+    constexpr int A_PER = BM / RP;
+    constexpr int B_PER = BNP / RP;
+    constexpr int LPS = A_PER + B_PER;
+    constexpr int STAGE = (BM + BNP) * 64;
+    static_assert(WM * WN == 8 && BM % RP == 0 && NSTAGE >= 4, "geometry");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int slot = t & 3, r0 = t >> 2;
+    const int kc = slot ^ ((r0 >> 1) & 3);
+    const int m0 = blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+    const bool late = wv >= 4;
+
+    const T* __restrict__ xg = reinterpret_cast<const T*>(a.x);
+    const T* __restrict__ wg = reinterpret_cast<const T*>(a.w);
+    const T* zero = reinterpret_cast<const T*>(a.zero);
+
+    const T* rowp[A_PER];
+    unsigned vmask[A_PER];
+    const int HoWo = a.Ho * a.Wo;
+    const int ntap = a.KH * a.KW;
+    const float inv_howo = 1.0f / (float)HoWo, inv_wo = 1.0f / (float)a.Wo;
+#pragma unroll
+    for (int i = 0; i < A_PER; ++i) {
+        const int m = m0 + r0 + RP * i;
+        unsigned mk = 0;
+        const T* rp = zero;
+        if (m < a.M) {
+            int img, rem, oh, ow;
+            fast_divmod(m, HoWo, inv_howo, img, rem);
+            fast_divmod(rem, a.Wo, inv_wo, oh, ow);
+            const int ih0 = oh * a.stride - a.pad, iw0 = ow * a.stride - a.pad;
+            rp = xg + (((long)img * a.H + ih0) * a.W + iw0) * a.x_cs + a.x_coff;
+            const int lo_w = max(0, -iw0), hi_w = min(a.KW, a.W - iw0);
+            const int lo_h = max(0, -ih0), hi_h = min(a.KH, a.H - ih0);
+            if (hi_w > lo_w && hi_h > lo_h) {
+                const unsigned vw = ((1u << hi_w) - 1u) & ~((1u << lo_w) - 1u);
+                const unsigned rows = (((1u << (hi_h * a.KW)) - 1u) & ~((1u << (lo_h * a.KW)) - 1u)) & a.tap_rows;
+                mk = vw * rows;
+            }
+        }
+        rowp[i] = rp;
+        vmask[i] = mk;
+    }
+    const int nsteps = a.Kp / BKE;
+    const int wm = wv / WN, wn = wv % WN;
+    const int q = lane >> 4, r = lane & 15;
+
+    floatx4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    int xoff[MT], woff[NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) xoff[i] = lds_off((wm * MT + i) * 16 + r, q);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) woff[j] = BM * 64 + lds_off((wn * NT + j) * 16 + r, q);
+    typedef typename Frag<T>::type frag_t;
+    char* const sdst = smem + (16 * wv) * 64;
+
+    const int csteps = a.Cin / BKE;
+    const T* aptr[A_PER];
+    int ainc[A_PER];
+    const T* wptr[B_PER];
+    int winc[B_PER];
+#pragma unroll
+    for (int j = 0; j < B_PER; ++j) {
+        const bool okr = r0 + RP * j < BN;
+        wptr[j] = okr ? wg + (size_t)(n0 + r0 + RP * j) * a.Kp + kc * CH : zero;
+        winc[j] = okr ? BKE : 0;
+    }
+    int tap = 0, kh = 0, kw = 0, cc = 0;
+    auto set_tap = [&] {
+        const long toff = ((long)kh * a.W + kw) * a.x_cs + kc * CH;
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) {
+            const bool ok = tap < ntap && ((vmask[i] >> (tap & 31)) & 1u);
+            aptr[i] = ok ? rowp[i] + toff : zero;
+            ainc[i] = ok ? BKE : 0;
+        }
+    };
+    set_tap();
+    auto issue = [&](int stage) {
+        char* sbase = sdst + stage * STAGE;
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) {
+            __builtin_amdgcn_global_load_lds((gptr_t)aptr[i], (lptr_t)(sbase + i * (RP * 64)), 16, 0, 0);
+            aptr[i] += ainc[i];
+        }
+#pragma unroll
+        for (int j = 0; j < B_PER; ++j) {
+            __builtin_amdgcn_global_load_lds((gptr_t)wptr[j], (lptr_t)(sbase + BM * 64 + j * (RP * 64)), 16, 0, 0);
+            wptr[j] += winc[j];
+        }
+        if (++cc == csteps) {
+            cc = 0;
+            ++tap;
+            if (++kw == a.KW) { kw = 0; ++kh; }
+            set_tap();
+        }
+    };
+#pragma unroll
+    for (int st = 0; st < NSTAGE - 2; ++st) issue(st);
+    wait_vmcnt<(NSTAGE - 3) * LPS>();          // step 0 has landed (this wave's part)
+    __builtin_amdgcn_s_barrier();              // ... everyone's
+    if (late) __builtin_amdgcn_s_barrier();    // waves 4..7 now run one segment behind
+
+    for (int step0 = 0; step0 < nsteps; step0 += NSTAGE) {
+#pragma unroll
+        for (int u = 0; u < NSTAGE; ++u) {
+            if (step0 + u < nsteps) {
+                // ---- LOAD segment
+                issue((u + NSTAGE - 2) % NSTAGE);
+                const char* base = smem + u * STAGE;
+                frag_t xf[MT], wf[NT];
+#pragma unroll
+                for (int j = 0; j < NT; ++j) wf[j] = *reinterpret_cast<const frag_t*>(base + woff[j]);
+#pragma unroll
+                for (int i = 0; i < MT; ++i) xf[i] = *reinterpret_cast<const frag_t*>(base + xoff[i]);
+                wait_vmcnt<(NSTAGE - 3) * LPS>();      // step+1 has landed (this wave's part)
+                __builtin_amdgcn_s_barrier();
+                // ---- COMPUTE segment
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc[i][j] = Frag<T>::mma(wf[j], xf[i], acc[i][j]);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+            }
+        }
+    }
+    if (!late) __builtin_amdgcn_s_barrier();   // every wave executes the same number of barriers
+    wait_vmcnt<0>();
+
+    int mrow[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int m = m0 + (wm * MT + i) * 16 + r;
+        mrow[i] = m < a.M ? m : -1;
+    }
+    epilogue_dispatch<T, MT, NT>(a, acc, mrow, n0 + wn * NT * 16, q);
+}
+
+template <typename T, int MT, int NT, int WM, int WN, int NSTAGE>
+static void launch_pp(const ConvArgs& a, hipStream_t s) {
+    constexpr int RP = 128;
+    constexpr int BM = WM * MT * 16, BN = WN * NT * 16, BNP = (BN + RP - 1) / RP * RP;
+    dim3 grid(ceil_div(a.M, BM), ceil_div(a.Cout, BN));
+    constexpr size_t lds = (size_t)NSTAGE * (BM + BNP) * 64;
+    static_assert(lds <= 160 * 1024, "ring does not fit the LDS");
+    auto kfn = conv_igemm_pp_kernel<T, MT, NT, WM, WN, NSTAGE>;
+    static bool attr = false;
+    if (!attr) {
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = true;
+    }
+    hipLaunchKernelGGL(kfn, grid, dim3(512), lds, s, a);
+    KCHECK();
+}
+
 static int conv_impl() {   // AICAM_CONV=v1 selects the register-staged kernel (A/B and fallback)
     static int v = [] { const char* e = getenv("AICAM_CONV"); return (e && e[0] == 'v' && e[1] == '1') ? 1 : 2; }();
     return v;
@@ -815,7 +1007,18 @@ static void launch_conv_t(const ConvArgs& a, hipStream_t s) {
     if (conv_impl() == 2 && try_patch<T>(a, s)) return;
     const long blocks128 = (long)ceil_div(a.M, 128);
     if (c % 128 == 0 || c > 160) {
-        if (conv_impl() == 2 && (blocks128 / 2) * ceil_div(c, 128) >= 384) launch_dma<T, 4, 4, 4, 2, 3>(a, s);   // 8 waves: 256 px x 128 ch
+        static const bool t256 = getenv("AICAM_NO_T256") == nullptr;   // +12% on ReID layer3/4 over 256x128 (profiles/)
+        // Ping-pong kernels (one block per CU) where the K loop is long enough to amortise the tile's prologue/epilogue:
+        // measured on MI355X (tools/conv_bench.py, profiles/): +17..19% on ReID layer3/4, +14% on layer2, a loss at K < 512.
+        static const bool pp = getenv("AICAM_NO_PP") == nullptr;
+        static const int pp_min = [] { const char* e = getenv("AICAM_PP_MIN"); return e ? atoi(e) : 200; }();
+        constexpr int BKE_ = 64 / (int)sizeof(T);
+        if (pp && conv_impl() == 2 && a.Cin % BKE_ == 0 && (a.Kp >= 16 * BKE_ || pp_min == 0)) {
+            if (c % 256 == 0 && (long)ceil_div(a.M, 256) * (c / 256) >= pp_min) { launch_pp<T, 8, 4, 2, 4, 4>(a, s); return; }   // 256 px x 256 ch
+            if (c == 128 && ceil_div(a.M, 512) >= pp_min) { launch_pp<T, 8, 4, 4, 2, 4>(a, s); return; }                      // 512 px x 128 ch
+        }
+        if (t256 && conv_impl() == 2 && c % 256 == 0 && (long)ceil_div(a.M, 256) * (c / 256) >= 200) launch_dma<T, 8, 4, 2, 4, 4>(a, s);   // 8 waves: 256 px x 256 ch
+        else if (conv_impl() == 2 && (blocks128 / 2) * ceil_div(c, 128) >= 384) launch_dma<T, 4, 4, 4, 2, 3>(a, s);   // 8 waves: 256 px x 128 ch
         else if (blocks128 * ceil_div(c, 128) >= 128) launch_variant<T, 4, 4, 2, 2>(a, s);   // 128 px x 128 ch
         else launch_variant<T, 2, 2, 2, 2>(a, s);                                       // 64 px x 64 ch (small maps)
     } else if (c % 80 == 0) {

@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Single-layer conv microbench through the C ABI: builds a throw-away ReID-kind engine whose body is
+`reps` copies of one conv (ping-pong buffers), runs it on n items and reports the conv-class TFLOP/s
+measured by the library's own HIP-event brackets.
+  python tools/conv_bench.py H W CIN COUT K [items] [reps] [res]"""
+import importlib
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+ef = importlib.import_module("ai-camera_amd.engine_file")
+L = importlib.import_module("ai-camera_amd._lib")
+he = importlib.import_module("ai-camera_amd.hip_engine")
+
+
+def graph(H, W, cin, cout, k, reps, res):
+    g = ef.Graph(ef.KIND_REID, H, W)
+    wg = ef._WeightGen(3)
+    inp = g.buf(H, W, ef.IN_C)
+    a, b = g.buf(H, W, cin), g.buf(H, W, cout)
+    g.conv("stem", inp, a, 3, cin, 1, 1, ef.ACT_RELU, wb=wg(cin, 3, 1, ef.ACT_RELU))
+    src = a
+    for i in range(reps):
+        dst = b if src == a else a
+        if cin != cout and i:
+            break
+        g.conv(f"t{i}", src, dst, cin, cout, k, 1, ef.ACT_RELU, wb=wg(cout, cin, k, ef.ACT_RELU, 0.5 if res else 1.0),
+               **(dict(res=(dst, 0), res_mode=ef.RES_ADD_THEN_ACT) if res and cin == cout else {}))
+        src = dst
+    p = g.buf(1, 1, cout)
+    g.simple(ef.OP_AVGPOOL, src, p, cout)
+    e = g.buf(1, 1, cout, ef.DT_F32)
+    g.simple(ef.OP_L2NORM, p, e, cout)
+    g.outputs.append([e, cout, 0, 0, 0, 0, 0, 0])
+    g.meta = [cout, 0, 0, 0, 0, 0, 0, 0]
+    return g
+
+
+def main():
+    H, W, cin, cout, k = (int(v) for v in sys.argv[1:6])
+    items = int(sys.argv[6]) if len(sys.argv) > 6 else 960
+    reps = int(sys.argv[7]) if len(sys.argv) > 7 else 8
+    res = int(sys.argv[8]) if len(sys.argv) > 8 else 0
+    g = graph(H, W, cin, cout, k, reps, res)
+    path = f"/tmp/convbench_{os.getpid()}.aicw"
+    ef.write_engine(path, g)
+    eng = he.HipEngine(path, dtype=os.environ.get("DTYPE", "fp16"), max_items=items, warm_up=False)
+    x = np.random.default_rng(0).standard_normal((items, 3, H, W)).astype(np.float32)
+    eng.reid_infer_np(x)
+    L.call("aic_prof_enable", 0, 1)
+    L.call("aic_prof_reset", 0)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        eng.reid_infer_np(x)
+    dt = time.perf_counter() - t0
+    p = L.prof_read(0)["conv_igemm"]
+    n_conv = sum(1 for o in g.ops if o[0] == 1)
+    us = p["ms"] * 1e3 / 5 / n_conv
+    print(f"H{H} W{W} cin{cin} cout{cout} k{k} items{items} res{res}: M={items*H*W} K={cin*k*k}  "
+          f"{p['flops'] / p['ms'] / 1e9:7.1f} TF  (~{us:.1f} us per conv, wall {dt/5*1e3:.2f} ms/iter) env={ {k_: v for k_, v in os.environ.items() if k_.startswith('AICAM')} }")
+    os.remove(path)
+
+
+if __name__ == "__main__":
+    main()
