@@ -50,7 +50,10 @@ template <> struct Frag<float> {
     }
 };
 
-__device__ __forceinline__ int lds_off(int row, int chunk) { return row * 64 + 16 * (chunk ^ ((row >> 1) & 3)); }
+// swz(row) = ((row>>1)&3) ^ ((row>>3)&2): conflict-free for 16 consecutive rows (pixel tiles, identity weight tiles) AND
+// for the permuted weight rows {c + 8k + s} of perm_row() (brute-forced over the ds_read_b128 lane groups).
+__device__ __forceinline__ int lds_swz(int row) { return ((row >> 1) & 3) ^ ((row >> 3) & 2); }
+__device__ __forceinline__ int lds_off(int row, int chunk) { return row * 64 + 16 * (chunk ^ lds_swz(row)); }
 
 // 4 waves per block arranged WM x WN; each wave owns MT x NT tiles of 16 pixels x 16 channels.
 template <typename T, int MT, int NT, int WM, int WN>
@@ -307,8 +310,113 @@ __device__ __forceinline__ void epilogue_fast(const ConvArgs& a, floatx4 (&acc)[
     }
 }
 
+// Channel permutation of the v2+ kernels: MFMA tile j, row rho (= 4q + e on the output side) of a wave's
+// NT-tile channel block carries output channel  32*(j>>1) + 8*(rho>>2) + 4*(j&1) + (rho&3)  (tiles taken in
+// pairs; an odd last tile keeps the identity 16j + rho).  A lane (r, q) then owns, per tile pair, EIGHT
+// consecutive channels of its pixel: one 16-byte fp16 store (two for fp32) instead of two 8-byte ones, and
+// the four q-lanes of a pixel write 64 contiguous bytes per instruction.  The A-operand (weight) rows are
+// fetched from LDS through the same map (perm_row), so the arithmetic per output is unchanged.
+template <int NT> __device__ __forceinline__ int perm_ch(int j, int q, int e) {
+    return j < (NT & ~1) ? 32 * (j >> 1) + 8 * q + 4 * (j & 1) + e : 16 * j + 4 * q + e;
+}
+template <int NT> __device__ __forceinline__ int perm_row(int j, int r) { return perm_ch<NT>(j, r >> 2, r & 3); }
+
+template <typename T, int MT, int NT, int ACT, int RES, bool F32OUT>
+__device__ __forceinline__ void epilogue_wide(const ConvArgs& a, floatx4 (&acc)[MT][NT], const int (&mrow)[MT], int n_base, int q) {
+    constexpr int NP = NT / 2;
+    const float* __restrict__ bias = a.bias;
+    const T* __restrict__ rg = reinterpret_cast<const T*>(a.res);
+    floatx4 b4[NT];
+    bool pcol[NP + 1];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int n = n_base + 32 * p + 8 * q;
+        pcol[p] = n < a.Cout;                       // Cout % 8 == 0 on this path: all eight or none
+        b4[2 * p] = *reinterpret_cast<const floatx4*>(bias + n);          // bias is padded to cout_pad
+        b4[2 * p + 1] = *reinterpret_cast<const floatx4*>(bias + n + 4);
+    }
+    if constexpr (NT & 1) {
+        const int n = n_base + 16 * (NT - 1) + 4 * q;
+        pcol[NP] = n < a.Cout;
+        b4[NT - 1] = *reinterpret_cast<const floatx4*>(bias + n);
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int m = mrow[i];
+        if (m < 0) continue;
+        const size_t ybase = (size_t)m * a.y_cs + a.y_coff;
+        const size_t rbase = RES ? (size_t)m * a.r_cs + a.r_coff : 0;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            if (!pcol[p]) continue;
+            const int n = n_base + 32 * p + 8 * q;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = acc[i][2 * p + (e >> 2)][e & 3] + b4[2 * p + (e >> 2)][e & 3];
+            if constexpr (RES != 0) {
+                float rv[8];
+                if constexpr (sizeof(T) == 2) {
+                    const half8 h = *reinterpret_cast<const half8*>(rg + rbase + n);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) rv[e] = (float)h[e];
+                } else {
+                    const floatx4 h0 = *reinterpret_cast<const floatx4*>(rg + rbase + n);
+                    const floatx4 h1 = *reinterpret_cast<const floatx4*>(rg + rbase + n + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { rv[e] = h0[e]; rv[4 + e] = h1[e]; }
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = RES == 1 ? act_fast<ACT>(v[e] + rv[e]) : act_fast<ACT>(v[e]) + rv[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = act_fast<ACT>(v[e]);
+            }
+            if constexpr (F32OUT || sizeof(T) == 4) {
+                float* yp = reinterpret_cast<float*>(a.y) + ybase + n;
+                *reinterpret_cast<floatx4*>(yp) = floatx4{v[0], v[1], v[2], v[3]};
+                *reinterpret_cast<floatx4*>(yp + 4) = floatx4{v[4], v[5], v[6], v[7]};
+            } else {
+                const half8 h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3], (half_t)v[4], (half_t)v[5], (half_t)v[6], (half_t)v[7]};
+                *reinterpret_cast<half8*>(reinterpret_cast<half_t*>(a.y) + ybase + n) = h;
+            }
+        }
+        if constexpr (NT & 1) {
+            if (pcol[NP]) {
+                constexpr int j = NT - 1;
+                const int n = n_base + 16 * j + 4 * q;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] + b4[j][e];
+                if constexpr (RES != 0) {
+                    float rv[4];
+                    if constexpr (sizeof(T) == 2) {
+                        const half4 h = *reinterpret_cast<const half4*>(rg + rbase + n);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) rv[e] = (float)h[e];
+                    } else {
+                        const floatx4 h = *reinterpret_cast<const floatx4*>(rg + rbase + n);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) rv[e] = h[e];
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = RES == 1 ? act_fast<ACT>(v[e] + rv[e]) : act_fast<ACT>(v[e]) + rv[e];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = act_fast<ACT>(v[e]);
+                }
+                if constexpr (F32OUT || sizeof(T) == 4) {
+                    *reinterpret_cast<floatx4*>(reinterpret_cast<float*>(a.y) + ybase + n) = floatx4{v[0], v[1], v[2], v[3]};
+                } else {
+                    const half4 h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+                    *reinterpret_cast<half4*>(reinterpret_cast<half_t*>(a.y) + ybase + n) = h;
+                }
+            }
+        }
+    }
+}
+
 // Generic (any Cout, any mode) fallback: runtime branches, scalar tail.
-template <typename T, int MT, int NT>
+template <typename T, int MT, int NT, bool PERM>
 __device__ __forceinline__ void epilogue_generic(const ConvArgs& a, floatx4 (&acc)[MT][NT], const int (&mrow)[MT], int n_base, int q) {
     // (inlined and fully unrolled on purpose: a call would force `a` and `acc` into scratch memory)
     const float* __restrict__ bias = a.bias;
@@ -319,7 +427,7 @@ __device__ __forceinline__ void epilogue_generic(const ConvArgs& a, floatx4 (&ac
         if (m < 0) continue;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-            const int n = n_base + j * 16 + 4 * q;
+            const int n = n_base + (PERM ? perm_ch<NT>(j, q, 0) : j * 16 + 4 * q);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 if (n + e >= a.Cout) continue;
@@ -336,18 +444,21 @@ __device__ __forceinline__ void epilogue_generic(const ConvArgs& a, floatx4 (&ac
     }
 }
 
-template <typename T, int MT, int NT>
+template <typename T, int MT, int NT, bool PERM = false>
 __device__ __forceinline__ void epilogue_dispatch(const ConvArgs& a, floatx4 (&acc)[MT][NT], const int (&mrow)[MT], int n_base, int q) {
-    const int key = (a.Cout & 3) ? -1 : (a.act | (a.res_mode << 2) | (a.out_f32 << 4));
+    const int key = (a.Cout & (PERM ? 7 : 3)) ? -1 : (a.act | (a.res_mode << 2) | (a.out_f32 << 4));
+#define AIC_EPI(ACT, RES, F32) do { if constexpr (PERM) epilogue_wide<T, MT, NT, ACT, RES, F32>(a, acc, mrow, n_base, q); \
+                                    else epilogue_fast<T, MT, NT, ACT, RES, F32>(a, acc, mrow, n_base, q); } while (0)
     switch (key) {
-        case 1: epilogue_fast<T, MT, NT, 1, 0, false>(a, acc, mrow, n_base, q); break;            // SiLU
-        case 1 | (2 << 2): epilogue_fast<T, MT, NT, 1, 2, false>(a, acc, mrow, n_base, q); break;  // SiLU then +res (C2f bottleneck)
-        case 2: epilogue_fast<T, MT, NT, 2, 0, false>(a, acc, mrow, n_base, q); break;            // ReLU
-        case 2 | (1 << 2): epilogue_fast<T, MT, NT, 2, 1, false>(a, acc, mrow, n_base, q); break;  // relu(x + res) (BasicBlock)
-        case 0: epilogue_fast<T, MT, NT, 0, 0, false>(a, acc, mrow, n_base, q); break;            // linear (downsample, FC)
-        case 0 | (1 << 4): epilogue_fast<T, MT, NT, 0, 0, true>(a, acc, mrow, n_base, q); break;   // linear fp32 (detect head)
-        default: epilogue_generic<T, MT, NT>(a, acc, mrow, n_base, q); break;
+        case 1: AIC_EPI(1, 0, false); break;             // SiLU
+        case 1 | (2 << 2): AIC_EPI(1, 2, false); break;  // SiLU then +res (C2f bottleneck)
+        case 2: AIC_EPI(2, 0, false); break;             // ReLU
+        case 2 | (1 << 2): AIC_EPI(2, 1, false); break;  // relu(x + res) (BasicBlock)
+        case 0: AIC_EPI(0, 0, false); break;             // linear (downsample, FC)
+        case 0 | (1 << 4): AIC_EPI(0, 0, true); break;   // linear fp32 (detect head)
+        default: epilogue_generic<T, MT, NT, PERM>(a, acc, mrow, n_base, q); break;
     }
+#undef AIC_EPI
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -405,7 +516,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const Conv
     const int t = threadIdx.x;
     const int lane = t & 63, wv = t >> 6;
     const int slot = t & 3, r0 = t >> 2;
-    const int kc = slot ^ ((r0 >> 1) & 3);     // K-chunk this thread fetches (source-side swizzle)
+    const int kc = slot ^ lds_swz(r0);         // K-chunk this thread fetches (source-side swizzle)
     const int m0 = blockIdx.x * BM;
     const int n0 = blockIdx.y * BN;
 
@@ -456,7 +567,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const Conv
 #pragma unroll
     for (int i = 0; i < MT; ++i) xoff[i] = lds_off((wm * MT + i) * 16 + r, q);
 #pragma unroll
-    for (int j = 0; j < NT; ++j) woff[j] = BM * 64 + lds_off((wn * NT + j) * 16 + r, q);
+    for (int j = 0; j < NT; ++j) woff[j] = BM * 64 + lds_off(wn * NT * 16 + perm_row<NT>(j, r), q);
     typedef typename Frag<T>::type frag_t;
     auto compute = [&](int stage) {
         const char* base = smem + stage * STAGE;
@@ -589,7 +700,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const Conv
         const int m = m0 + (wm * MT + i) * 16 + r;
         mrow[i] = m < a.M ? m : -1;
     }
-    epilogue_dispatch<T, MT, NT>(a, acc, mrow, n0 + wn * NT * 16, q);
+    epilogue_dispatch<T, MT, NT, true>(a, acc, mrow, n0 + wn * NT * 16, q);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -606,8 +717,14 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const Conv
 //   WAR  the ring slot read in L_k (data in registers by C_k) is re-filled by the DMA issued in L_{k+2}: three
 //        segments after the read was issued, hence after the late half's C_k.
 // Needs Cin % K-step == 0 (uniform tap per K-step) and 8 waves; one block per CU (LDS: NSTAGE stages).
+// Optional per-block phase timestamps (100 MHz wall clock) for tools/conv_bench.py: AICAM_PP_TIMES=1.
+__device__ unsigned long long g_pp_times[4 * 4096];
+__device__ int g_pp_times_on;
+#define PP_STAMP(k) do { if (g_pp_times_on && threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 4096) g_pp_times[4 * blockIdx.x + (k)] = wall_clock64(); } while (0)
+
 template <typename T, int MT, int NT, int WM, int WN, int NSTAGE>
 __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(const ConvArgs a) {
+    PP_STAMP(0);
     constexpr int CH = 16 / (int)sizeof(T);
     constexpr int BKE = 4 * CH;
     constexpr int NTHR = 512;
@@ -626,7 +743,7 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(const ConvArgs a) {
     const int t = threadIdx.x;
     const int lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
     const int slot = t & 3, r0 = t >> 2;
-    const int kc = slot ^ ((r0 >> 1) & 3);
+    const int kc = slot ^ lds_swz(r0);
     const int m0 = blockIdx.x * BM;
     const int n0 = blockIdx.y * BN;
     const bool late = wv >= 4;
@@ -676,7 +793,7 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(const ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < MT; ++i) xoff[i] = lds_off((wm * MT + i) * 16 + r, q);
 #pragma unroll
-    for (int j = 0; j < NT; ++j) woff[j] = BM * 64 + lds_off((wn * NT + j) * 16 + r, q);
+    for (int j = 0; j < NT; ++j) woff[j] = BM * 64 + lds_off(wn * NT * 16 + perm_row<NT>(j, r), q);
     typedef typename Frag<T>::type frag_t;
     char* const sdst = smem + (16 * wv) * 64;
 
@@ -725,6 +842,7 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(const ConvArgs a) {
     for (int st = 0; st < NSTAGE - 2; ++st) issue(st);
     wait_vmcnt<(NSTAGE - 3) * LPS>();          // step 0 has landed (this wave's part)
     __builtin_amdgcn_s_barrier();              // ... everyone's
+    PP_STAMP(1);
     if (late) __builtin_amdgcn_s_barrier();    // waves 4..7 now run one segment behind
 
     for (int step0 = 0; step0 < nsteps; step0 += NSTAGE) {
@@ -757,6 +875,7 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(const ConvArgs a) {
     }
     if (!late) __builtin_amdgcn_s_barrier();   // every wave executes the same number of barriers
     wait_vmcnt<0>();
+    PP_STAMP(2);
 
     int mrow[MT];
 #pragma unroll
@@ -764,7 +883,33 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(const ConvArgs a) {
         const int m = m0 + (wm * MT + i) * 16 + r;
         mrow[i] = m < a.M ? m : -1;
     }
-    epilogue_dispatch<T, MT, NT>(a, acc, mrow, n0 + wn * NT * 16, q);
+    epilogue_dispatch<T, MT, NT, true>(a, acc, mrow, n0 + wn * NT * 16, q);
+    if (g_pp_times_on) { wait_vmcnt<0>(); PP_STAMP(3); }
+}
+
+static void pp_times_report(hipStream_t s, int nblk) {
+    static std::vector<unsigned long long> h(4 * 4096);
+    HIP_CHECK(hipStreamSynchronize(s));
+    HIP_CHECK(hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_pp_times), sizeof(unsigned long long) * 4 * 4096));
+    nblk = std::min(nblk, 4096);
+    unsigned long long t0 = ~0ull, t3 = 0;
+    double d[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
+    for (int b = 0; b < nblk; ++b) {
+        t0 = std::min(t0, h[4 * b]);
+        t3 = std::max(t3, h[4 * b + 3]);
+        for (int k = 0; k < 3; ++k) {
+            const double v = (double)(h[4 * b + k + 1] - h[4 * b + k]) * 0.01;
+            d[k] += v / nblk;
+            mx[k] = std::max(mx[k], v);
+        }
+    }
+    double start_spread = 0, end_spread = 0;
+    for (int b = 0; b < nblk; ++b) {
+        start_spread = std::max(start_spread, (double)(h[4 * b] - t0) * 0.01);
+        end_spread = std::max(end_spread, (double)(t3 - h[4 * b + 3]) * 0.01);
+    }
+    fprintf(stderr, "[pp_times] blocks %d: prologue %.2f (max %.2f) us, k-loop %.2f (max %.2f), epilogue+drain %.2f (max %.2f); first start -> last end %.2f us; start spread %.2f, end spread %.2f\n",
+            nblk, d[0], mx[0], d[1], mx[1], d[2], mx[2], (double)(t3 - t0) * 0.01, start_spread, end_spread);
 }
 
 template <typename T, int MT, int NT, int WM, int WN, int NSTAGE>
@@ -780,8 +925,14 @@ static void launch_pp(const ConvArgs& a, hipStream_t s) {
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr = true;
     }
+    static const bool times = getenv("AICAM_PP_TIMES") != nullptr;
+    if (times) {
+        const int on = 1;
+        HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_pp_times_on), &on, sizeof(int)));
+    }
     hipLaunchKernelGGL(kfn, grid, dim3(512), lds, s, a);
     KCHECK();
+    if (times) pp_times_report(s, (int)grid.x);
 }
 
 static int conv_impl() {   // AICAM_CONV=v1 selects the register-staged kernel (A/B and fallback)
@@ -857,7 +1008,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(const ConvA
 
     // ---- weight stream: one 16-byte chunk per thread per K-step; rows past Cout read the zero page with stride 0
     const int slot = t & 3, r0 = t >> 2;
-    const int kc = slot ^ ((r0 >> 1) & 3);
+    const int kc = slot ^ lds_swz(r0);
     const bool wrow_ok = r0 < BN;
     const T* wptr = wrow_ok ? wg + (size_t)(n0 + r0) * a.Kp + kc * CH : zero;
     const int winc = wrow_ok ? BKE : 0;
@@ -886,7 +1037,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(const ConvA
     }
     int woff[NT];
 #pragma unroll
-    for (int j = 0; j < NT; ++j) woff[j] = PATCH_BYTES + lds_off((wn * NT + j) * 16 + r, q);
+    for (int j = 0; j < NT; ++j) woff[j] = PATCH_BYTES + lds_off(wn * NT * 16 + perm_row<NT>(j, r), q);
 
     floatx4 acc[MT][NT];
 #pragma unroll
@@ -932,7 +1083,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(const ConvA
         const int oy = oy0 + pt / TW, ox = ox0 + pt % TW;
         mrow[i] = (oy < a.Ho && ox < a.Wo) ? (img * a.Ho + oy) * a.Wo + ox : -1;
     }
-    epilogue_dispatch<T, MT, NT>(a, acc, mrow, n0 + wn * NT * 16, q);
+    epilogue_dispatch<T, MT, NT, true>(a, acc, mrow, n0 + wn * NT * 16, q);
 }
 
 template <typename T, int MT, int NT, int WM, int WN, int TH, int TW, int NSTAGE, int LGCPP>
