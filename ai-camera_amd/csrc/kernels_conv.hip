@@ -1166,7 +1166,7 @@ static void launch_conv_t(const ConvArgs& a, hipStream_t s) {
         constexpr int BKE_ = 64 / (int)sizeof(T);
         if (pp && conv_impl() == 2 && a.Cin % BKE_ == 0 && (a.Kp >= 16 * BKE_ || pp_min == 0)) {
             if (c % 256 == 0 && (long)ceil_div(a.M, 256) * (c / 256) >= pp_min) { launch_pp<T, 8, 4, 2, 4, 4>(a, s); return; }   // 256 px x 256 ch
-            if (c == 128 && ceil_div(a.M, 512) >= pp_min) { launch_pp<T, 8, 4, 4, 2, 4>(a, s); return; }                      // 512 px x 128 ch
+            if (c == 128 && (a.Kp >= 32 * BKE_ || pp_min == 0) && ceil_div(a.M, 512) >= pp_min) { launch_pp<T, 8, 4, 4, 2, 4>(a, s); return; }                      // 512 px x 128 ch
         }
         if (t256 && conv_impl() == 2 && c % 256 == 0 && (long)ceil_div(a.M, 256) * (c / 256) >= 200) launch_dma<T, 8, 4, 2, 4, 4>(a, s);   // 8 waves: 256 px x 256 ch
         else if (conv_impl() == 2 && (blocks128 / 2) * ceil_div(c, 128) >= 384) launch_dma<T, 4, 4, 4, 2, 3>(a, s);   // 8 waves: 256 px x 128 ch
@@ -1287,10 +1287,149 @@ __global__ __launch_bounds__(256) void reid_stem_pool_kernel(const StemArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fused ReID stem, second form (default): one block = one crop, 8 waves, wave w owns pooled rows [Hp/8*w, +Hp/8).
+//  * K is laid out (tap, RGB0): taps 0..7 = one v_mfma_f32_16x16x32_f16 whose B fragment is two aligned 8-byte
+//    patch pixels per lane, tap 8 = a second one with zero weights outside (q = 0, j < 3): the im2col fragment is
+//    3 ds_read_b64, no scalar gathers (the first form spent 71 VALU per MFMA on them).  [v_mfma_f32_16x16x16_f16
+//    for tap 8 returned stale accumulator halves under hipcc 7.2: the first two results were read too early];
+//  * the bias rides in as the accumulator's initial value, ReLU is a packed fp16 max after the conversion;
+//  * the 3x3/2 max-pool never touches LDS: vertical max of three conv rows in registers (v_pk_max_f16),
+//    horizontal max over lane neighbours by DPP row shifts inside the 16-pixel tile (lane 0 takes pixel 15 of
+//    the tile to its left by row_ror), out-of-image taps are 0 = the identity of max over post-ReLU values;
+//  * with the channel permutation of perm_ch() a lane owns 8 consecutive channels per tile pair; odd lanes take
+//    the second pair of their even neighbour, so one 16-byte store instruction writes 8 pooled pixels x 128 B.
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef short short2_t __attribute__((ext_vector_type(2)));
+// max of packed fp16 pairs as SIGNED 16-bit integers (v_pk_max_i16): exact for the values met here -- non-negative
+// halves order like their bit patterns, and against 0 it is ReLU (any negative half, -0 included, has the sign bit
+// set and loses to 0).  The fp16 form would add a canonicalising v_pk_max_f16 v,v,v per operand.
+__device__ __forceinline__ unsigned pk_max(unsigned a, unsigned b) {
+    const short2_t m = __builtin_elementwise_max(__builtin_bit_cast(short2_t, a), __builtin_bit_cast(short2_t, b));
+    return __builtin_bit_cast(unsigned, m);
+}
+template <int CTRL, bool BOUND> __device__ __forceinline__ unsigned dpp(unsigned old, unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, 0xf, 0xf, BOUND);
+}
+struct Row8 { unsigned u[8]; };   // one pixel's 16 output channels x 2 tile pairs, packed fp16: u[4p + i]
+
+__global__ __launch_bounds__(512) void reid_stem_pool2_kernel(const StemArgs a) {
+    constexpr int CW = 64, PW = CW + 2, NTX = CW / 16;
+    constexpr int ROW_SHL1 = 0x101, ROW_SHR1 = 0x111, ROW_ROR1 = 0x121;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint2* patch = reinterpret_cast<uint2*>(smem);                        // [H + 2][PW] pixels x RGB0 halves, zero border
+
+    const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6), r = lane & 15, q = lane >> 4;
+    const int H = a.H, Hp = H / 2, Wp = CW / 2, rows_per_wave = Hp / 8;
+    const int img = blockIdx.x;
+    const half_t* xg = reinterpret_cast<const half_t*>(a.x) + (size_t)img * H * CW * 8;
+
+    for (int idx = t; idx < (H + 2) * PW; idx += 512) {
+        const int iy = idx / PW, ix = idx - iy * PW;
+        const int gy = iy - 1, gx = ix - 1;
+        uint2 v = make_uint2(0u, 0u);
+        if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)CW) v = *reinterpret_cast<const uint2*>(xg + ((size_t)gy * CW + gx) * 8);
+        patch[idx] = v;
+    }
+
+    // A operands: MFMA row rho of channel tile ct carries channel perm_row<4>(ct, rho); lane (rho = r, q) holds k = 8q..8q+7
+    const half_t* wg = reinterpret_cast<const half_t*>(a.w);
+    half8 wa[4], wb[4];
+    floatx4 bi[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+        const half_t* wr = wg + (size_t)perm_row<4>(ct, r) * a.Kp;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int tap = 2 * q + (j >> 2), ci = j & 3;
+            wa[ct][j] = ci < 3 ? wr[tap * 8 + ci] : (half_t)0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) wb[ct][j] = (q == 0 && j < 3) ? wr[8 * 8 + j] : (half_t)0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bi[ct][e] = a.bias[perm_ch<4>(ct, q, e)];
+    }
+    // patch offsets (in pixels) of this lane's taps relative to (conv row y, tile pixel): taps 2q, 2q+1 and tap 8
+    const int t0 = 2 * q, t1 = 2 * q + 1;
+    const int off0 = (t0 / 3) * PW + t0 % 3 + r, off1 = (t1 / 3) * PW + t1 % 3 + r, off2 = 2 * PW + 2 + r;
+    __syncthreads();
+
+    auto conv_tile = [&](int y, int tx) -> Row8 {   // conv + bias + ReLU of 16 pixels (row y, columns 16tx..) x 64 channels
+        Row8 o;
+        if ((unsigned)y >= (unsigned)H) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o.u[i] = 0u;
+            return o;
+        }
+        const uint2* pp = patch + y * PW + 16 * tx;
+        const uint2 x0 = pp[off0], x1 = pp[off1], x2 = pp[off2];
+        const uint4 xa4 = make_uint4(x0.x, x0.y, x1.x, x1.y), xb4 = make_uint4(x2.x, x2.y, 0u, 0u);
+        const half8 xa = __builtin_bit_cast(half8, xa4), xb = __builtin_bit_cast(half8, xb4);
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            floatx4 acc = bi[ct];
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[ct], xa, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[ct], xb, acc, 0, 0, 0);
+            const half2_t h01 = {(half_t)acc[0], (half_t)acc[1]}, h23 = {(half_t)acc[2], (half_t)acc[3]};
+            o.u[2 * ct] = pk_max(__builtin_bit_cast(unsigned, h01), 0u);
+            o.u[2 * ct + 1] = pk_max(__builtin_bit_cast(unsigned, h23), 0u);
+        }
+        return o;
+    };
+
+    half_t* yg = reinterpret_cast<half_t*>(a.y);
+    const int py0 = wv * rows_per_wave;
+    Row8 prev[NTX];
+#pragma unroll
+    for (int tx = 0; tx < NTX; ++tx) prev[tx] = conv_tile(2 * py0 - 1, tx);
+    for (int py = py0; py < py0 + rows_per_wave; ++py) {
+        Row8 vleft;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) vleft.u[i] = 0u;
+#pragma unroll
+        for (int tx = 0; tx < NTX; ++tx) {
+            const Row8 b = conv_tile(2 * py, tx), c = conv_tile(2 * py + 1, tx);
+            Row8 v, hm;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                v.u[i] = pk_max(pk_max(prev[tx].u[i], b.u[i]), c.u[i]);
+                prev[tx].u[i] = c.u[i];
+                const unsigned rot = dpp<ROW_ROR1, false>(0u, vleft.u[i]);          // lane 0 <- pixel 15 of the tile to the left (0 at tx = 0)
+                const unsigned lf = dpp<ROW_SHR1, false>(rot, v.u[i]);               // lane r <- pixel r-1 (lane 0 keeps rot)
+                const unsigned rt = dpp<ROW_SHL1, true>(0u, v.u[i]);                 // lane r <- pixel r+1 (only even r are used)
+                hm.u[i] = pk_max(pk_max(lf, v.u[i]), rt);
+            }
+            vleft = v;
+            // even lane 2u: pooled pixel 8tx+u, channels of pair 0; odd lane 2u+1: same pixel, pair 1 (taken from lane 2u)
+            uint4 out;
+            unsigned* op = reinterpret_cast<unsigned*>(&out);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const unsigned nb = dpp<ROW_SHR1, true>(0u, hm.u[4 + i]);
+                op[i] = (r & 1) ? nb : hm.u[i];
+            }
+            const size_t pix = ((size_t)img * Hp + py) * Wp + 8 * tx + (r >> 1);
+            *reinterpret_cast<uint4*>(yg + pix * a.y_cs + a.y_coff + (r & 1) * 32 + 8 * q) = out;
+        }
+    }
+}
+
 void launch_reid_stem_pool(const void* x, const void* w, const float* bias, void* y, int n, int H, int W, int Kp, int y_cs,
                            int y_coff, hipStream_t s) {
     if (n <= 0) return;
     StemArgs a{x, w, bias, y, n, H, W, Kp, y_cs, y_coff};
+    static const bool v1 = [] { const char* e = getenv("AICAM_STEM"); return e && e[0] == 'v' && e[1] == '1'; }();
+    const size_t lds2 = (size_t)(H + 2) * 66 * 8;
+    if (!v1 && W == 64 && H % 16 == 0 && lds2 <= 160 * 1024) {
+        static bool attr2 = false;
+        if (!attr2) {
+            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(reid_stem_pool2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr2 = true;
+        }
+        hipLaunchKernelGGL(reid_stem_pool2_kernel, dim3(n), dim3(512), lds2, s, a);
+        KCHECK();
+        return;
+    }
     const size_t lds = ((11 * 66 * 8 + 15) / 16) * 16 + (size_t)9 * 64 * 128;
     static bool attr = false;
     if (!attr) {

@@ -45,8 +45,8 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=12)
     p.add_argument("--warmup", type=int, default=3)
-    p.add_argument("--ring", type=int, default=64, help="rendered frames R; a step processes 2R frames")
-    p.add_argument("--batch", type=int, default=32, help="frames per detection/ReID launch group")
+    p.add_argument("--ring", type=int, default=128, help="rendered frames R; a step processes 2R frames")
+    p.add_argument("--batch", type=int, default=64, help="frames per detection/ReID launch group")
     p.add_argument("--persons", type=int, default=30)
     p.add_argument("--width", type=int, default=1280)
     p.add_argument("--height", type=int, default=720)
