@@ -12,7 +12,9 @@ consume the planted boxes (inject switch) because seeded weights cann
 
 A STEP = one pass of the hot path over one batch: the 2R frames resident in HBM (R rendered frames
 played forward then backward, so the planted persons move continuously and the tracker stays in
-steady state).  Timed span = the reference's own FPS span (detect + track,
+steady state; defaults R = 512, launch groups of 128 frames: the tracker tail of the last group of a
+call is not overlapped, so a longer pass amortises it -- 6505 / 6835 / 6997 frames/s at R = 128 / 256 / 512).
+Timed span = the reference's own FPS span (detect + track,
 src/aicamera_tracker.py:175,201-207): frames already in HBM -> track tuples on the host.
 
 One JSON line on rank 0.  `roofline`: the dominant kernel conv_igemm (MFMA implicit GEMM), achieved =
@@ -43,10 +45,10 @@ PEAK_F32_TFLOPS = 157.3
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=12)
-    p.add_argument("--warmup", type=int, default=3)
-    p.add_argument("--ring", type=int, default=128, help="rendered frames R; a step processes 2R frames")
-    p.add_argument("--batch", type=int, default=64, help="frames per detection/ReID launch group")
+    p.add_argument("--steps", type=int, default=6)
+    p.add_argument("--warmup", type=int, default=2)
+    p.add_argument("--ring", type=int, default=512, help="rendered frames R; a step processes 2R frames")
+    p.add_argument("--batch", type=int, default=128, help="frames per detection/ReID launch group")
     p.add_argument("--persons", type=int, default=30)
     p.add_argument("--width", type=int, default=1280)
     p.add_argument("--height", type=int, default=720)
