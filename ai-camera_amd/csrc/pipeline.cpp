@@ -256,9 +256,23 @@ struct Pipeline {
              float* det_scores, int32_t* det_labels) {
         AIC_REQUIRE(slot >= 0 && count >= 0 && slot + count <= prm.ring_frames, AIC_ERR_INVALID, "slot range outside the ring");
         dev->use();
-        const int nchunks = ceil_div(count, prm.batch);
-        if (!nchunks) return;
-        auto span = [&](int k) { return std::min(prm.batch, count - k * prm.batch); };
+        if (count <= 0) return;
+        // Launch groups: full batches, then the last batch tapered (1/2, 1/4, ... down to 16 frames): stage B of the
+        // final group cannot overlap any GPU work, so a short final group shortens the un-overlapped tail of the call.
+        std::vector<int> goff, glen;
+        {
+            static const bool taper = getenv("AICAM_NO_TAPER") == nullptr;
+            int done = 0;
+            while (count - done > prm.batch) { goff.push_back(done); glen.push_back(prm.batch); done += prm.batch; }
+            int rem = count - done;
+            while (taper && rem > 16) {
+                const int g = std::max(16, rem / 2);
+                if (rem - g < 8) break;
+                goff.push_back(done); glen.push_back(g); done += g; rem -= g;
+            }
+            if (rem > 0) { goff.push_back(done); glen.push_back(rem); }
+        }
+        const int nchunks = (int)goff.size();
         // Two host threads: the producer issues the detection/ReID launch groups (stage A, ~100 launches
         // per group), this thread walks the frames of each finished group through the tracker (stage B:
         // small launches + syncs). A chunk context is reissued only after stage B released it.
@@ -274,7 +288,7 @@ struct Pipeline {
                         std::unique_lock<std::mutex> lk(mu);
                         cv.wait(lk, [&] { return k < consumed + 2; });
                     }
-                    stage_a(ck[k & 1], slot + k * prm.batch, span(k));
+                    stage_a(ck[k & 1], slot + goff[k], glen[k]);
                     {
                         std::lock_guard<std::mutex> lk(mu);
                         issued = k + 1;
@@ -296,7 +310,7 @@ struct Pipeline {
                     cv.wait(lk, [&] { return issued > k; });
                     if (perr) break;
                 }
-                stage_b(ck[k & 1], k * prm.batch, n_tracks, tracks6, track_conf, n_dets, det_boxes, det_scores, det_labels);
+                stage_b(ck[k & 1], goff[k], n_tracks, tracks6, track_conf, n_dets, det_boxes, det_scores, det_labels);
                 {
                     std::lock_guard<std::mutex> lk(mu);
                     consumed = k + 1;
