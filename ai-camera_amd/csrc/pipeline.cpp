@@ -218,6 +218,19 @@ struct Pipeline {
         const double t1 = now();
         t_wait += t1 - t0;
         std::vector<uint8_t> has;
+        trk.defer_outputs = true;
+        auto emit = [&](int o) {               // the tracker's resolved outputs -> row o of the caller's arrays
+            const std::vector<TrackOut>& outs = trk.resolved;
+            if (n_tracks) n_tracks[o] = (int32_t)outs.size();
+            for (size_t k = 0; k < outs.size() && (int)k < prm.max_persons; ++k) {
+                const TrackOut& t = outs[k];
+                if (tracks6) {
+                    int32_t* r = tracks6 + ((size_t)o * prm.max_persons + k) * 6;
+                    r[0] = t.x1, r[1] = t.y1, r[2] = t.x2, r[3] = t.y2, r[4] = t.id, r[5] = t.cls;
+                }
+                if (track_conf) track_conf[(size_t)o * prm.max_persons + k] = t.conf;
+            }
+        };
         for (int f = 0; f < c.frames; ++f) {
             FrameDets& fd = c.dets[f];
             has.assign(fd.n, 1);
@@ -226,21 +239,15 @@ struct Pipeline {
             trk.update(fd.tlwh.data(), fd.conf.data(), fd.cls.data(), fd.n ? c.d_emb.p + (size_t)fd.crop0 * dim : nullptr,
                        AIC_DEVICE, has.data(), fd.n, dim, fd.n ? c.d_emb_n.p + (size_t)fd.crop0 * dim : nullptr);
             const int o = out_base + f;
-            if (n_tracks) n_tracks[o] = (int32_t)trk.outputs.size();
-            for (size_t k = 0; k < trk.outputs.size() && (int)k < prm.max_persons; ++k) {
-                const TrackOut& t = trk.outputs[k];
-                if (tracks6) {
-                    int32_t* r = tracks6 + ((size_t)o * prm.max_persons + k) * 6;
-                    r[0] = t.x1, r[1] = t.y1, r[2] = t.x2, r[3] = t.y2, r[4] = t.id, r[5] = t.cls;
-                }
-                if (track_conf) track_conf[(size_t)o * prm.max_persons + k] = t.conf;
-            }
+            if (f > 0) emit(o - 1);            // frame f-1's boxes came back behind frame f's cost-matrix sync
             if (n_dets) n_dets[o] = c.h_numdets.p[f];
             const size_t md = prm.max_det;
             if (det_boxes) std::copy(c.h_detboxes.p + f * md * 4, c.h_detboxes.p + (f + 1) * md * 4, det_boxes + (size_t)o * md * 4);
             if (det_scores) std::copy(c.h_scores.p + f * md, c.h_scores.p + (f + 1) * md, det_scores + (size_t)o * md);
             if (det_labels) std::copy(c.h_labels.p + f * md, c.h_labels.p + (f + 1) * md, det_labels + (size_t)o * md);
             if (f == c.frames - 1) {
+                trk.finish_outputs();          // also fences the chunk's embedding buffers before the producer reuses them
+                emit(o);
                 last_emb_n = fd.n;
                 last_emb.resize((size_t)fd.n * dim);
                 if (fd.n) {
@@ -248,6 +255,7 @@ struct Pipeline {
                 }
             }
         }
+        trk.defer_outputs = false;             // direct users of the tracker handle get synchronous outputs
         t_track += now() - t1;
         n_frames_done += c.frames;
     }

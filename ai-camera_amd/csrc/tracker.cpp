@@ -141,6 +141,24 @@ void Tracker::match(int T, int N, const float* app, const float* maha, const flo
 
 static inline int round_half_even(float v) { return (int)std::nearbyintf(v); }
 
+void Tracker::resolve_pending(bool need_sync) {
+    if (!pend.active) return;
+    if (need_sync) HIP_CHECK(hipStreamSynchronize(dev->s_trk));
+    resolved.clear();
+    const float* tl = h_tlwh2[pend.buf].p;
+    for (const OutMeta& m : pend.meta) {
+        const float* b = tl + (size_t)m.k * 4;
+        const float x1 = b[0], y1 = b[1];
+        const float w = b[2] > 0.f ? b[2] : 0.f, h = b[3] > 0.f ? b[3] : 0.f;
+        TrackOut o;
+        o.x1 = round_half_even(x1), o.y1 = round_half_even(y1);
+        o.x2 = round_half_even(x1 + w), o.y2 = round_half_even(y1 + h);
+        o.id = m.id, o.cls = m.cls, o.conf = m.conf;
+        resolved.push_back(o);
+    }
+    pend.active = false;
+}
+
 void Tracker::update(const float* det_tlwh, const float* conf, const int32_t* cls, const float* feat, int feat_mem,
                      const uint8_t* has_feat, int n, int dim_in, const float* feat_n) {
     dev->use();
@@ -216,10 +234,13 @@ void Tracker::update(const float* det_tlwh, const float* conf, const int32_t* cl
         }
         HIP_CHECK(hipMemcpyAsync(h_cost.p, d_cost.p, 3 * tn * 4, hipMemcpyDeviceToHost, s));
         HIP_CHECK(hipStreamSynchronize(s));
+        resolve_pending(false);                // the previous frame's box read-back was queued ahead of this sync
         std::copy(h_cost.p, h_cost.p + tn, last_app.begin());
         std::copy(h_cost.p + tn, h_cost.p + 2 * tn, last_maha.begin());
         std::copy(h_cost.p + 2 * tn, h_cost.p + 3 * tn, last_iou.begin());
     }
+
+    resolve_pending(true);                     // (no-op when the sync above already resolved it)
 
     // ---- host: association
     std::vector<std::pair<int, int>> matches;
@@ -286,9 +307,11 @@ void Tracker::update(const float* det_tlwh, const float* conf, const int32_t* cl
         const size_t words = (size_t)2 * M + 2 * U + 3 * A;
         const size_t xy_off = ((words * 4 + 15) / 16) * 16;
         const size_t bytes = xy_off + (size_t)n * 16;
-        h_stage.ensure(bytes);
-        d_stage.ensure(bytes);
-        int* hs = reinterpret_cast<int*>(h_stage.p);
+        PinBuf<char>& hst = defer_outputs ? h_stage2 : h_stage;
+        DevBuf<char>& dst = defer_outputs ? d_stage2 : d_stage;
+        hst.ensure(bytes);
+        dst.ensure(bytes);
+        int* hs = reinterpret_cast<int*>(hst.p);
         int* p = hs;
         std::copy(upd_slot.begin(), upd_slot.end(), p); p += M;
         std::copy(upd_det.begin(), upd_det.end(), p); p += M;
@@ -297,35 +320,49 @@ void Tracker::update(const float* det_tlwh, const float* conf, const int32_t* cl
         std::copy(ap_slot.begin(), ap_slot.end(), p); p += A;
         std::copy(ap_pos.begin(), ap_pos.end(), p); p += A;
         std::copy(ap_det.begin(), ap_det.end(), p); p += A;
-        std::memcpy(h_stage.p + xy_off, xyah.data(), (size_t)n * 16);
-        HIP_CHECK(hipMemcpyAsync(d_stage.p, h_stage.p, bytes, hipMemcpyHostToDevice, s));
-        const int* d = reinterpret_cast<const int*>(d_stage.p);
-        const float* d_xy = reinterpret_cast<const float*>(d_stage.p + xy_off);
+        std::memcpy(hst.p + xy_off, xyah.data(), (size_t)n * 16);
+        HIP_CHECK(hipMemcpyAsync(dst.p, hst.p, bytes, hipMemcpyHostToDevice, s));
+        const int* d = reinterpret_cast<const int*>(dst.p);
+        const float* d_xy = reinterpret_cast<const float*>(dst.p + xy_off);
         d_tlwh.ensure((size_t)std::max(M, 1) * 4);
-        h_tlwh.ensure((size_t)std::max(M, 1) * 4);
+        PinBuf<float>& htl = defer_outputs ? h_tlwh2[out_parity] : h_tlwh;
+        htl.ensure((size_t)std::max(M, 1) * 4);
         {
             Prof pr(*dev, PROF_TRK, s, 0, (double)(M + U) * 72 * 4 * 2 + (double)A * dim * 8);
             launch_trk_commit(d_mean.p, d_cov.p, d, M, U, A, d_xy, d_tlwh.p, d_gal_raw.p, d_gal_n.p, gmax, dim, d_featp, d_featn, s);
         }
-        if (M) HIP_CHECK(hipMemcpyAsync(h_tlwh.p, d_tlwh.p, (size_t)M * 16, hipMemcpyDeviceToHost, s));
-        HIP_CHECK(hipStreamSynchronize(s));
+        if (M) HIP_CHECK(hipMemcpyAsync(htl.p, d_tlwh.p, (size_t)M * 16, hipMemcpyDeviceToHost, s));
+        if (!defer_outputs) HIP_CHECK(hipStreamSynchronize(s));
     }
 
     // ---- outputs (deepsort_tracker.py:126-141), before pruning: indices still refer to `tracks`
-    outputs.clear();
+    std::vector<OutMeta> meta;
     for (int i = 0; i < T; ++i) {
         const TrackRec& t = tracks[i];
         if (t.state != TRK_CONFIRMED || t.tsu != 0) continue;
         const int k = match_index_of_track[i];
         if (k < 0) continue;
-        const float* b = h_tlwh.p + (size_t)k * 4;
-        const float x1 = b[0], y1 = b[1];
-        const float w = b[2] > 0.f ? b[2] : 0.f, h = b[3] > 0.f ? b[3] : 0.f;
-        TrackOut o;
-        o.x1 = round_half_even(x1), o.y1 = round_half_even(y1);
-        o.x2 = round_half_even(x1 + w), o.y2 = round_half_even(y1 + h);
-        o.id = t.id, o.cls = t.cls, o.conf = t.conf;
-        outputs.push_back(o);
+        meta.push_back(OutMeta{k, t.id, t.cls, t.conf});
+    }
+    auto build = [](const std::vector<OutMeta>& mt, const float* tl, std::vector<TrackOut>& out) {
+        out.clear();
+        for (const OutMeta& m : mt) {
+            const float* b = tl + (size_t)m.k * 4;
+            const float x1 = b[0], y1 = b[1];
+            const float w = b[2] > 0.f ? b[2] : 0.f, h = b[3] > 0.f ? b[3] : 0.f;
+            TrackOut o;
+            o.x1 = round_half_even(x1), o.y1 = round_half_even(y1);
+            o.x2 = round_half_even(x1 + w), o.y2 = round_half_even(y1 + h);
+            o.id = m.id, o.cls = m.cls, o.conf = m.conf;
+            out.push_back(o);
+        }
+    };
+    if (defer_outputs) {
+        pend.active = true, pend.buf = out_parity, pend.meta.swap(meta);
+        out_parity ^= 1;
+        outputs.clear();
+    } else {
+        build(meta, h_tlwh.p, outputs);
     }
     // ---- prune (tracker_core.py:75)
     std::vector<TrackRec> alive;

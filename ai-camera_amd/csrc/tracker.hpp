@@ -36,6 +36,18 @@ struct Tracker {
     PinBuf<float> h_cost;
     DevBuf<float> d_cost, d_detn, d_feat, d_tlwh;
     PinBuf<float> h_tlwh;
+    // Deferred outputs (the HBM-resident pipeline): update() does not wait for the commit kernel; the boxes of frame f
+    // are read back behind the cost-matrix sync of frame f+1 (same in-order stream), or by finish_outputs().
+    bool defer_outputs = false;
+    PinBuf<char> h_stage2;                 // phase-2 staging: may still be the source of a copy when the next frame starts
+    DevBuf<char> d_stage2;
+    PinBuf<float> h_tlwh2[2];
+    struct OutMeta { int k, id, cls; float conf; };
+    struct { bool active = false; int buf = 0; std::vector<OutMeta> meta; } pend;
+    int out_parity = 0;
+    std::vector<TrackOut> resolved;        // outputs of the most recently resolved frame
+    void resolve_pending(bool need_sync);
+    void finish_outputs() { resolve_pending(true); }
     // last frame
     std::vector<float> last_app, last_maha, last_iou;
     int last_t = 0, last_n = 0;
