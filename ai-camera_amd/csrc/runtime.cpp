@@ -1,6 +1,8 @@
 // runtime.cpp -- device contexts, error state, HIP-event profiling, library-level C ABI.
 #include "common.hpp"
 
+#include <cstdlib>
+
 namespace aic {
 
 static thread_local std::string g_last_error;
@@ -33,7 +35,12 @@ Device& device(int id) {
                     std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
         d->n_cu = prop.multiProcessorCount;
         HIP_CHECK(hipStreamCreateWithFlags(&d->s_main, hipStreamNonBlocking));
-        HIP_CHECK(hipStreamCreateWithFlags(&d->s_trk, hipStreamNonBlocking));
+        {   // the tracker chain is latency-critical: its small launches should win CU slots as soon as they free up
+            int lo = 0, hi = 0;
+            HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+            const bool prio = getenv("AICAM_NO_TRK_PRIO") == nullptr;
+            HIP_CHECK(hipStreamCreateWithPriority(&d->s_trk, hipStreamNonBlocking, prio ? hi : lo));
+        }
         HIP_CHECK(hipStreamCreateWithFlags(&d->s_det, hipStreamNonBlocking));
         HIP_CHECK(hipStreamCreateWithFlags(&d->s_reid, hipStreamNonBlocking));
         g_devs[id] = std::move(d);

@@ -214,12 +214,19 @@ void Tracker::update(const float* det_tlwh, const float* conf, const int32_t* cl
         std::memcpy(h_stage.p + off_tlwh, det_tlwh, (size_t)n * 16);
         std::memcpy(h_stage.p + off_xyah, xyah.data(), (size_t)n * 16);
         std::memcpy(h_stage.p + off_has, hf.data(), n);
-        HIP_CHECK(hipMemcpyAsync(d_stage.p, h_stage.p, stage_bytes, hipMemcpyHostToDevice, s));
-        const int* d_slots = reinterpret_cast<const int*>(d_stage.p + off_slots);
-        const int* d_glen = reinterpret_cast<const int*>(d_stage.p + off_glen);
-        const float* d_tl = reinterpret_cast<const float*>(d_stage.p + off_tlwh);
-        const float* d_xy = reinterpret_cast<const float*>(d_stage.p + off_xyah);
-        const unsigned char* d_has = reinterpret_cast<const unsigned char*>(d_stage.p + off_has);
+        // The per-frame parameter block (a few hundred bytes) is read by the kernels straight from pinned host memory:
+        // one PCIe read per wave instead of a blit launch on the critical chain (AICAM_TRK_COPY=1 restores the copy).
+        static const bool zero_copy = getenv("AICAM_TRK_COPY") == nullptr;
+        const char* pbase = h_stage.p;
+        if (!zero_copy) {
+            HIP_CHECK(hipMemcpyAsync(d_stage.p, h_stage.p, stage_bytes, hipMemcpyHostToDevice, s));
+            pbase = d_stage.p;
+        }
+        const int* d_slots = reinterpret_cast<const int*>(pbase + off_slots);
+        const int* d_glen = reinterpret_cast<const int*>(pbase + off_glen);
+        const float* d_tl = reinterpret_cast<const float*>(pbase + off_tlwh);
+        const float* d_xy = reinterpret_cast<const float*>(pbase + off_xyah);
+        const unsigned char* d_has = reinterpret_cast<const unsigned char*>(pbase + off_has);
         const size_t tn = (size_t)T * n;
         d_cost.ensure(3 * tn);
         h_cost.ensure(3 * tn);
@@ -321,17 +328,23 @@ void Tracker::update(const float* det_tlwh, const float* conf, const int32_t* cl
         std::copy(ap_pos.begin(), ap_pos.end(), p); p += A;
         std::copy(ap_det.begin(), ap_det.end(), p); p += A;
         std::memcpy(hst.p + xy_off, xyah.data(), (size_t)n * 16);
-        HIP_CHECK(hipMemcpyAsync(dst.p, hst.p, bytes, hipMemcpyHostToDevice, s));
-        const int* d = reinterpret_cast<const int*>(dst.p);
-        const float* d_xy = reinterpret_cast<const float*>(dst.p + xy_off);
+        static const bool zero_copy2 = getenv("AICAM_TRK_COPY") == nullptr;
+        const char* pbase2 = hst.p;
+        if (!zero_copy2) {
+            HIP_CHECK(hipMemcpyAsync(dst.p, hst.p, bytes, hipMemcpyHostToDevice, s));
+            pbase2 = dst.p;
+        }
+        const int* d = reinterpret_cast<const int*>(pbase2);
+        const float* d_xy = reinterpret_cast<const float*>(pbase2 + xy_off);
         d_tlwh.ensure((size_t)std::max(M, 1) * 4);
         PinBuf<float>& htl = defer_outputs ? h_tlwh2[out_parity] : h_tlwh;
         htl.ensure((size_t)std::max(M, 1) * 4);
         {
             Prof pr(*dev, PROF_TRK, s, 0, (double)(M + U) * 72 * 4 * 2 + (double)A * dim * 8);
-            launch_trk_commit(d_mean.p, d_cov.p, d, M, U, A, d_xy, d_tlwh.p, d_gal_raw.p, d_gal_n.p, gmax, dim, d_featp, d_featn, s);
+            launch_trk_commit(d_mean.p, d_cov.p, d, M, U, A, d_xy, zero_copy2 ? htl.p : d_tlwh.p, d_gal_raw.p, d_gal_n.p, gmax, dim,
+                              d_featp, d_featn, s);   // the boxes go straight to pinned host memory
         }
-        if (M) HIP_CHECK(hipMemcpyAsync(htl.p, d_tlwh.p, (size_t)M * 16, hipMemcpyDeviceToHost, s));
+        if (M && !zero_copy2) HIP_CHECK(hipMemcpyAsync(htl.p, d_tlwh.p, (size_t)M * 16, hipMemcpyDeviceToHost, s));
         if (!defer_outputs) HIP_CHECK(hipStreamSynchronize(s));
     }
 
