@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""HBM bytes per conv launch from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE: separate runs, as
+MI355X_MICROARCH.md prescribes) -> profiles/pmc_traffic.json (read by bench.py's roofline.traffic).
+  python tools/pmc_traffic.py <fetch_dir> <write_dir> "<method note>" """
+import csv, glob, json, os, sys
+
+CONV = ("conv_igemm_dma_kernel", "conv3x3_patch_kernel", "conv_igemm_pp_kernel", "conv3x3_pp_patch_kernel", "conv_igemm_kernel")
+
+
+def per_launch(d, counter):
+    f = glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))[0]
+    tot, n = 0.0, 0
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] == counter and any(k in r["Kernel_Name"] for k in CONV):
+            tot += float(r["Counter_Value"])
+            n += 1
+    return tot / max(n, 1), n
+
+
+fetch_kib, n1 = per_launch(sys.argv[1], "FETCH_SIZE")
+write_kib, n2 = per_launch(sys.argv[2], "WRITE_SIZE")
+out = {
+    "kernel": "conv class of bench.py: conv_igemm_dma / conv_igemm_pp / conv3x3_pp_patch / conv3x3_patch kernels",
+    "launches_sampled": n1,
+    "fetch_bytes_per_launch_raw": fetch_kib * 1024,
+    "fetch_bytes_per_launch_corrected_x2": fetch_kib * 2048,
+    "write_bytes_per_launch": write_kib * 1024,
+    "hbm_bytes_per_launch": fetch_kib * 2048 + write_kib * 1024,
+    "method": sys.argv[3],
+}
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for name in ("pmc_traffic.json", "r01_pmc_traffic.json"):
+    json.dump(out, open(os.path.join(root, "profiles", name), "w"), indent=1)
+print(json.dumps(out, indent=1))

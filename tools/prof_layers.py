@@ -34,7 +34,7 @@ def main(d, frames=16, crops=480, top=30, fused_stem=1):
     print(f"{'kernel':42s} {'calls':>7s} {'total ms':>9s} {'%':>6s} {'avg us':>8s}")
     for n, (c, us) in sorted(tot.items(), key=lambda kv: -kv[1][1])[:24]:
         print(f"{n[:42]:42s} {c:7d} {us / 1e3:9.2f} {100 * us / all_us:6.1f} {us / c:8.1f}")
-    conv = [r for r in rows if "conv_igemm" in r["Kernel_Name"] or "conv3x3_patch" in r["Kernel_Name"]]
+    conv = [r for r in rows if any(k in r["Kernel_Name"] for k in ("conv_igemm", "conv3x3_patch", "conv3x3_pp_patch"))]
     layers = []
     for name, g, n in (("yolo", ef.build_yolov8("n", calibrate=False), frames), ("reid", ef.build_reid(calibrate=False), crops)):
         for o in g.ops:
@@ -44,9 +44,15 @@ def main(d, frames=16, crops=480, top=30, fused_stem=1):
     per = len(layers)
     groups = len(conv) // per
     conv = conv[len(conv) - groups * per:]
+    # launch groups may differ in size (the last batch of a call is tapered): keep the groups of the modal (full) size
+    gkey = [int(conv[g * per].get("Grid_Size_X", conv[g * per].get("Grid_Size", 0))) for g in range(groups)]
+    modal = collections.Counter(gkey).most_common(1)[0][0]
     dur = [[] for _ in range(per)]
     for i, r in enumerate(conv):
+        if gkey[i // per] != modal:
+            continue
         dur[i % per].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    groups = sum(1 for k in gkey if k == modal)
     out = []
     for (name, ln, m, co, k), ts in zip(layers, dur):
         t = statistics.median(ts)
