@@ -1165,6 +1165,128 @@ static bool try_pp_patch(const ConvArgs& a, hipStream_t s) {
     return false;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Direct 3x3 (pad 1, stride 1 or 2) for 16 input channels, fp16, SiLU: YOLOv8n's P1/P2 layers (1.conv, 2.c2f.m0.cv1/cv2).
+// Through the implicit GEMM these run 3-4x above their HBM floor: K = 144 straddles taps inside a K-step (generic
+// gather path, ~12 VALU per 16-byte LDS-DMA) and every input pixel is fetched 9 times for 16-32 output channels.
+// Here a block owns 8 x 32 output pixels of one image: the input patch is read once into LDS, the weights (<= 9 KB)
+// live in registers as MFMA A fragments, K is the natural (tap, 16 ch) order so one v_mfma_f32_16x16x32_f16 eats
+// two taps and the B fragment of a lane is ONE aligned 16-byte ds_read (its tap's channel half).
+// LDS entry (row, column parity p, channel half h, column c2) = 16 bytes; for stride 2 even and odd input columns
+// are kept apart so that 16 consecutive output pixels read 16 consecutive entries (conflict-free).
+template <int COUT, int S>
+__global__ __launch_bounds__(256) void conv3x3_c16_kernel(const ConvArgs a, int tiles_x, int tiles_y) {
+    constexpr int TH = 8, TW = 32, NCT = COUT / 16;
+    constexpr int PR = (TH - 1) * S + 3, PC = (TW - 1) * S + 3;
+    constexpr int NPAR = S, PCP = (PC + NPAR - 1) / NPAR;
+    static_assert((S == 1 || S == 2) && (COUT == 16 || COUT == 32), "variants");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, r = lane & 15, q = lane >> 4;
+    int bx = blockIdx.x;
+    const int tx = bx % tiles_x; bx /= tiles_x;
+    const int ty = bx % tiles_y;
+    const int img = bx / tiles_y;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
+    const half_t* xg = reinterpret_cast<const half_t*>(a.x) + (size_t)img * a.H * a.W * a.x_cs + a.x_coff;
+
+    for (int idx = t; idx < PR * PC * 2; idx += 256) {
+        const int h = idx & 1, pp = idx >> 1;
+        const int pr = pp / PC, pc = pp - pr * PC;
+        const int iy = iy0 + pr, ix = ix0 + pc;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
+            v = *reinterpret_cast<const uint4*>(xg + ((size_t)iy * a.W + ix) * a.x_cs + h * 8);
+        const int par = pc % NPAR, c2 = pc / NPAR;
+        *reinterpret_cast<uint4*>(smem + (((pr * NPAR + par) * 2 + h) * PCP + c2) * 16) = v;
+    }
+
+    // A fragments: MFMA m covers K = 32m .. 32m+31 = taps 2m, 2m+1 x 16 channels (Kp = 160: k >= 144 are zero rows)
+    const half_t* wg = reinterpret_cast<const half_t*>(a.w);
+    half8 wa[NCT][5];
+    floatx4 bi[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+        const half_t* wr = wg + (size_t)perm_row<NCT>(ct, r) * a.Kp + 8 * q;
+#pragma unroll
+        for (int m = 0; m < 5; ++m) wa[ct][m] = *reinterpret_cast<const half8*>(wr + 32 * m);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bi[ct][e] = a.bias[perm_ch<NCT>(ct, q, e)];
+    }
+    int d[5];                                  // LDS offset of this lane's (tap, channel half) relative to its output pixel
+#pragma unroll
+    for (int m = 0; m < 5; ++m) {
+        const int tap = min(2 * m + (q >> 1), 8), kh = tap / 3, kw = tap - 3 * kh, h = q & 1;
+        d[m] = (((kh * NPAR + kw % NPAR) * 2 + h) * PCP + kw / NPAR) * 16;
+    }
+    __syncthreads();
+
+    half_t* yg = reinterpret_cast<half_t*>(a.y);
+    const half_t* rg = reinterpret_cast<const half_t*>(a.res);
+#pragma unroll
+    for (int tile = 0; tile < 4; ++tile) {
+        const int oyl = 2 * wv + (tile >> 1), oxl = (tile & 1) * 16 + r;
+        const int base = (oyl * S * NPAR * 2 * PCP + oxl) * 16;
+        half8 xb[5];
+#pragma unroll
+        for (int m = 0; m < 5; ++m) xb[m] = *reinterpret_cast<const half8*>(smem + base + d[m]);
+        const size_t pix = ((size_t)img * a.Ho + oy0 + oyl) * a.Wo + ox0 + oxl;
+        float v[NCT][4];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+            floatx4 acc = bi[ct];
+#pragma unroll
+            for (int m = 0; m < 5; ++m) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[ct][m], xb[m], acc, 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[ct][e] = act_fast<1>(acc[e]);
+        }
+        if constexpr (NCT == 1) {
+            const int ch = 4 * q;
+            if (a.res_mode == 2) {
+                const half4 h = *reinterpret_cast<const half4*>(rg + pix * a.r_cs + a.r_coff + ch);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[0][e] += (float)h[e];
+            }
+            const half4 o = {(half_t)v[0][0], (half_t)v[0][1], (half_t)v[0][2], (half_t)v[0][3]};
+            *reinterpret_cast<half4*>(yg + pix * a.y_cs + a.y_coff + ch) = o;
+        } else {
+            const int ch = 8 * q;                                       // perm_ch<2>: tiles 0, 1 -> channels 8q + 4*(ct) + e
+            if (a.res_mode == 2) {
+                const half8 h = *reinterpret_cast<const half8*>(rg + pix * a.r_cs + a.r_coff + ch);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e >> 2][e & 3] += (float)h[e];
+            }
+            const half8 o = {(half_t)v[0][0], (half_t)v[0][1], (half_t)v[0][2], (half_t)v[0][3],
+                             (half_t)v[1][0], (half_t)v[1][1], (half_t)v[1][2], (half_t)v[1][3]};
+            *reinterpret_cast<half8*>(yg + pix * a.y_cs + a.y_coff + ch) = o;
+        }
+    }
+}
+
+template <int COUT, int S>
+static void launch_c16(const ConvArgs& a, hipStream_t s) {
+    constexpr int PR = 7 * S + 3, PC = 31 * S + 3, PCP = (PC + S - 1) / S;
+    constexpr size_t lds = (size_t)PR * S * 2 * PCP * 16;
+    const int tiles_x = a.Wo / 32, tiles_y = a.Ho / 8, n_img = a.M / (a.Ho * a.Wo);
+    hipLaunchKernelGGL((conv3x3_c16_kernel<COUT, S>), dim3(n_img * tiles_x * tiles_y), dim3(256), lds, s, a, tiles_x, tiles_y);
+    KCHECK();
+}
+
+static bool try_c16(const ConvArgs& a, hipStream_t s) {
+    static const bool off = getenv("AICAM_NO_C16") != nullptr;
+    if (off || a.KH != 3 || a.KW != 3 || a.pad != 1 || a.Cin != 16 || a.act != 1 || a.out_f32 || (a.res_mode != 0 && a.res_mode != 2)) return false;
+    if (a.Wo % 32 || a.Ho % 8 || a.Kp != 160 || (a.x_cs | a.x_coff | a.y_cs | a.y_coff | a.r_cs | a.r_coff) % 8) return false;
+    if (a.stride == 1 && (a.Ho != a.H || a.Wo != a.W)) return false;
+    if (a.stride == 2 && (a.Ho != (a.H + 1) / 2 || a.Wo != (a.W + 1) / 2)) return false;
+    if (a.Cout == 16 && a.stride == 1) launch_c16<16, 1>(a, s);
+    else if (a.Cout == 32 && a.stride == 2) launch_c16<32, 2>(a, s);
+    else if (a.Cout == 16 && a.stride == 2) launch_c16<16, 2>(a, s);
+    else if (a.Cout == 32 && a.stride == 1) launch_c16<32, 1>(a, s);
+    else return false;
+    return true;
+}
+
 static int conv_impl() {   // AICAM_CONV=v1 selects the register-staged kernel (A/B and fallback)
     static int v = [] { const char* e = getenv("AICAM_CONV"); return (e && e[0] == 'v' && e[1] == '1') ? 1 : 2; }();
     return v;
@@ -1419,6 +1541,7 @@ static void launch_conv_t(const ConvArgs& a, hipStream_t s) {
 
 void launch_conv_igemm(int dtype, const ConvArgs& a, hipStream_t s) {
     if (a.M <= 0) return;
+    if (dtype == AIC_F16 && try_c16(a, s)) return;
     if (dtype == AIC_F16) launch_conv_t<half_t>(a, s);
     else launch_conv_t<float>(a, s);
 }
