@@ -220,6 +220,35 @@ void Model::run(int n, hipStream_t s) {
     }
 }
 
+void Model::run_frames(const uint8_t* frames, int n, const LetterboxGeom& g, hipStream_t s) {
+    AIC_REQUIRE(n >= 0 && n <= max_items, AIC_ERR_CAPACITY, "batch exceeds the engine's max_items");
+    if (n == 0) return;
+    static const bool no_fuse = getenv("AICAM_NO_FUSE_LB") != nullptr;
+    const int* v = ops[0].v;
+    const bool stem = kind == KIND_YOLO && dtype == AIC_F16 && !no_fuse && ops[0].fuse == 0 && v[0] == OP_CONV && v[1] == 0 && v[2] == 0 &&
+                      v[3] == 3 && v[6] == 16 && v[7] == 3 && v[8] == 3 && v[9] == 2 && v[10] == 1 && v[11] == 1 && v[14] == 0 &&
+                      !(lead_ops > 0 && sub_items > 0);
+    if (stem) {
+        const ConvWeights& w = weights[v[15]];
+        const BufDesc& db = bufs[v[4]];
+        bool ok;
+        {
+            Prof pr(*dev, PROF_LETTERBOX, s, 2.0 * n * db.h * db.w * 16.0 * 27.0,
+                    (double)n * ((double)g.src_h * g.src_w * 3 + (double)db.h * db.w * 32.0));
+            ok = launch_yolo_stem_fused(frames, n, g, w.w.p, w.bias.p, w.Kp, db.p, db.c, v[5], db.h, db.w, s);
+        }
+        if (ok) {
+            run_range(1, ops.size(), 0, n, s);
+            return;
+        }
+    }
+    {
+        Prof pr(*dev, PROF_LETTERBOX, s, 0, (double)n * ((double)g.src_h * g.src_w * 3 + 16.0 * in_h * in_w));
+        launch_letterbox(frames, n, g, 1, dtype, input(), s);
+    }
+    run(n, s);
+}
+
 void Model::run_range(size_t op0, size_t op1, int i0, int n, hipStream_t s) {
     auto at = [&](const BufDesc& b) { return static_cast<char*>(b.p) + (size_t)i0 * b.per_item; };
     // HIP-event timing of the conv kernel brackets RUNS of consecutive conv launches (one event pair per
@@ -533,11 +562,7 @@ int aic_detect(aic_model* mm, const uint8_t* frames, int batch, int h, int w, in
         hipStream_t s = m.dev->s_main;
         const uint8_t* df = stage_frames(m, frames, (size_t)batch * h * w * 3, mem, s);
         const LetterboxGeom g = letterbox_geometry(h, w, m.in_h, m.in_w);
-        {
-            Prof pr(*m.dev, PROF_LETTERBOX, s, 0, (double)batch * ((double)h * w * 3 + 16.0 * m.in_h * m.in_w));
-            launch_letterbox(df, batch, g, 1, m.dtype, m.input(), s);
-        }
-        m.run(batch, s);
+        m.run_frames(df, batch, g, s);
         m.decode_nms(batch, conf, iou, max_det, &g, s);
         copy_out(num_dets, m.d_numdets.p, (size_t)batch * 4, AIC_HOST, s);
         copy_out(boxes, m.d_out_boxes_orig.p, (size_t)batch * max_det * 16, AIC_HOST, s);

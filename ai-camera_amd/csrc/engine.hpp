@@ -38,6 +38,8 @@ struct Model {
     Model(Device& d, const void* blob, size_t nbytes, int dtype_, int max_items_);
     void* input() { return bufs[0].p; }
     void run(int n_items, hipStream_t s);
+    // u8 BGR frames -> letterbox -> the whole graph; fp16 YOLO engines fuse the letterbox into the stem conv
+    void run_frames(const uint8_t* frames, int n, const LetterboxGeom& g, hipStream_t s);
     void run_range(size_t op0, size_t op1, int i0, int n, hipStream_t s);
     size_t lead_ops = 0;   // leading ops whose activations are large: run in sub-batches (Infinity-Cache residency)
     int sub_items = 0;

@@ -27,6 +27,11 @@ struct ConvArgs {
 // dtype: AIC_F16 or AIC_F32 (type of x / w / res and, unless out_f32, y)
 void launch_conv_igemm(int dtype, const ConvArgs& a, hipStream_t s);
 
+// letterbox + conv 3x3/2 (3->16) + SiLU fused (fp16 YOLOv8 stem); false = geometry not supported, nothing launched
+struct LetterboxGeom;
+bool launch_yolo_stem_fused(const uint8_t* frames, int n, const LetterboxGeom& g, const void* w, const float* bias, int Kp, void* y,
+                            int y_cs, int y_coff, int Ho, int Wo, hipStream_t s);
+
 // conv 3x3/1 (3->64) + ReLU + max-pool 3x3/2 fused (fp16, W == 64, H % 8 == 0): ReID stem
 void launch_reid_stem_pool(const void* x, const void* w, const float* bias, void* y, int n, int H, int W, int Kp, int y_cs,
                            int y_coff, hipStream_t s);

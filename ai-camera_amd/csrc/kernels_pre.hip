@@ -136,6 +136,99 @@ __global__ void letterbox_kernel(const uint8_t* __restrict__ frames, int n, Lett
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fused letterbox + YOLOv8 stem (conv 3x3 / stride 2, 3 -> 16, SiLU), fp16.  Unfused, the letterbox writes a
+// 6.5 MB NHWC8 canvas per frame that the stem reads straight back (the two are 6 % of the per-frame GPU time, both
+// HBM-bound); here a block owns 8 x 32 output pixels: the 17 x 65 letterboxed input pixels it needs are resampled
+// from the u8 frame with the very arithmetic of letterbox_kernel (sample_px, /255 in fp32, fp16 rounding) into LDS
+// as RGB0, even and odd columns apart (stride 2: 16 consecutive outputs read 16 consecutive entries), and the
+// convolution runs on the matrix cores exactly like the ReID stem: K = (tap, RGB0), taps 0..7 in one
+// v_mfma_f32_16x16x32_f16, tap 8 in a second one, bias as the accumulator's initial value.
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+typedef float floatx4_t __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void yolo_stem_fused_kernel(const uint8_t* __restrict__ frames, LetterboxGeom g,
+                                                              const half_t* __restrict__ w, const float* __restrict__ bias, int Kp,
+                                                              half_t* __restrict__ y, int y_cs, int y_coff, int Ho, int Wo, int tiles_x,
+                                                              int tiles_y) {
+    constexpr int TH = 8, TW = 32, PR = 2 * TH + 1, PC = 2 * TW + 1, PCP = (PC + 1) / 2;
+    __shared__ uint2 patch[PR * 2 * PCP];      // entry (row, column parity, column / 2)
+
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, r = lane & 15, q = lane >> 4;
+    int bx = blockIdx.x;
+    const int tx = bx % tiles_x; bx /= tiles_x;
+    const int ty = bx % tiles_y;
+    const int img = bx / tiles_y;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int Y0 = 2 * oy0 - 1, X0 = 2 * ox0 - 1;
+    const uint8_t* f = frames + (size_t)img * g.src_h * g.src_w * 3;
+    const bool area2 = is_area2(g.src_w, g.src_h, g.unpad_w, g.unpad_h);
+    const double sx = 1.0 / ((double)g.unpad_w / (double)g.src_w);
+    const double sy = 1.0 / ((double)g.unpad_h / (double)g.src_h);
+
+    for (int idx = t; idx < PR * PC; idx += 256) {
+        const int pr = idx / PC, pc = idx - pr * PC;
+        const int Y = Y0 + pr, X = X0 + pc;
+        uint2 v = make_uint2(0u, 0u);                                  // the convolution's zero padding
+        if ((unsigned)Y < (unsigned)g.out_h && (unsigned)X < (unsigned)g.out_w) {
+            int px[3] = {114, 114, 114};
+            const int yy = Y - g.top, xx = X - g.left;
+            if (yy >= 0 && yy < g.unpad_h && xx >= 0 && xx < g.unpad_w)
+                sample_px(f, g.src_w * 3, 0, 0, g.src_w, g.src_h, xx, yy, g.unpad_w, g.unpad_h, area2, sx, sy, px);
+            const half4_t h = {(half_t)((float)px[2] / 255.0f), (half_t)((float)px[1] / 255.0f), (half_t)((float)px[0] / 255.0f), (half_t)0.f};
+            v = __builtin_bit_cast(uint2, h);
+        }
+        patch[(pr * 2 + (pc & 1)) * PCP + (pc >> 1)] = v;
+    }
+
+    half8 wa, wb;
+    floatx4_t bi;
+    {
+        const half_t* wr = w + (size_t)r * Kp;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int tap = 2 * q + (j >> 2), ci = j & 3;
+            wa[j] = ci < 3 ? wr[tap * 8 + ci] : (half_t)0.f;
+            wb[j] = (q == 0 && j < 3) ? wr[8 * 8 + j] : (half_t)0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bi[e] = bias[4 * q + e];
+    }
+    auto tap_off = [](int tap) { const int kh = tap / 3, kw = tap - 3 * kh; return (kh * 2 + (kw & 1)) * PCP + (kw >> 1); };
+    const int off0 = tap_off(2 * q), off1 = tap_off(2 * q + 1), off2 = tap_off(8);
+    __syncthreads();
+
+#pragma unroll
+    for (int tile = 0; tile < 4; ++tile) {
+        const int oyl = 2 * wv + (tile >> 1), oxl = (tile & 1) * 16 + r;
+        const int base = oyl * 4 * PCP + oxl;
+        const uint2 x0 = patch[base + off0], x1 = patch[base + off1], x2 = patch[base + off2];
+        const uint4 xa4 = make_uint4(x0.x, x0.y, x1.x, x1.y), xb4 = make_uint4(x2.x, x2.y, 0u, 0u);
+        floatx4_t acc = bi;
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa, __builtin_bit_cast(half8, xa4), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb, __builtin_bit_cast(half8, xb4), acc, 0, 0, 0);
+        half4_t o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {   // SiLU = v * sigmoid(v), same form as the conv epilogue (v_exp_f32 + v_rcp_f32)
+            const float v = acc[e];
+            o[e] = (half_t)(v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f)));
+        }
+        const size_t pix = ((size_t)img * Ho + oy0 + oyl) * Wo + ox0 + oxl;
+        *reinterpret_cast<half4_t*>(y + pix * y_cs + y_coff + 4 * q) = o;
+    }
+}
+
+bool launch_yolo_stem_fused(const uint8_t* frames, int n, const LetterboxGeom& g, const void* w, const float* bias, int Kp, void* y,
+                            int y_cs, int y_coff, int Ho, int Wo, hipStream_t s) {
+    if (n <= 0) return true;
+    if (Ho % 8 || Wo % 32 || Ho * 2 != g.out_h || Wo * 2 != g.out_w || (y_cs | y_coff) % 4) return false;
+    const int tiles_x = Wo / 32, tiles_y = Ho / 8;
+    hipLaunchKernelGGL(yolo_stem_fused_kernel, dim3(n * tiles_x * tiles_y), dim3(256), 0, s, frames, g, reinterpret_cast<const half_t*>(w),
+                       bias, Kp, reinterpret_cast<half_t*>(y), y_cs, y_coff, Ho, Wo, tiles_x, tiles_y);
+    KCHECK();
+    return true;
+}
+
 // One block = 16 output rows of one crop. The tap tables (fp64 coordinate math of the cv2 spec) are
 // computed once per block into LDS -- 64 + 16 entries instead of once per output pixel.
 template <typename T>

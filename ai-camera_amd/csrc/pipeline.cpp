@@ -145,11 +145,7 @@ struct Pipeline {
             if (split_streams) HIP_CHECK(hipStreamWaitEvent(dev->s_reid, ev_copy[ci], 0));
         }
         const uint8_t* f0 = ring.p + (size_t)slot * frame_bytes;
-        {
-            Prof pr(*dev, PROF_LETTERBOX, s, 0, (double)frames * ((double)frame_bytes + 16.0 * yolo->in_h * yolo->in_w));
-            launch_letterbox(f0, frames, geom, 1, yolo->dtype, yolo->input(), s);
-        }
-        yolo->run(frames, s);
+        yolo->run_frames(f0, frames, geom, s);
         // decode + NMS + read-back on the side stream: a few latency-bound blocks that overlap the
         // (CU-filling) ReID launch group instead of serialising the main stream
         hipStream_t sd = dev->s_det;
