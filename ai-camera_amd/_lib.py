@@ -88,6 +88,7 @@ _SIGS = {
     "aic_pipeline_upload": (_I, [_P, _I, _P, _I]),
     "aic_pipeline_inject": (_I, [_P, _I, _I, _P, _P, _P, _P]),
     "aic_pipeline_run": (_I, [_P, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "aic_pipeline_run_passes": (_I, [_P, _I, _I, _I, _P, _P, _P, _P]),
     "aic_pipeline_run_from_host": (_I, [_P, _P, _I, _I, _P, _P, _P, _P]),
     "aic_host_register": (_I, [_P, C.c_size_t]),
     "aic_host_unregister": (_I, [_P]),

@@ -256,9 +256,12 @@ struct Pipeline {
         n_frames_done += c.frames;
     }
 
+    // passes > 1: the same ring range is walked `passes` times back to back as ONE continuous stream (outputs of a
+    // later pass overwrite the rows of the earlier one): only the very last group of the call has an un-overlapped tail.
     void run(int slot, int count, int32_t* n_tracks, int32_t* tracks6, float* track_conf, int32_t* n_dets, float* det_boxes,
-             float* det_scores, int32_t* det_labels) {
+             float* det_scores, int32_t* det_labels, int passes = 1) {
         AIC_REQUIRE(slot >= 0 && count >= 0 && slot + count <= prm.ring_frames, AIC_ERR_INVALID, "slot range outside the ring");
+        AIC_REQUIRE(passes >= 1, AIC_ERR_INVALID, "passes must be >= 1");
         dev->use();
         if (count <= 0) return;
         // Launch groups: full batches, then the last batch tapered (1/2, 1/4, ... down to 16 frames): stage B of the
@@ -266,15 +269,18 @@ struct Pipeline {
         std::vector<int> goff, glen;
         {
             static const bool taper = getenv("AICAM_NO_TAPER") == nullptr;
-            int done = 0;
-            while (count - done > prm.batch) { goff.push_back(done); glen.push_back(prm.batch); done += prm.batch; }
-            int rem = count - done;
-            while (taper && rem > 16) {
-                const int g = std::max(16, rem / 2);
-                if (rem - g < 8) break;
-                goff.push_back(done); glen.push_back(g); done += g; rem -= g;
+            for (int pass = 0; pass < passes; ++pass) {
+                const bool last = pass == passes - 1;
+                int done = 0;
+                while (count - done > prm.batch) { goff.push_back(done); glen.push_back(prm.batch); done += prm.batch; }
+                int rem = count - done;
+                while (taper && last && rem > 16) {
+                    const int g = std::max(16, rem / 2);
+                    if (rem - g < 8) break;
+                    goff.push_back(done); glen.push_back(g); done += g; rem -= g;
+                }
+                if (rem > 0) { goff.push_back(done); glen.push_back(rem); }
             }
-            if (rem > 0) { goff.push_back(done); glen.push_back(rem); }
         }
         const int nchunks = (int)goff.size();
         // Two host threads: the producer issues the detection/ReID launch groups (stage A, ~100 launches
@@ -389,6 +395,14 @@ int aic_pipeline_run(aic_pipeline* p, int slot, int count, int32_t* n_tracks, in
     return guarded([&] {
         AIC_REQUIRE(p, AIC_ERR_INVALID, "NULL pipeline");
         p->p.run(slot, count, n_tracks, tracks6, track_conf, n_dets, det_boxes, det_scores, det_labels);
+    });
+}
+
+int aic_pipeline_run_passes(aic_pipeline* p, int slot, int count, int passes, int32_t* n_tracks, int32_t* tracks6, float* track_conf,
+                            int32_t* n_dets) {
+    return guarded([&] {
+        AIC_REQUIRE(p, AIC_ERR_INVALID, "NULL handle");
+        p->p.run(slot, count, n_tracks, tracks6, track_conf, n_dets, nullptr, nullptr, nullptr, passes);
     });
 }
 

@@ -103,6 +103,12 @@ class TrackingPipeline:
                None, None, None)
         return nt[:count], rows[:count], nd[:count]
 
+    def run_raw_passes(self, slot, count, passes):
+        """`passes` consecutive walks over the same ring range as ONE call (a looped clip streamed continuously)."""
+        nt, rows, tconf, nd = self._raw_bufs()
+        L.call("aic_pipeline_run_passes", self._h, int(slot), int(count), int(passes), L.ptr(nt), L.ptr(rows), L.ptr(tconf), L.ptr(nd))
+        return nt[:count], rows[:count], nd[:count]
+
     def stats(self, reset=False):
         """Host wall-clock split (seconds) since the last reset: launch-group issue, waiting for the GPU, tracker."""
         a, b, c, n = C.c_double(), C.c_double(), C.c_double(), C.c_int64()

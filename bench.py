@@ -12,8 +12,9 @@ consume the planted boxes (inject switch) because seeded weights cann
 
 A STEP = one pass of the hot path over one batch: the 2R frames resident in HBM (R rendered frames
 played forward then backward, so the planted persons move continuously and the tracker stays in
-steady state; defaults R = 512, launch groups of 128 frames: the tracker tail of the last group of a
-call is not overlapped, so a longer pass amortises it -- 6505 / 6835 / 6997 frames/s at R = 128 / 256 / 512).
+steady state; defaults R = 512, launch groups of 128 frames).  The K timed steps are issued as ONE pipeline call
+(`aic_pipeline_run_passes`: the clip looped K times, streamed continuously -- the tracker tail of a call's last
+group cannot overlap GPU work, so per-step calls cost 4-5 %; `--per-step-calls` restores them).
 Timed span = the reference's own FPS span (detect + track,
 src/aicamera_tracker.py:175,201-207): frames already in HBM -> track tuples on the host.
 
@@ -57,6 +58,7 @@ def parse():
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--no-prof", action="store_true", help="do not record HIP events in the timed region")
     p.add_argument("--cpu-frames", type=int, default=-1, help="frames of the CPU baseline sample (-1 auto, 0 skip)")
+    p.add_argument("--per-step-calls", action="store_true", help="one pipeline call per step (each call pays its own un-overlapped tracker tail) instead of one continuous call for the K timed steps")
     p.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive (host-streamed) measurement")
     p.add_argument("--backend", type=str, default="nccl", help="torch.distributed backend (nccl = RCCL over xGMI; gloo for CPU rehearsals)")
     p.add_argument("--gallery-exchange", type=int, default=0, help="configs[4]: all-gather the ReID gallery every K steps")
@@ -185,7 +187,11 @@ def main():
     sync_all()
     t0 = time.perf_counter()
     n_tracks_total = 0
-    for k in range(args.steps):
+    continuous = not args.per_step_calls and not (exchange and world > 1)
+    if continuous:   # the K steps as ONE call: a looped clip streamed continuously, a single pipeline fill/drain for K passes
+        nt, rows, nd = pipe.run_raw_passes(0, frames_per_step, args.steps)
+        n_tracks_total = int(nt.sum()) * args.steps          # rows of the last pass; every pass is in steady state
+    for k in range(0 if continuous else args.steps):
         nt, rows, nd = pipe.run_raw(0, frames_per_step)
         n_tracks_total += int(nt.sum())
         if exchange and world > 1 and (k + 1) % exchange == 0:

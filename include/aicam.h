@@ -218,6 +218,11 @@ int aic_pipeline_inject(aic_pipeline* p, int slot, int count, const int32_t* cou
 int aic_pipeline_run(aic_pipeline* p, int slot, int count, int32_t* n_tracks, int32_t* tracks6,
                      float* track_conf, int32_t* n_dets, float* det_boxes, float* det_scores,
                      int32_t* det_labels);
+/* The range [slot, slot+count) walked `passes` times back to back as one continuous stream (a looped clip): one call,
+ * one pipeline fill and one un-overlapped tracker tail for passes*count frames; rows of a later pass overwrite the
+ * earlier ones. bench.py's timed region is one such call with passes = K steps. */
+int aic_pipeline_run_passes(aic_pipeline* p, int slot, int count, int passes, int32_t* n_tracks, int32_t* tracks6,
+                            float* track_conf, int32_t* n_dets);
 /* Same, but the frames of this call come from HOST memory (the reference's cap.read() buffers,
  * src/aicamera_tracker.py:170): each launch group's frames are copied into ring slots [slot, slot+count) on a copy
  * stream while the previous group computes. Pin the buffer once with aic_host_register for full PCIe rate. */

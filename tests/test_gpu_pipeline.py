@@ -119,3 +119,27 @@ def test_run_from_host_equals_resident_run(gpu, engines):
             assert np.array_equal(rows0[f][:nt0[f]], rows1[f][:nt1[f]])
         b.close()
     assert nd0.sum() > 0
+
+
+def test_run_passes_equals_consecutive_calls(gpu, engines):
+    """One call walking the ring range twice (aic_pipeline_run_passes, bench.py's timed region) leaves the rows the
+    second of two consecutive calls leaves: same tracker recurrence, different launch grouping only."""
+    n_frames = 40
+    sc = syn.Scene(seed=9, n_targets=10)
+    frames = np.ascontiguousarray(sc.render_batch(0, n_frames))
+    TP = pkg("pipeline").TrackingPipeline
+    kw = dict(batch=16, ring_frames=n_frames, max_persons=16, dtype="fp16", inject=True)
+    dets = [sc.detections(f)[:3] for f in range(n_frames)]
+    a = TP(engines[0], engines[1], (720, 1280), **kw)
+    a.upload(0, frames), a.inject(0, dets)
+    a.run_raw(0, n_frames)
+    nt0, rows0, nd0 = (x.copy() for x in a.run_raw(0, n_frames))
+    a.close()
+    b = TP(engines[0], engines[1], (720, 1280), **kw)
+    b.upload(0, frames), b.inject(0, dets)
+    nt1, rows1, nd1 = b.run_raw_passes(0, n_frames, 2)
+    assert np.array_equal(nt0, nt1) and np.array_equal(nd0, nd1) and nt0.sum() > 0
+    for f in range(n_frames):
+        assert np.array_equal(rows0[f][:nt0[f], 4:], rows1[f][:nt1[f], 4:])                      # ids, classes
+        assert np.abs(rows0[f][:nt0[f], :4] - rows1[f][:nt1[f], :4]).max(initial=0) <= 1        # boxes (px)
+    b.close()

@@ -15,7 +15,7 @@ sys.path.insert(0, ROOT)
 ef = importlib.import_module("ai-camera_amd.engine_file")
 
 
-def main(d, frames=16, crops=480, top=30, fused_stem=1):
+def main(d, frames=16, crops=480, top=30, fused_stem=1, fused_yolo_stem=1):
     trace = glob.glob(os.path.join(d, "*kernel_trace.csv"))[0]
     rows = list(csv.DictReader(open(trace)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
@@ -38,7 +38,8 @@ def main(d, frames=16, crops=480, top=30, fused_stem=1):
     layers = []
     for name, g, n in (("yolo", ef.build_yolov8("n", calibrate=False), frames), ("reid", ef.build_reid(calibrate=False), crops)):
         for o in g.ops:
-            if o[0] == 1 and not (name == "reid" and g.names[o[15]] == "conv0" and fused_stem):
+            if o[0] == 1 and not (name == "reid" and g.names[o[15]] == "conv0" and fused_stem) \
+                    and not (name == "yolo" and g.names[o[15]] == "0.conv" and fused_yolo_stem):
                 h, w, _, _ = g.buffers[o[4]]
                 layers.append((name, g.names[o[15]], n * h * w, o[6], o[3] * o[7] * o[8]))
     per = len(layers)
