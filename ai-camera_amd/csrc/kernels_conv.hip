@@ -1468,11 +1468,21 @@ static bool try_patch(const ConvArgs& a, hipStream_t s) {
     // for Cout >= 128 the 8-wave im2col tile is faster, and small maps are launch-bound either way.
     static const bool off = getenv("AICAM_NO_PATCH") != nullptr;
     static const bool all = getenv("AICAM_PATCH_ALL") != nullptr;
-    if (off || a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.Wo < 16 || a.Ho < 8 || a.Cout != 64) return false;
-    if (a.M < 400000 && !all) return false;
-    constexpr int LG64 = sizeof(T) == 2 ? 3 : 4;    // Cin = 64: 8 chunks (fp16) / 16 chunks (fp32) per pixel
-    if (a.Wo >= 32) return launch_patch<T, 4, 4, 4, 1, 8, 32, 3, LG64>(a, s);
-    return launch_patch<T, 4, 4, 4, 1, 16, 16, 3, LG64>(a, s);
+    static const bool c32 = getenv("AICAM_NO_PATCH_C32") == nullptr;   // Cin = Cout = 32 (YOLOv8n P3 bottlenecks): 244 -> 460 TFLOP/s
+    if (off || a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.Wo < 16 || a.Ho < 8) return false;
+    if (a.M < 200000 && !all) return false;
+    const bool wide = a.Wo % 32 == 0 || (a.Wo % 16 != 0 && a.Wo >= 32);   // 8 x 32 tiles unless 16 x 16 tiles cover the map exactly
+    if (a.Cout == 64) {
+        constexpr int LG64 = sizeof(T) == 2 ? 3 : 4;    // Cin = 64: 8 chunks (fp16) / 16 chunks (fp32) per pixel
+        if (wide) return launch_patch<T, 4, 4, 4, 1, 8, 32, 3, LG64>(a, s);
+        return launch_patch<T, 4, 4, 4, 1, 16, 16, 3, LG64>(a, s);
+    }
+    if (a.Cout == 32 && c32) {
+        constexpr int LG32 = sizeof(T) == 2 ? 2 : 3;    // Cin = 32
+        if (wide) return launch_patch<T, 4, 2, 4, 1, 8, 32, 3, LG32>(a, s);
+        return launch_patch<T, 4, 2, 4, 1, 16, 16, 3, LG32>(a, s);
+    }
+    return false;
 }
 
 template <typename T, int MT, int NT, int WM, int WN, int NSTAGE>
