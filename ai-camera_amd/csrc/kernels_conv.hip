@@ -1287,6 +1287,162 @@ static bool try_c16(const ConvArgs& a, hipStream_t s) {
     return true;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Persistent, weights-resident 3x3 / stride 1 / pad 1 for Cin = Cout = 64, fp16 (ReID layer1: 21 % of the FLOPs, tensors
+// of 1 GB per 128-frame launch group, K = 576 only).  A tile's K loop is too short to amortise a block's prologue and
+// epilogue (conv3x3_patch_kernel: 38 % MFMA busy), and every block re-fetches the 72 KB of weights through L2 -> LDS.
+// Here one 8-wave block per CU walks many 8 x 32-pixel tiles:
+//  * the weights never touch LDS: wave w keeps the A fragments of its 32 output channels (half w>>2) for all 18
+//    K-steps in 144 VGPRs, loaded once per kernel;
+//  * the input patch (10 x 34 pixels x 64 channels, eight 16-byte planes, conflict-free, tap shift = ds_read
+//    immediate) is triple-buffered: the LDS-DMA of tile t+2 is issued right after the one barrier of tile t and has
+//    two tiles of MFMAs (144 per wave each) to land; no barrier and no global load inside the K loop;
+//  * waves w and w+4 share a SIMD and a pixel group (same B fragments, other channel half), so one wave's ds_reads
+//    and epilogue sit under its partner's MFMAs.
+template <int ACT, int RES>
+__global__ __launch_bounds__(512) void conv3x3_c64_resident_kernel(const ConvArgs a, int n_tiles, int tiles_x, int tiles_y) {
+    constexpr int TH = 8, TW = 32, PW = TW + 2, PH = TH + 2, NPIX = PW * PH, NPASS = (NPIX + 63) / 64, NPIXP = NPASS * 64;
+    constexpr int PLANE = NPIXP * 16, PBUF = 8 * PLANE;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6), r = lane & 15, q = lane >> 4;
+    const int pg = wv & 3, ch = wv >> 2;
+    const half_t* __restrict__ xg = reinterpret_cast<const half_t*>(a.x);
+    const half_t* __restrict__ wg = reinterpret_cast<const half_t*>(a.w);
+    const half_t* zero = reinterpret_cast<const half_t*>(a.zero);
+
+    // ---- weights: A fragments of channels 32*ch + perm_row<2>(j, rho) for K-step s = (tap, channel half cc): k = 32 s + 8 q
+    half8 wreg[18][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const half_t* wr = wg + (size_t)(32 * ch + perm_row<2>(j, r)) * a.Kp + 8 * q;
+#pragma unroll
+        for (int s2 = 0; s2 < 18; ++s2) wreg[s2][j] = *reinterpret_cast<const half8*>(wr + 32 * s2);
+    }
+    floatx4 bi[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bi[j][e] = a.bias[32 * ch + perm_ch<2>(j, q, e)];
+
+    // tile order: the tiles of one image stay on one XCD (blocks b, b+8, ... share an L2) so halo rows are L2 hits
+    const int tpi = tiles_x * tiles_y;
+    auto tile_of = [&](int k) -> int {
+        if (tpi == 8 && (gridDim.x & 63) == 0) {
+            const int xcd = blockIdx.x & 7, sl = blockIdx.x >> 3, per = gridDim.x >> 6;     // images in flight per XCD
+            const int im = ((sl >> 3) + per * k) * 8 + xcd;
+            return im * 8 + (sl & 7);
+        }
+        return blockIdx.x + k * gridDim.x;
+    };
+    auto issue_patch = [&](int tile, int buf) {
+        const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, img = tile / tpi;
+        const int oy0 = ty * TH, ox0 = tx * TW;
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i) {
+            const int p = i * 64 + lane;
+            const int py = p / PW, px = p - py * PW;
+            const int iy = oy0 + py - 1, ix = ox0 + px - 1;
+            const bool ok = p < NPIX && tile < n_tiles && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            const half_t* src = ok ? xg + ((size_t)(img * a.H + iy) * a.W + ix) * a.x_cs + a.x_coff + wv * 8 : zero;
+            asm volatile("" : "+v"(src));
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + buf * PBUF + wv * PLANE + i * 1024), 16, 0, 0);
+        }
+    };
+
+    int xa[4];                                  // this lane's pixel of MFMA tile i in plane q of buffer 0, tap (0,0)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xa[i] = q * PLANE + ((2 * pg + (i >> 1)) * PW + (i & 1) * 16 + r) * 16;
+
+    half_t* yg = reinterpret_cast<half_t*>(a.y);
+    const half_t* rg = reinterpret_cast<const half_t*>(a.res);
+    const int trips = (n_tiles + (int)gridDim.x - 1) / (int)gridDim.x;      // same trip count for every block
+    issue_patch(tile_of(0), 0);
+    issue_patch(tile_of(1), 1);                                             // (zero page when past the end)
+    int buf = 0;                                                            // k % 3
+    for (int k = 0; k < trips; ++k) {
+        const int tile = tile_of(k);
+        // In flight, oldest first: patch k | stores k-2 | patch k+1 | stores k-1.  Leaving NPASS operations
+        // outstanding retires patch k for certain (a conservative count: it also retires the head of patch k+1).
+        wait_vmcnt<NPASS>();
+        __builtin_amdgcn_s_barrier();           // patch k complete for everyone; everyone is done reading buffer (k+2) % 3
+        {
+            int nb = buf + 2; if (nb >= 3) nb -= 3;
+            issue_patch(tile_of(k + 2), nb);
+        }
+        if (tile < n_tiles) {
+            const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, img = tile / tpi;
+            const size_t pix0 = ((size_t)img * a.Ho + ty * TH) * a.Wo + tx * TW;
+            const int boff = buf * PBUF;
+            half8 rv[4];                        // residual vectors: requested now, they land under the K loop
+            if constexpr (RES == 1) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const size_t pix = pix0 + (size_t)(2 * pg + (i >> 1)) * a.Wo + (i & 1) * 16 + r;
+                    rv[i] = *reinterpret_cast<const half8*>(rg + pix * a.r_cs + a.r_coff + 32 * ch + 8 * q);
+                }
+            }
+            floatx4 acc[4][2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = bi[j];
+#pragma unroll
+            for (int s2 = 0; s2 < 18; ++s2) {
+                const int tap = s2 >> 1, cc = s2 & 1, kh = tap / 3, kw = tap - 3 * kh;
+                const int off = cc * 4 * PLANE + (kh * PW + kw) * 16;
+                half8 xf[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) xf[i] = *reinterpret_cast<const half8*>(smem + xa[i] + boff + off);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[s2][j], xf[i], acc[i][j], 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const size_t pix = pix0 + (size_t)(2 * pg + (i >> 1)) * a.Wo + (i & 1) * 16 + r;
+                const int n = 32 * ch + 8 * q;
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = acc[i][e >> 2][e & 3];
+                if constexpr (RES == 1) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += (float)rv[i][e];
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = act_fast<ACT>(v[e]);
+                const half8 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3], (half_t)v[4], (half_t)v[5], (half_t)v[6], (half_t)v[7]};
+                *reinterpret_cast<half8*>(yg + pix * a.y_cs + a.y_coff + n) = o;
+            }
+        }
+        if (++buf == 3) buf = 0;
+    }
+    wait_vmcnt<0>();
+}
+
+static bool try_c64_resident(const ConvArgs& a, hipStream_t s) {
+    static const int on = [] { const char* e = getenv("AICAM_C64R"); return e ? atoi(e) : 1; }();   // 0: off, 1 (default): layers without residual (+6 % on them), 2: also with residual (slower: its loads are exposed)
+    if (!on || (a.res_mode != 0 && on < 2) || a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.Cin != 64 || a.Cout != 64 || a.out_f32 || a.Kp != 576) return false;
+    if (a.W % 32 || a.H % 8 || a.Ho != a.H || a.Wo != a.W || a.M < 1500000 || (long)a.M * a.x_cs >= (1l << 31)) return false;
+    if ((a.x_cs | a.x_coff | a.y_cs | a.y_coff | a.r_cs | a.r_coff) % 8) return false;
+    const int tiles_x = a.W / 32, tiles_y = a.H / 8, n_img = a.M / (a.H * a.W), n_tiles = n_img * tiles_x * tiles_y;
+    constexpr size_t lds = (size_t)3 * 8 * 384 * 16;
+    auto launch = [&](auto kfn) {
+        static bool attr = false;
+        if (!attr) {
+            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr = true;
+        }
+        hipLaunchKernelGGL(kfn, dim3(256), dim3(512), lds, s, a, n_tiles, tiles_x, tiles_y);
+        KCHECK();
+    };
+    if (a.act == 2 && a.res_mode == 0) launch(conv3x3_c64_resident_kernel<2, 0>);
+    else if (a.act == 2 && a.res_mode == 1) launch(conv3x3_c64_resident_kernel<2, 1>);
+    else return false;
+    return true;
+}
+
 static int conv_impl() {   // AICAM_CONV=v1 selects the register-staged kernel (A/B and fallback)
     static int v = [] { const char* e = getenv("AICAM_CONV"); return (e && e[0] == 'v' && e[1] == '1') ? 1 : 2; }();
     return v;
@@ -1529,7 +1685,8 @@ static void launch_conv_t(const ConvArgs& a, hipStream_t s) {
         constexpr int BKE_ = 64 / (int)sizeof(T);
         if (pp && conv_impl() == 2 && a.Cin % BKE_ == 0 && (a.Kp >= 16 * BKE_ || pp_min == 0)) {
             if (c % 256 == 0 && (long)ceil_div(a.M, 256) * (c / 256) >= pp_min) { launch_pp<T, 8, 4, 2, 4, 4>(a, s); return; }   // 256 px x 256 ch
-            if (c == 128 && (a.Kp >= 32 * BKE_ || pp_min == 0) && ceil_div(a.M, 512) >= pp_min) { launch_pp<T, 8, 4, 4, 2, 4>(a, s); return; }                      // 512 px x 128 ch
+            static const int pp128_k = [] { const char* e = getenv("AICAM_PP128_K"); return e ? atoi(e) : 32; }();
+            if (c == 128 && (a.Kp >= pp128_k * BKE_ || pp_min == 0) && ceil_div(a.M, 512) >= pp_min) { launch_pp<T, 8, 4, 4, 2, 4>(a, s); return; }                      // 512 px x 128 ch
         }
         if (t256 && conv_impl() == 2 && c % 256 == 0 && (long)ceil_div(a.M, 256) * (c / 256) >= 200) launch_dma<T, 8, 4, 2, 4, 4>(a, s);   // 8 waves: 256 px x 256 ch
         else if (conv_impl() == 2 && (blocks128 / 2) * ceil_div(c, 128) >= 384) launch_dma<T, 4, 4, 4, 2, 3>(a, s);   // 8 waves: 256 px x 128 ch
@@ -1552,6 +1709,7 @@ static void launch_conv_t(const ConvArgs& a, hipStream_t s) {
 void launch_conv_igemm(int dtype, const ConvArgs& a, hipStream_t s) {
     if (a.M <= 0) return;
     if (dtype == AIC_F16 && try_c16(a, s)) return;
+    if (dtype == AIC_F16 && try_c64_resident(a, s)) return;
     if (dtype == AIC_F16) launch_conv_t<half_t>(a, s);
     else launch_conv_t<float>(a, s);
 }

@@ -17,18 +17,18 @@ L = importlib.import_module("ai-camera_amd._lib")
 he = importlib.import_module("ai-camera_amd.hip_engine")
 
 
-def graph(H, W, cin, cout, k, reps, res):
+def graph(H, W, cin, cout, k, reps, res, stride=1):
     g = ef.Graph(ef.KIND_REID, H, W)
     wg = ef._WeightGen(3)
     inp = g.buf(H, W, ef.IN_C)
-    a, b = g.buf(H, W, cin), g.buf(H, W, cout)
+    a, b = g.buf(H, W, cin), g.buf(H // stride, W // stride, cout)
     g.conv("stem", inp, a, 3, cin, 1, 1, ef.ACT_RELU, wb=wg(cin, 3, 1, ef.ACT_RELU))
     src = a
     for i in range(reps):
         dst = b if src == a else a
-        if cin != cout and i:
+        if (cin != cout or stride != 1) and i:
             break
-        g.conv(f"t{i}", src, dst, cin, cout, k, 1, ef.ACT_RELU, wb=wg(cout, cin, k, ef.ACT_RELU, 0.5 if res else 1.0),
+        g.conv(f"t{i}", src, dst, cin, cout, k, stride, ef.ACT_RELU, wb=wg(cout, cin, k, ef.ACT_RELU, 0.5 if res else 1.0),
                **(dict(res=(dst, 0), res_mode=ef.RES_ADD_THEN_ACT) if res and cin == cout else {}))
         src = dst
     p = g.buf(1, 1, cout)
@@ -45,7 +45,8 @@ def main():
     items = int(sys.argv[6]) if len(sys.argv) > 6 else 960
     reps = int(sys.argv[7]) if len(sys.argv) > 7 else 8
     res = int(sys.argv[8]) if len(sys.argv) > 8 else 0
-    g = graph(H, W, cin, cout, k, reps, res)
+    stride = int(sys.argv[9]) if len(sys.argv) > 9 else 1
+    g = graph(H, W, cin, cout, k, reps, res, stride)
     path = f"/tmp/convbench_{os.getpid()}.aicw"
     ef.write_engine(path, g)
     eng = he.HipEngine(path, dtype=os.environ.get("DTYPE", "fp16"), max_items=items, warm_up=False)
@@ -60,7 +61,7 @@ def main():
     p = L.prof_read(0)["conv_igemm"]
     n_conv = sum(1 for o in g.ops if o[0] == 1)
     us = p["ms"] * 1e3 / 5 / n_conv
-    print(f"H{H} W{W} cin{cin} cout{cout} k{k} items{items} res{res}: M={items*H*W} K={cin*k*k}  "
+    print(f"H{H} W{W} cin{cin} cout{cout} k{k} s{stride} items{items} res{res}: M={items*(H//stride)*(W//stride)} K={cin*k*k}  "
           f"{p['flops'] / p['ms'] / 1e9:7.1f} TF  (~{us:.1f} us per conv, wall {dt/5*1e3:.2f} ms/iter) env={ {k_: v for k_, v in os.environ.items() if k_.startswith('AICAM')} }")
     os.remove(path)
 
