@@ -1,0 +1,304 @@
+// conv_common.hpp -- device helpers shared by the convolution translation units (kernels_conv*.hip): MFMA fragment
+// types, the LDS swizzle, the channel permutation and the epilogues, LDS-DMA typedefs and counted waits; plus the host
+// entry points by which launch_conv_igemm() (kernels_conv.hip) reaches the kernels that live in the other units.
+#pragma once
+#include "kernels.hpp"
+
+#include <cstdlib>
+#include <type_traits>
+
+namespace aic {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+    if (act == 1) return v / (1.0f + __expf(-v));   // SiLU
+    if (act == 2) return fmaxf(v, 0.0f);             // ReLU
+    return v;
+}
+
+template <typename T> struct Frag;
+template <> struct Frag<half_t> {
+    typedef half8 type;
+    static __device__ __forceinline__ floatx4 mma(const half8& a, const half8& b, floatx4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct Frag<float> {
+    typedef floatx4 type;
+    static __device__ __forceinline__ floatx4 mma(const floatx4& a, const floatx4& b, floatx4 c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], c, 0, 0, 0);
+        return c;
+    }
+};
+
+// swz(row) = ((row>>1)&3) ^ ((row>>3)&2): conflict-free for 16 consecutive rows (pixel tiles, identity weight tiles) AND
+// for the permuted weight rows {c + 8k + s} of perm_row() (brute-forced over the ds_read_b128 lane groups).
+__device__ __forceinline__ int lds_swz(int row) { return ((row >> 1) & 3) ^ ((row >> 3) & 2); }
+__device__ __forceinline__ int lds_off(int row, int chunk) { return row * 64 + 16 * (chunk ^ lds_swz(row)); }
+
+// ---- shared by the v2 kernel: cheap index math and a specialised epilogue ------------------------
+// m -> (m / d, m % d) with one reciprocal multiply and a +-1 fix-up (m < 2^26 here).
+__device__ __forceinline__ void fast_divmod(int m, int d, float inv, int& q, int& r) {
+    q = (int)(__int2float_rz(m) * inv);
+    r = m - q * d;
+    if (r >= d) { r -= d; ++q; }
+    if (r < 0) { r += d; --q; }
+}
+
+template <int ACT> __device__ __forceinline__ float act_fast(float v) {
+    if constexpr (ACT == 1) {   // SiLU = v * sigmoid(v); v_exp_f32 + v_rcp_f32 (<= 1 ulp each)
+        return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f));
+    } else if constexpr (ACT == 2) {
+        return fmaxf(v, 0.0f);
+    } else {
+        return v;
+    }
+}
+
+// One lane owns, per (i, j) tile, 4 consecutive output channels of one pixel.
+// ACT / RES / F32OUT are compile-time so the unrolled body carries no branches.
+template <typename T, int MT, int NT, int ACT, int RES, bool F32OUT>
+__device__ __forceinline__ void epilogue_fast(const ConvArgs& a, floatx4 (&acc)[MT][NT], const int (&mrow)[MT], int n_base, int q) {
+    const float* __restrict__ bias = a.bias;
+    const T* __restrict__ rg = reinterpret_cast<const T*>(a.res);
+    floatx4 b4[NT];
+    bool ncol[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int n = n_base + j * 16 + 4 * q;
+        ncol[j] = n < a.Cout;                       // Cout % 4 == 0 on this path: all four or none
+        b4[j] = *reinterpret_cast<const floatx4*>(bias + n);   // bias is padded to cout_pad
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int m = mrow[i];
+        if (m < 0) continue;
+        const size_t ybase = (size_t)m * a.y_cs + a.y_coff;
+        const size_t rbase = RES ? (size_t)m * a.r_cs + a.r_coff : 0;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            if (!ncol[j]) continue;
+            const int n = n_base + j * 16 + 4 * q;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] + b4[j][e];
+            if constexpr (RES != 0) {
+                float rv[4];
+                if constexpr (sizeof(T) == 2) {
+                    const half4 h = *reinterpret_cast<const half4*>(rg + rbase + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) rv[e] = (float)h[e];
+                } else {
+                    const floatx4 h = *reinterpret_cast<const floatx4*>(rg + rbase + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) rv[e] = h[e];
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = RES == 1 ? act_fast<ACT>(v[e] + rv[e]) : act_fast<ACT>(v[e]) + rv[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = act_fast<ACT>(v[e]);
+            }
+            if constexpr (F32OUT || sizeof(T) == 4) {
+                *reinterpret_cast<floatx4*>(reinterpret_cast<float*>(a.y) + ybase + n) = floatx4{v[0], v[1], v[2], v[3]};
+            } else {
+                const half4 h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+                *reinterpret_cast<half4*>(reinterpret_cast<half_t*>(a.y) + ybase + n) = h;
+            }
+        }
+    }
+}
+
+// Channel permutation of the v2+ kernels: MFMA tile j, row rho (= 4q + e on the output side) of a wave's
+// NT-tile channel block carries output channel  32*(j>>1) + 8*(rho>>2) + 4*(j&1) + (rho&3)  (tiles taken in
+// pairs; an odd last tile keeps the identity 16j + rho).  A lane (r, q) then owns, per tile pair, EIGHT
+// consecutive channels of its pixel: one 16-byte fp16 store (two for fp32) instead of two 8-byte ones, and
+// the four q-lanes of a pixel write 64 contiguous bytes per instruction.  The A-operand (weight) rows are
+// fetched from LDS through the same map (perm_row), so the arithmetic per output is unchanged.
+template <int NT> __device__ __forceinline__ int perm_ch(int j, int q, int e) {
+    return j < (NT & ~1) ? 32 * (j >> 1) + 8 * q + 4 * (j & 1) + e : 16 * j + 4 * q + e;
+}
+template <int NT> __device__ __forceinline__ int perm_row(int j, int r) { return perm_ch<NT>(j, r >> 2, r & 3); }
+
+template <typename T, int MT, int NT, int ACT, int RES, bool F32OUT>
+__device__ __forceinline__ void epilogue_wide(const ConvArgs& a, floatx4 (&acc)[MT][NT], const int (&mrow)[MT], int n_base, int q) {
+    constexpr int NP = NT / 2;
+    const float* __restrict__ bias = a.bias;
+    const T* __restrict__ rg = reinterpret_cast<const T*>(a.res);
+    floatx4 b4[NT];
+    bool pcol[NP + 1];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int n = n_base + 32 * p + 8 * q;
+        pcol[p] = n < a.Cout;                       // Cout % 8 == 0 on this path: all eight or none
+        b4[2 * p] = *reinterpret_cast<const floatx4*>(bias + n);          // bias is padded to cout_pad
+        b4[2 * p + 1] = *reinterpret_cast<const floatx4*>(bias + n + 4);
+    }
+    if constexpr (NT & 1) {
+        const int n = n_base + 16 * (NT - 1) + 4 * q;
+        pcol[NP] = n < a.Cout;
+        b4[NT - 1] = *reinterpret_cast<const floatx4*>(bias + n);
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int m = mrow[i];
+        if (m < 0) continue;
+        const size_t ybase = (size_t)m * a.y_cs + a.y_coff;
+        const size_t rbase = RES ? (size_t)m * a.r_cs + a.r_coff : 0;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            if (!pcol[p]) continue;
+            const int n = n_base + 32 * p + 8 * q;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = acc[i][2 * p + (e >> 2)][e & 3] + b4[2 * p + (e >> 2)][e & 3];
+            if constexpr (RES != 0) {
+                float rv[8];
+                if constexpr (sizeof(T) == 2) {
+                    const half8 h = *reinterpret_cast<const half8*>(rg + rbase + n);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) rv[e] = (float)h[e];
+                } else {
+                    const floatx4 h0 = *reinterpret_cast<const floatx4*>(rg + rbase + n);
+                    const floatx4 h1 = *reinterpret_cast<const floatx4*>(rg + rbase + n + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { rv[e] = h0[e]; rv[4 + e] = h1[e]; }
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = RES == 1 ? act_fast<ACT>(v[e] + rv[e]) : act_fast<ACT>(v[e]) + rv[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = act_fast<ACT>(v[e]);
+            }
+            if constexpr (F32OUT || sizeof(T) == 4) {
+                float* yp = reinterpret_cast<float*>(a.y) + ybase + n;
+                *reinterpret_cast<floatx4*>(yp) = floatx4{v[0], v[1], v[2], v[3]};
+                *reinterpret_cast<floatx4*>(yp + 4) = floatx4{v[4], v[5], v[6], v[7]};
+            } else {
+                const half8 h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3], (half_t)v[4], (half_t)v[5], (half_t)v[6], (half_t)v[7]};
+                *reinterpret_cast<half8*>(reinterpret_cast<half_t*>(a.y) + ybase + n) = h;
+            }
+        }
+        if constexpr (NT & 1) {
+            if (pcol[NP]) {
+                constexpr int j = NT - 1;
+                const int n = n_base + 16 * j + 4 * q;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] + b4[j][e];
+                if constexpr (RES != 0) {
+                    float rv[4];
+                    if constexpr (sizeof(T) == 2) {
+                        const half4 h = *reinterpret_cast<const half4*>(rg + rbase + n);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) rv[e] = (float)h[e];
+                    } else {
+                        const floatx4 h = *reinterpret_cast<const floatx4*>(rg + rbase + n);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) rv[e] = h[e];
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = RES == 1 ? act_fast<ACT>(v[e] + rv[e]) : act_fast<ACT>(v[e]) + rv[e];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = act_fast<ACT>(v[e]);
+                }
+                if constexpr (F32OUT || sizeof(T) == 4) {
+                    *reinterpret_cast<floatx4*>(reinterpret_cast<float*>(a.y) + ybase + n) = floatx4{v[0], v[1], v[2], v[3]};
+                } else {
+                    const half4 h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+                    *reinterpret_cast<half4*>(reinterpret_cast<half_t*>(a.y) + ybase + n) = h;
+                }
+            }
+        }
+    }
+}
+
+// Generic (any Cout, any mode) fallback: runtime branches, scalar tail.
+template <typename T, int MT, int NT, bool PERM>
+__device__ __forceinline__ void epilogue_generic(const ConvArgs& a, floatx4 (&acc)[MT][NT], const int (&mrow)[MT], int n_base, int q) {
+    // (inlined and fully unrolled on purpose: a call would force `a` and `acc` into scratch memory)
+    const float* __restrict__ bias = a.bias;
+    const T* __restrict__ rg = reinterpret_cast<const T*>(a.res);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int m = mrow[i];
+        if (m < 0) continue;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int n = n_base + (PERM ? perm_ch<NT>(j, q, 0) : j * 16 + 4 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (n + e >= a.Cout) continue;
+                float x = acc[i][j][e] + bias[n + e];
+                const float rv = a.res_mode ? (float)rg[(size_t)m * a.r_cs + a.r_coff + n + e] : 0.f;
+                if (a.res_mode == 1) x += rv;
+                x = act_apply(x, a.act);
+                if (a.res_mode == 2) x += rv;
+                const size_t yo = (size_t)m * a.y_cs + a.y_coff + n + e;
+                if (a.out_f32 || sizeof(T) == 4) reinterpret_cast<float*>(a.y)[yo] = x;
+                else reinterpret_cast<half_t*>(a.y)[yo] = (half_t)x;
+            }
+        }
+    }
+}
+
+template <typename T, int MT, int NT, bool PERM = false>
+__device__ __forceinline__ void epilogue_dispatch(const ConvArgs& a, floatx4 (&acc)[MT][NT], const int (&mrow)[MT], int n_base, int q) {
+    const int key = (a.Cout & (PERM ? 7 : 3)) ? -1 : (a.act | (a.res_mode << 2) | (a.out_f32 << 4));
+#define AIC_EPI(ACT, RES, F32) do { if constexpr (PERM) epilogue_wide<T, MT, NT, ACT, RES, F32>(a, acc, mrow, n_base, q); \
+                                    else epilogue_fast<T, MT, NT, ACT, RES, F32>(a, acc, mrow, n_base, q); } while (0)
+    switch (key) {
+        case 1: AIC_EPI(1, 0, false); break;             // SiLU
+        case 1 | (2 << 2): AIC_EPI(1, 2, false); break;  // SiLU then +res (C2f bottleneck)
+        case 2: AIC_EPI(2, 0, false); break;             // ReLU
+        case 2 | (1 << 2): AIC_EPI(2, 1, false); break;  // relu(x + res) (BasicBlock)
+        case 0: AIC_EPI(0, 0, false); break;             // linear (downsample, FC)
+        case 0 | (1 << 4): AIC_EPI(0, 0, true); break;   // linear fp32 (detect head)
+        default: epilogue_generic<T, MT, NT, PERM>(a, acc, mrow, n_base, q); break;
+    }
+#undef AIC_EPI
+}
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if constexpr (N == 15) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+    else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if constexpr (N == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+    else if constexpr (N == 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+    else static_assert(N < 0, "add this vmcnt literal");
+}
+
+
+inline int conv_impl() {   // AICAM_CONV=v1 selects the register-staged kernel (A/B and fallback)
+    static int v = [] { const char* e = getenv("AICAM_CONV"); return (e && e[0] == 'v' && e[1] == '1') ? 1 : 2; }();
+    return v;
+}
+
+// ---- host entry points of the other conv units; each returns false when the layer is not one of its shapes
+bool conv_try_pp_patch(int dtype, const ConvArgs& a, hipStream_t s);   // kernels_conv_pp.hip: v5 ping-pong patch (3x3/s1, Cout 128 / 256k)
+bool conv_try_pp(int dtype, const ConvArgs& a, hipStream_t s);         // kernels_conv_pp.hip: v4 ping-pong im2col (long K, Cout 128 / 256k)
+bool conv_try_patch(int dtype, const ConvArgs& a, hipStream_t s);      // kernels_conv_direct.hip: 4-wave patch kernel (Cout 64 / 32)
+bool conv_try_c16(const ConvArgs& a, hipStream_t s);                   // kernels_conv_direct.hip: 16 input channels, fp16
+bool conv_try_c64_resident(const ConvArgs& a, hipStream_t s);          // kernels_conv_direct.hip: persistent Cin = Cout = 64, fp16
+
+}  // namespace aic

@@ -1,0 +1,734 @@
+// kernels_conv_direct.hip -- conv kernels that keep the input PATCH in LDS instead of gathering im2col tiles: the 4-wave
+// patch kernel (v3), the 16-input-channel direct kernel, the persistent weights-resident kernel, the fused ReID stem.
+#include "conv_common.hpp"
+
+namespace aic {
+
+// ------------------------------------------------------------------------------------------------
+// Direct 3x3 (pad 1, stride 1 or 2) for 16 input channels, fp16, SiLU: YOLOv8n's P1/P2 layers (1.conv, 2.c2f.m0.cv1/cv2).
+// Through the implicit GEMM these run 3-4x above their HBM floor: K = 144 straddles taps inside a K-step (generic
+// gather path, ~12 VALU per 16-byte LDS-DMA) and every input pixel is fetched 9 times for 16-32 output channels.
+// Here a block owns 8 x 32 output pixels of one image: the input patch is read once into LDS, the weights (<= 9 KB)
+// live in registers as MFMA A fragments, K is the natural (tap, 16 ch) order so one v_mfma_f32_16x16x32_f16 eats
+// two taps and the B fragment of a lane is ONE aligned 16-byte ds_read (its tap's channel half).
+// LDS entry (row, column parity p, channel half h, column c2) = 16 bytes; for stride 2 even and odd input columns
+// are kept apart so that 16 consecutive output pixels read 16 consecutive entries (conflict-free).
+template <int COUT, int S>
+__global__ __launch_bounds__(256) void conv3x3_c16_kernel(const ConvArgs a, int tiles_x, int tiles_y) {
+    constexpr int TH = 8, TW = 32, NCT = COUT / 16;
+    constexpr int PR = (TH - 1) * S + 3, PC = (TW - 1) * S + 3;
+    constexpr int NPAR = S, PCP = (PC + NPAR - 1) / NPAR;
+    static_assert((S == 1 || S == 2) && (COUT == 16 || COUT == 32), "variants");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, r = lane & 15, q = lane >> 4;
+    int bx = blockIdx.x;
+    const int tx = bx % tiles_x; bx /= tiles_x;
+    const int ty = bx % tiles_y;
+    const int img = bx / tiles_y;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
+    const half_t* xg = reinterpret_cast<const half_t*>(a.x) + (size_t)img * a.H * a.W * a.x_cs + a.x_coff;
+
+    for (int idx = t; idx < PR * PC * 2; idx += 256) {
+        const int h = idx & 1, pp = idx >> 1;
+        const int pr = pp / PC, pc = pp - pr * PC;
+        const int iy = iy0 + pr, ix = ix0 + pc;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
+            v = *reinterpret_cast<const uint4*>(xg + ((size_t)iy * a.W + ix) * a.x_cs + h * 8);
+        const int par = pc % NPAR, c2 = pc / NPAR;
+        *reinterpret_cast<uint4*>(smem + (((pr * NPAR + par) * 2 + h) * PCP + c2) * 16) = v;
+    }
+
+    // A fragments: MFMA m covers K = 32m .. 32m+31 = taps 2m, 2m+1 x 16 channels (Kp = 160: k >= 144 are zero rows)
+    const half_t* wg = reinterpret_cast<const half_t*>(a.w);
+    half8 wa[NCT][5];
+    floatx4 bi[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+        const half_t* wr = wg + (size_t)perm_row<NCT>(ct, r) * a.Kp + 8 * q;
+#pragma unroll
+        for (int m = 0; m < 5; ++m) wa[ct][m] = *reinterpret_cast<const half8*>(wr + 32 * m);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bi[ct][e] = a.bias[perm_ch<NCT>(ct, q, e)];
+    }
+    int d[5];                                  // LDS offset of this lane's (tap, channel half) relative to its output pixel
+#pragma unroll
+    for (int m = 0; m < 5; ++m) {
+        const int tap = min(2 * m + (q >> 1), 8), kh = tap / 3, kw = tap - 3 * kh, h = q & 1;
+        d[m] = (((kh * NPAR + kw % NPAR) * 2 + h) * PCP + kw / NPAR) * 16;
+    }
+    __syncthreads();
+
+    half_t* yg = reinterpret_cast<half_t*>(a.y);
+    const half_t* rg = reinterpret_cast<const half_t*>(a.res);
+#pragma unroll
+    for (int tile = 0; tile < 4; ++tile) {
+        const int oyl = 2 * wv + (tile >> 1), oxl = (tile & 1) * 16 + r;
+        const int base = (oyl * S * NPAR * 2 * PCP + oxl) * 16;
+        half8 xb[5];
+#pragma unroll
+        for (int m = 0; m < 5; ++m) xb[m] = *reinterpret_cast<const half8*>(smem + base + d[m]);
+        const size_t pix = ((size_t)img * a.Ho + oy0 + oyl) * a.Wo + ox0 + oxl;
+        float v[NCT][4];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+            floatx4 acc = bi[ct];
+#pragma unroll
+            for (int m = 0; m < 5; ++m) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[ct][m], xb[m], acc, 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[ct][e] = act_fast<1>(acc[e]);
+        }
+        if constexpr (NCT == 1) {
+            const int ch = 4 * q;
+            if (a.res_mode == 2) {
+                const half4 h = *reinterpret_cast<const half4*>(rg + pix * a.r_cs + a.r_coff + ch);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[0][e] += (float)h[e];
+            }
+            const half4 o = {(half_t)v[0][0], (half_t)v[0][1], (half_t)v[0][2], (half_t)v[0][3]};
+            *reinterpret_cast<half4*>(yg + pix * a.y_cs + a.y_coff + ch) = o;
+        } else {
+            const int ch = 8 * q;                                       // perm_ch<2>: tiles 0, 1 -> channels 8q + 4*(ct) + e
+            if (a.res_mode == 2) {
+                const half8 h = *reinterpret_cast<const half8*>(rg + pix * a.r_cs + a.r_coff + ch);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e >> 2][e & 3] += (float)h[e];
+            }
+            const half8 o = {(half_t)v[0][0], (half_t)v[0][1], (half_t)v[0][2], (half_t)v[0][3],
+                             (half_t)v[1][0], (half_t)v[1][1], (half_t)v[1][2], (half_t)v[1][3]};
+            *reinterpret_cast<half8*>(yg + pix * a.y_cs + a.y_coff + ch) = o;
+        }
+    }
+}
+
+template <int COUT, int S>
+static void launch_c16(const ConvArgs& a, hipStream_t s) {
+    constexpr int PR = 7 * S + 3, PC = 31 * S + 3, PCP = (PC + S - 1) / S;
+    constexpr size_t lds = (size_t)PR * S * 2 * PCP * 16;
+    const int tiles_x = a.Wo / 32, tiles_y = a.Ho / 8, n_img = a.M / (a.Ho * a.Wo);
+    hipLaunchKernelGGL((conv3x3_c16_kernel<COUT, S>), dim3(n_img * tiles_x * tiles_y), dim3(256), lds, s, a, tiles_x, tiles_y);
+    KCHECK();
+}
+
+static bool try_c16(const ConvArgs& a, hipStream_t s) {
+    static const bool off = getenv("AICAM_NO_C16") != nullptr;
+    if (off || a.KH != 3 || a.KW != 3 || a.pad != 1 || a.Cin != 16 || a.act != 1 || a.out_f32 || (a.res_mode != 0 && a.res_mode != 2)) return false;
+    if (a.Wo % 32 || a.Ho % 8 || a.Kp != 160 || (a.x_cs | a.x_coff | a.y_cs | a.y_coff | a.r_cs | a.r_coff) % 8) return false;
+    if (a.stride == 1 && (a.Ho != a.H || a.Wo != a.W)) return false;
+    if (a.stride == 2 && (a.Ho != (a.H + 1) / 2 || a.Wo != (a.W + 1) / 2)) return false;
+    if (a.Cout == 16 && a.stride == 1) launch_c16<16, 1>(a, s);
+    else if (a.Cout == 32 && a.stride == 2) launch_c16<32, 2>(a, s);
+    else if (a.Cout == 16 && a.stride == 2) launch_c16<16, 2>(a, s);
+    else if (a.Cout == 32 && a.stride == 1) launch_c16<32, 1>(a, s);
+    else return false;
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Persistent, weights-resident 3x3 / stride 1 / pad 1 for Cin = Cout = 64, fp16 (ReID layer1: 21 % of the FLOPs, tensors
+// of 1 GB per 128-frame launch group, K = 576 only).  A tile's K loop is too short to amortise a block's prologue and
+// epilogue (conv3x3_patch_kernel: 38 % MFMA busy), and every block re-fetches the 72 KB of weights through L2 -> LDS.
+// Here one 8-wave block per CU walks many 8 x 32-pixel tiles:
+//  * the weights never touch LDS: wave w keeps the A fragments of its 32 output channels (half w>>2) for all 18
+//    K-steps in 144 VGPRs, loaded once per kernel;
+//  * the input patch (10 x 34 pixels x 64 channels, eight 16-byte planes, conflict-free, tap shift = ds_read
+//    immediate) is triple-buffered: the LDS-DMA of tile t+2 is issued right after the one barrier of tile t and has
+//    two tiles of MFMAs (144 per wave each) to land; no barrier and no global load inside the K loop;
+//  * waves w and w+4 share a SIMD and a pixel group (same B fragments, other channel half), so one wave's ds_reads
+//    and epilogue sit under its partner's MFMAs.
+template <int ACT, int RES>
+__global__ __launch_bounds__(512) void conv3x3_c64_resident_kernel(const ConvArgs a, int n_tiles, int tiles_x, int tiles_y) {
+    constexpr int TH = 8, TW = 32, PW = TW + 2, PH = TH + 2, NPIX = PW * PH, NPASS = (NPIX + 63) / 64, NPIXP = NPASS * 64;
+    constexpr int PLANE = NPIXP * 16, PBUF = 8 * PLANE;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6), r = lane & 15, q = lane >> 4;
+    const int pg = wv & 3, ch = wv >> 2;
+    const half_t* __restrict__ xg = reinterpret_cast<const half_t*>(a.x);
+    const half_t* __restrict__ wg = reinterpret_cast<const half_t*>(a.w);
+    const half_t* zero = reinterpret_cast<const half_t*>(a.zero);
+
+    // ---- weights: A fragments of channels 32*ch + perm_row<2>(j, rho) for K-step s = (tap, channel half cc): k = 32 s + 8 q
+    half8 wreg[18][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const half_t* wr = wg + (size_t)(32 * ch + perm_row<2>(j, r)) * a.Kp + 8 * q;
+#pragma unroll
+        for (int s2 = 0; s2 < 18; ++s2) wreg[s2][j] = *reinterpret_cast<const half8*>(wr + 32 * s2);
+    }
+    floatx4 bi[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bi[j][e] = a.bias[32 * ch + perm_ch<2>(j, q, e)];
+
+    // tile order: the tiles of one image stay on one XCD (blocks b, b+8, ... share an L2) so halo rows are L2 hits
+    const int tpi = tiles_x * tiles_y;
+    auto tile_of = [&](int k) -> int {
+        if (tpi == 8 && (gridDim.x & 63) == 0) {
+            const int xcd = blockIdx.x & 7, sl = blockIdx.x >> 3, per = gridDim.x >> 6;     // images in flight per XCD
+            const int im = ((sl >> 3) + per * k) * 8 + xcd;
+            return im * 8 + (sl & 7);
+        }
+        return blockIdx.x + k * gridDim.x;
+    };
+    auto issue_patch = [&](int tile, int buf) {
+        const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, img = tile / tpi;
+        const int oy0 = ty * TH, ox0 = tx * TW;
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i) {
+            const int p = i * 64 + lane;
+            const int py = p / PW, px = p - py * PW;
+            const int iy = oy0 + py - 1, ix = ox0 + px - 1;
+            const bool ok = p < NPIX && tile < n_tiles && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            const half_t* src = ok ? xg + ((size_t)(img * a.H + iy) * a.W + ix) * a.x_cs + a.x_coff + wv * 8 : zero;
+            asm volatile("" : "+v"(src));
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + buf * PBUF + wv * PLANE + i * 1024), 16, 0, 0);
+        }
+    };
+
+    int xa[4];                                  // this lane's pixel of MFMA tile i in plane q of buffer 0, tap (0,0)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xa[i] = q * PLANE + ((2 * pg + (i >> 1)) * PW + (i & 1) * 16 + r) * 16;
+
+    half_t* yg = reinterpret_cast<half_t*>(a.y);
+    const half_t* rg = reinterpret_cast<const half_t*>(a.res);
+    const int trips = (n_tiles + (int)gridDim.x - 1) / (int)gridDim.x;      // same trip count for every block
+    issue_patch(tile_of(0), 0);
+    issue_patch(tile_of(1), 1);                                             // (zero page when past the end)
+    int buf = 0;                                                            // k % 3
+    for (int k = 0; k < trips; ++k) {
+        const int tile = tile_of(k);
+        // In flight, oldest first: patch k | stores k-2 | patch k+1 | stores k-1.  Leaving NPASS operations
+        // outstanding retires patch k for certain (a conservative count: it also retires the head of patch k+1).
+        wait_vmcnt<NPASS>();
+        __builtin_amdgcn_s_barrier();           // patch k complete for everyone; everyone is done reading buffer (k+2) % 3
+        {
+            int nb = buf + 2; if (nb >= 3) nb -= 3;
+            issue_patch(tile_of(k + 2), nb);
+        }
+        if (tile < n_tiles) {
+            const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, img = tile / tpi;
+            const size_t pix0 = ((size_t)img * a.Ho + ty * TH) * a.Wo + tx * TW;
+            const int boff = buf * PBUF;
+            half8 rv[4];                        // residual vectors: requested now, they land under the K loop
+            if constexpr (RES == 1) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const size_t pix = pix0 + (size_t)(2 * pg + (i >> 1)) * a.Wo + (i & 1) * 16 + r;
+                    rv[i] = *reinterpret_cast<const half8*>(rg + pix * a.r_cs + a.r_coff + 32 * ch + 8 * q);
+                }
+            }
+            floatx4 acc[4][2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = bi[j];
+#pragma unroll
+            for (int s2 = 0; s2 < 18; ++s2) {
+                const int tap = s2 >> 1, cc = s2 & 1, kh = tap / 3, kw = tap - 3 * kh;
+                const int off = cc * 4 * PLANE + (kh * PW + kw) * 16;
+                half8 xf[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) xf[i] = *reinterpret_cast<const half8*>(smem + xa[i] + boff + off);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[s2][j], xf[i], acc[i][j], 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const size_t pix = pix0 + (size_t)(2 * pg + (i >> 1)) * a.Wo + (i & 1) * 16 + r;
+                const int n = 32 * ch + 8 * q;
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = acc[i][e >> 2][e & 3];
+                if constexpr (RES == 1) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += (float)rv[i][e];
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = act_fast<ACT>(v[e]);
+                const half8 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3], (half_t)v[4], (half_t)v[5], (half_t)v[6], (half_t)v[7]};
+                *reinterpret_cast<half8*>(yg + pix * a.y_cs + a.y_coff + n) = o;
+            }
+        }
+        if (++buf == 3) buf = 0;
+    }
+    wait_vmcnt<0>();
+}
+
+static bool try_c64_resident(const ConvArgs& a, hipStream_t s) {
+    static const int on = [] { const char* e = getenv("AICAM_C64R"); return e ? atoi(e) : 1; }();   // 0: off, 1 (default): layers without residual (+6 % on them), 2: also with residual (slower: its loads are exposed)
+    if (!on || (a.res_mode != 0 && on < 2) || a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.Cin != 64 || a.Cout != 64 || a.out_f32 || a.Kp != 576) return false;
+    if (a.W % 32 || a.H % 8 || a.Ho != a.H || a.Wo != a.W || a.M < 1500000 || (long)a.M * a.x_cs >= (1l << 31)) return false;
+    if ((a.x_cs | a.x_coff | a.y_cs | a.y_coff | a.r_cs | a.r_coff) % 8) return false;
+    const int tiles_x = a.W / 32, tiles_y = a.H / 8, n_img = a.M / (a.H * a.W), n_tiles = n_img * tiles_x * tiles_y;
+    constexpr size_t lds = (size_t)3 * 8 * 384 * 16;
+    auto launch = [&](auto kfn) {
+        static bool attr = false;
+        if (!attr) {
+            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr = true;
+        }
+        hipLaunchKernelGGL(kfn, dim3(256), dim3(512), lds, s, a, n_tiles, tiles_x, tiles_y);
+        KCHECK();
+    };
+    if (a.act == 2 && a.res_mode == 0) launch(conv3x3_c64_resident_kernel<2, 0>);
+    else if (a.act == 2 && a.res_mode == 1) launch(conv3x3_c64_resident_kernel<2, 1>);
+    else return false;
+    return true;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// v3 for 3x3 / stride 1 / pad 1: the im2col gather of v2 fetches every input chunk 9 times (once per
+// tap) through L2 -> LDS.  Here a block owns a TH x TW tile of output pixels of ONE image; the
+// (TH+2) x (TW+2) x Cin input patch (with its halo; zero page outside the image) is pulled into LDS
+// once by LDS-DMA and the nine taps are generated from LDS at shifted addresses.  Only the weights
+// stream through the NSTAGE ring.  K order = tap-major, Cin/BKE steps per tap (needs Cin % BKE == 0).
+// Patch image: pixel p, 16-byte chunk j stored at chunk slot j ^ swz(p) (source-side swizzle again);
+// swz(p) = p & (CPP-1) (CPP = chunks per pixel >= 8) or (p>>1)&3 (CPP == 4): conflict-free /
+// <= 2-way for the ds_read_b128 lane groups (16 consecutive pixels x 4 consecutive chunks).
+template <int CPP> __device__ __forceinline__ int patch_swz(int p) { return CPP == 4 ? ((p >> 1) & 3) : (p & (CPP - 1)); }
+
+// Everything the hot loop needs is a compile-time constant or a precomputed register:
+//  * LGCPP: log2 of the 16-byte chunks per pixel (Cin fixed per instantiation), CSTEPS = CPP/4 K-steps per tap;
+//  * patch rows are padded to PWP pixels, a multiple of max(8, CPP): the swizzle term of a patch pixel
+//    then depends on its column only, so the LDS address of (tile i, tap column kw, chunk cc) is one of
+//    3*CSTEPS*MT precomputed VGPRs and the tap row kh is a ds_read immediate;
+//  * taps, chunks and ring stages are fully unrolled; the weight stream is a pointer increment.
+// VALU per MFMA drops from ~12 to <1 (SQ_INSTS_VALU / SQ_INSTS_MFMA, profiles/).
+template <typename T, int MT, int NT, int WM, int WN, int TH, int TW, int NSTAGE, int LGCPP>
+__global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(const ConvArgs a, int tiles_x, int tiles_y) {
+    constexpr int CH = 16 / (int)sizeof(T);
+    constexpr int BKE = 4 * CH;
+    constexpr int NTHR = 64 * WM * WN;
+    constexpr int RP = NTHR / 4;
+    constexpr int BM = WM * MT * 16;
+    constexpr int BN = WN * NT * 16;
+    constexpr int BNP = (BN + RP - 1) / RP * RP;
+    constexpr int B_PER = BNP / RP;
+    constexpr int WSTAGE = BNP * 64;
+    constexpr int CPP = 1 << LGCPP, CSTEPS = CPP / 4, NSTEPS = 9 * CSTEPS;
+    constexpr int PAL = CPP >= 8 ? CPP : 8;
+    constexpr int PH = TH + 2, PWP = (TW + 2 + PAL - 1) / PAL * PAL;
+    constexpr int TOTAL = PH * PWP * CPP;
+    constexpr int PATCH_BYTES = (TOTAL + NTHR - 1) / NTHR * NTHR * 16;
+    constexpr int ROWB = PWP * CPP * 16;                    // bytes per patch row
+    static_assert(BM == TH * TW && TW % 16 == 0 && (TW & (TW - 1)) == 0 && B_PER == 1, "tile geometry");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* ring = smem + PATCH_BYTES;
+
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    int bx = blockIdx.x;
+    const int tx = bx % tiles_x; bx /= tiles_x;
+    const int ty = bx % tiles_y;
+    const int img = bx / tiles_y;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int n0 = blockIdx.y * BN;
+
+    const T* __restrict__ wg = reinterpret_cast<const T*>(a.w);
+    const T* zero = reinterpret_cast<const T*>(a.zero);
+    const T* ximg = reinterpret_cast<const T*>(a.x) + (size_t)img * a.H * a.W * a.x_cs + a.x_coff;
+
+    // ---- the input patch, once (pad columns and out-of-image pixels come from the zero page)
+#pragma unroll 2
+    for (int base = 0; base < TOTAL; base += NTHR) {
+        const int L = base + t;
+        const int p = L >> LGCPP, sl = L & (CPP - 1);
+        const int j = sl ^ patch_swz<CPP>(p);
+        const int py = p / PWP, px = p - py * PWP;
+        const int iy = oy0 + py - 1, ix = ox0 + px - 1;
+        const bool ok = L < TOTAL && px < TW + 2 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        const T* src = ok ? ximg + ((size_t)iy * a.W + ix) * a.x_cs + j * CH : zero;
+        asm volatile("" : "+v"(src));
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + (size_t)(base + 64 * wv) * 16), 16, 0, 0);
+    }
+
+    // ---- weight stream: one 16-byte chunk per thread per K-step; rows past Cout read the zero page with stride 0
+    const int slot = t & 3, r0 = t >> 2;
+    const int kc = slot ^ lds_swz(r0);
+    const bool wrow_ok = r0 < BN;
+    const T* wptr = wrow_ok ? wg + (size_t)(n0 + r0) * a.Kp + kc * CH : zero;
+    const int winc = wrow_ok ? BKE : 0;
+    char* wdst = ring + (16 * wv) * 64;
+#pragma unroll
+    for (int st = 0; st < NSTAGE - 1; ++st) {
+        __builtin_amdgcn_global_load_lds((gptr_t)wptr, (lptr_t)(wdst + st * WSTAGE), 16, 0, 0);
+        wptr += winc;
+    }
+
+    const int wm = wv / WN, wn = wv % WN;
+    const int q = lane >> 4, r = lane & 15;
+    // LDS byte address of this lane's 16-byte operand chunk for (tap column kw, K-chunk cc, pixel tile i), tap row 0
+    int xaddr[3][CSTEPS][MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int pt = (wm * MT + i) * 16 + r;
+        const int ly = pt / TW, lx = pt % TW;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int p0 = ly * PWP + lx + kw;
+            const int sw = patch_swz<CPP>(p0);
+#pragma unroll
+            for (int cc = 0; cc < CSTEPS; ++cc) xaddr[kw][cc][i] = (p0 * CPP + ((cc * 4 + q) ^ sw)) * 16;
+        }
+    }
+    int woff[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) woff[j] = PATCH_BYTES + lds_off(wn * NT * 16 + perm_row<NT>(j, r), q);
+
+    floatx4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    typedef typename Frag<T>::type frag_t;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+#pragma unroll
+            for (int cc = 0; cc < CSTEPS; ++cc) {
+                constexpr int dummy = 0; (void)dummy;
+                const int step = (kh * 3 + kw) * CSTEPS + cc;       // compile-time after unrolling
+                const int cur = step % NSTAGE, nxt = (step + NSTAGE - 1) % NSTAGE;
+                wait_vmcnt<(NSTAGE - 2) * B_PER>();
+                __builtin_amdgcn_s_barrier();
+                {   // refill the stage that step-1 released (zero page once the real K-steps are exhausted)
+                    const T* src = (step + NSTAGE - 1 < NSTEPS) ? wptr : zero;
+                    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(wdst + nxt * WSTAGE), 16, 0, 0);
+                    wptr += winc;
+                }
+                frag_t xf[MT], wf[NT];
+#pragma unroll
+                for (int i = 0; i < MT; ++i) xf[i] = *reinterpret_cast<const frag_t*>(smem + xaddr[kw][cc][i] + kh * ROWB);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) wf[j] = *reinterpret_cast<const frag_t*>(smem + woff[j] + cur * WSTAGE);
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc[i][j] = Frag<T>::mma(wf[j], xf[i], acc[i][j]);
+            }
+        }
+    }
+    wait_vmcnt<0>();
+
+    int mrow[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int pt = (wm * MT + i) * 16 + r;
+        const int oy = oy0 + pt / TW, ox = ox0 + pt % TW;
+        mrow[i] = (oy < a.Ho && ox < a.Wo) ? (img * a.Ho + oy) * a.Wo + ox : -1;
+    }
+    epilogue_dispatch<T, MT, NT, true>(a, acc, mrow, n0 + wn * NT * 16, q);
+}
+
+template <typename T, int MT, int NT, int WM, int WN, int TH, int TW, int NSTAGE, int LGCPP>
+static bool launch_patch(const ConvArgs& a, hipStream_t s) {
+    constexpr int CH = 16 / (int)sizeof(T), NTHR = 64 * WM * WN, RP = NTHR / 4;
+    constexpr int BN = WN * NT * 16, BNP = (BN + RP - 1) / RP * RP;
+    constexpr int CPP = 1 << LGCPP, PAL = CPP >= 8 ? CPP : 8, PWP = (TW + 2 + PAL - 1) / PAL * PAL;
+    constexpr int TOTAL = (TH + 2) * PWP * CPP;
+    constexpr size_t lds = (size_t)(TOTAL + NTHR - 1) / NTHR * NTHR * 16 + (size_t)NSTAGE * BNP * 64;
+    static_assert(lds <= 160 * 1024, "patch does not fit the LDS");
+    if (a.Cin != CPP * CH) return false;
+    const int tiles_x = ceil_div(a.Wo, TW), tiles_y = ceil_div(a.Ho, TH);
+    const int n_img = a.M / (a.Ho * a.Wo);
+    auto kfn = conv3x3_patch_kernel<T, MT, NT, WM, WN, TH, TW, NSTAGE, LGCPP>;
+    static bool attr = false;
+    if (lds > 64 * 1024 && !attr) {
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = true;
+    }
+    dim3 grid(n_img * tiles_x * tiles_y, ceil_div(a.Cout, BN));
+    hipLaunchKernelGGL(kfn, grid, dim3(NTHR), lds, s, a, tiles_x, tiles_y);
+    KCHECK();
+    return true;
+}
+
+// 3x3/s1/p1 with Cin a multiple of the K-step: tile shape by output width.
+template <typename T>
+static bool try_patch(const ConvArgs& a, hipStream_t s) {
+    // Measured on MI355X (profiles/): the patch form wins where Cout is small and M is large (ReID layer1);
+    // for Cout >= 128 the 8-wave im2col tile is faster, and small maps are launch-bound either way.
+    static const bool off = getenv("AICAM_NO_PATCH") != nullptr;
+    static const bool all = getenv("AICAM_PATCH_ALL") != nullptr;
+    static const bool c32 = getenv("AICAM_NO_PATCH_C32") == nullptr;   // Cin = Cout = 32 (YOLOv8n P3 bottlenecks): 244 -> 460 TFLOP/s
+    if (off || a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.Wo < 16 || a.Ho < 8) return false;
+    if (a.M < 200000 && !all) return false;
+    const bool wide = a.Wo % 32 == 0 || (a.Wo % 16 != 0 && a.Wo >= 32);   // 8 x 32 tiles unless 16 x 16 tiles cover the map exactly
+    if (a.Cout == 64) {
+        constexpr int LG64 = sizeof(T) == 2 ? 3 : 4;    // Cin = 64: 8 chunks (fp16) / 16 chunks (fp32) per pixel
+        if (wide) return launch_patch<T, 4, 4, 4, 1, 8, 32, 3, LG64>(a, s);
+        return launch_patch<T, 4, 4, 4, 1, 16, 16, 3, LG64>(a, s);
+    }
+    if (a.Cout == 32 && c32) {
+        constexpr int LG32 = sizeof(T) == 2 ? 2 : 3;    // Cin = 32
+        if (wide) return launch_patch<T, 4, 2, 4, 1, 8, 32, 3, LG32>(a, s);
+        return launch_patch<T, 4, 2, 4, 1, 16, 16, 3, LG32>(a, s);
+    }
+    return false;
+}
+
+bool conv_try_patch(int dtype, const ConvArgs& a, hipStream_t s) {
+    return dtype == AIC_F16 ? try_patch<half_t>(a, s) : try_patch<float>(a, s);
+}
+bool conv_try_c16(const ConvArgs& a, hipStream_t s) { return try_c16(a, s); }
+bool conv_try_c64_resident(const ConvArgs& a, hipStream_t s) { return try_c64_resident(a, s); }
+
+// ------------------------------------------------------------------------------------------------
+// Fused ReID stem: conv 3x3/1 (3 -> 64) + bias + ReLU + max-pool 3x3/2 (pad 1) in one kernel, fp16.
+// The unfused pair writes and re-reads a [N,128,64,64] tensor (1 MB per crop) for 14 MMAC of work;
+// here a block owns 4 pooled rows of one crop: the 11x66 input patch (RGB0) and the 9x64x64 conv
+// tile live in LDS only, K = 27 is padded to one v_mfma_f32_16x16x32_f16 per 16 px x 16 ch tile
+// (the im2col fragment is gathered from the patch), and only the pooled [N,64,32,64] tensor
+// reaches HBM.  PyTorch semantics: conv zero-pads its input, the pool ignores out-of-image taps.
+struct StemArgs {
+    const void* x; const void* w; const float* bias; void* y;
+    int n, H, W, Kp, y_cs, y_coff;   // input [n][H][W][8]; output [n][H/2][W/2][y_cs]
+};
+
+__global__ __launch_bounds__(256) void reid_stem_pool_kernel(const StemArgs a) {
+    constexpr int PT = 4, CR = 2 * PT + 1, IR = 2 * PT + 3, CW = 64, PW = CW + 2, CO = 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint2* patch = reinterpret_cast<uint2*>(smem);                        // [IR][PW] pixels x 4 halves
+    char* convbuf = smem + ((IR * PW * 8 + 15) / 16) * 16;               // [CR][CW] pixels x 128 B (swizzled chunks)
+    const half_t* patch_h = reinterpret_cast<const half_t*>(smem);
+
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, r = lane & 15, q = lane >> 4;
+    const int Hp = a.H / 2, Wp = a.W / 2;
+    const int groups = Hp / PT;
+    const int img = blockIdx.x / groups, rg = blockIdx.x - img * groups;
+    const int oy0 = rg * PT, cr0 = 2 * oy0 - 1, ir0 = cr0 - 1;
+    const half_t* xg = reinterpret_cast<const half_t*>(a.x) + (size_t)img * a.H * a.W * 8;
+
+    for (int idx = t; idx < IR * PW; idx += 256) {
+        const int iy = idx / PW, ix = idx - iy * PW;
+        const int gy = ir0 + iy, gx = ix - 1;
+        uint2 v = make_uint2(0u, 0u);
+        if ((unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W)
+            v = *reinterpret_cast<const uint2*>(xg + ((size_t)gy * a.W + gx) * 8);
+        patch[idx] = v;
+    }
+    // weight fragments (A operand): lane (r, q) of channel tile ct holds w[16ct + r][k = 8q .. 8q+7]
+    const half_t* wg = reinterpret_cast<const half_t*>(a.w);
+    half8 wf[4];
+    int poff[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = 8 * q + j;
+        const int tap = k / 3, ci = k - 3 * tap, kh = tap / 3, kw = tap - 3 * kh;
+        poff[j] = k < 27 ? (kh * PW + kw) * 4 + ci : -1;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+            wf[ct][j] = k < 27 ? wg[(size_t)(16 * ct + r) * a.Kp + tap * 8 + ci] : (half_t)0.f;
+    }
+    floatx4 b4[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) b4[ct] = *reinterpret_cast<const floatx4*>(a.bias + 16 * ct + 4 * q);
+    __syncthreads();
+
+    for (int tile = wv; tile < CR * (CW / 16); tile += 4) {
+        const int cr = tile / (CW / 16), cx = (tile - cr * (CW / 16)) * 16 + r;
+        const int base = (cr * PW + cx) * 4;
+        half8 xf;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xf[j] = poff[j] >= 0 ? patch_h[base + poff[j]] : (half_t)0.f;
+        char* dst = convbuf + (size_t)(cr * CW + cx) * 128 + (q & 1) * 8;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ct], xf, acc, 0, 0, 0);
+            half4 h;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) h[e] = (half_t)fmaxf(acc[e] + b4[ct][e], 0.f);
+            const int chunk = 2 * ct + (q >> 1);                         // 16-byte chunk of the pixel's 64 channels
+            *reinterpret_cast<half4*>(dst + ((chunk ^ (cx & 7)) * 16)) = h;
+        }
+    }
+    __syncthreads();
+
+    half_t* yg = reinterpret_cast<half_t*>(a.y);
+    for (int o = t; o < PT * Wp * (CO / 8); o += 256) {
+        const int g = o & 7, px = (o >> 3) % Wp, py = (o >> 3) / Wp;
+        half8 m;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = (half_t)0.f;                  // post-ReLU values are >= 0
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int cr = 2 * py + dy;
+            if ((unsigned)(cr0 + cr) >= (unsigned)a.H) continue;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int cc = 2 * px - 1 + dx;
+                if ((unsigned)cc >= (unsigned)a.W) continue;
+                const half8 v = *reinterpret_cast<const half8*>(convbuf + (size_t)(cr * CW + cc) * 128 + ((g ^ (cc & 7)) * 16));
+#pragma unroll
+                for (int e = 0; e < 8; ++e) m[e] = v[e] > m[e] ? v[e] : m[e];
+            }
+        }
+        *reinterpret_cast<half8*>(yg + ((size_t)(img * Hp + oy0 + py) * Wp + px) * a.y_cs + a.y_coff + g * 8) = m;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused ReID stem, second form (default): one block = one crop, 8 waves, wave w owns pooled rows [Hp/8*w, +Hp/8).
+//  * K is laid out (tap, RGB0): taps 0..7 = one v_mfma_f32_16x16x32_f16 whose B fragment is two aligned 8-byte
+//    patch pixels per lane, tap 8 = a second one with zero weights outside (q = 0, j < 3): the im2col fragment is
+//    3 ds_read_b64, no scalar gathers (the first form spent 71 VALU per MFMA on them).  [v_mfma_f32_16x16x16_f16
+//    for tap 8 returned stale accumulator halves under hipcc 7.2: the first two results were read too early];
+//  * the bias rides in as the accumulator's initial value, ReLU is a packed fp16 max after the conversion;
+//  * the 3x3/2 max-pool never touches LDS: vertical max of three conv rows in registers (v_pk_max_f16),
+//    horizontal max over lane neighbours by DPP row shifts inside the 16-pixel tile (lane 0 takes pixel 15 of
+//    the tile to its left by row_ror), out-of-image taps are 0 = the identity of max over post-ReLU values;
+//  * with the channel permutation of perm_ch() a lane owns 8 consecutive channels per tile pair; odd lanes take
+//    the second pair of their even neighbour, so one 16-byte store instruction writes 8 pooled pixels x 128 B.
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef short short2_t __attribute__((ext_vector_type(2)));
+// max of packed fp16 pairs as SIGNED 16-bit integers (v_pk_max_i16): exact for the values met here -- non-negative
+// halves order like their bit patterns, and against 0 it is ReLU (any negative half, -0 included, has the sign bit
+// set and loses to 0).  The fp16 form would add a canonicalising v_pk_max_f16 v,v,v per operand.
+__device__ __forceinline__ unsigned pk_max(unsigned a, unsigned b) {
+    const short2_t m = __builtin_elementwise_max(__builtin_bit_cast(short2_t, a), __builtin_bit_cast(short2_t, b));
+    return __builtin_bit_cast(unsigned, m);
+}
+template <int CTRL, bool BOUND> __device__ __forceinline__ unsigned dpp(unsigned old, unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, 0xf, 0xf, BOUND);
+}
+struct Row8 { unsigned u[8]; };   // one pixel's 16 output channels x 2 tile pairs, packed fp16: u[4p + i]
+
+__global__ __launch_bounds__(512) void reid_stem_pool2_kernel(const StemArgs a) {
+    constexpr int CW = 64, PW = CW + 2, NTX = CW / 16;
+    constexpr int ROW_SHL1 = 0x101, ROW_SHR1 = 0x111, ROW_ROR1 = 0x121;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint2* patch = reinterpret_cast<uint2*>(smem);                        // [H + 2][PW] pixels x RGB0 halves, zero border
+
+    const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6), r = lane & 15, q = lane >> 4;
+    const int H = a.H, Hp = H / 2, Wp = CW / 2, rows_per_wave = Hp / 8;
+    const int img = blockIdx.x;
+    const half_t* xg = reinterpret_cast<const half_t*>(a.x) + (size_t)img * H * CW * 8;
+
+    for (int idx = t; idx < (H + 2) * PW; idx += 512) {
+        const int iy = idx / PW, ix = idx - iy * PW;
+        const int gy = iy - 1, gx = ix - 1;
+        uint2 v = make_uint2(0u, 0u);
+        if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)CW) v = *reinterpret_cast<const uint2*>(xg + ((size_t)gy * CW + gx) * 8);
+        patch[idx] = v;
+    }
+
+    // A operands: MFMA row rho of channel tile ct carries channel perm_row<4>(ct, rho); lane (rho = r, q) holds k = 8q..8q+7
+    const half_t* wg = reinterpret_cast<const half_t*>(a.w);
+    half8 wa[4], wb[4];
+    floatx4 bi[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+        const half_t* wr = wg + (size_t)perm_row<4>(ct, r) * a.Kp;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int tap = 2 * q + (j >> 2), ci = j & 3;
+            wa[ct][j] = ci < 3 ? wr[tap * 8 + ci] : (half_t)0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) wb[ct][j] = (q == 0 && j < 3) ? wr[8 * 8 + j] : (half_t)0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bi[ct][e] = a.bias[perm_ch<4>(ct, q, e)];
+    }
+    // patch offsets (in pixels) of this lane's taps relative to (conv row y, tile pixel): taps 2q, 2q+1 and tap 8
+    const int t0 = 2 * q, t1 = 2 * q + 1;
+    const int off0 = (t0 / 3) * PW + t0 % 3 + r, off1 = (t1 / 3) * PW + t1 % 3 + r, off2 = 2 * PW + 2 + r;
+    __syncthreads();
+
+    auto conv_tile = [&](int y, int tx) -> Row8 {   // conv + bias + ReLU of 16 pixels (row y, columns 16tx..) x 64 channels
+        Row8 o;
+        if ((unsigned)y >= (unsigned)H) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o.u[i] = 0u;
+            return o;
+        }
+        const uint2* pp = patch + y * PW + 16 * tx;
+        const uint2 x0 = pp[off0], x1 = pp[off1], x2 = pp[off2];
+        const uint4 xa4 = make_uint4(x0.x, x0.y, x1.x, x1.y), xb4 = make_uint4(x2.x, x2.y, 0u, 0u);
+        const half8 xa = __builtin_bit_cast(half8, xa4), xb = __builtin_bit_cast(half8, xb4);
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            floatx4 acc = bi[ct];
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[ct], xa, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[ct], xb, acc, 0, 0, 0);
+            const half2_t h01 = {(half_t)acc[0], (half_t)acc[1]}, h23 = {(half_t)acc[2], (half_t)acc[3]};
+            o.u[2 * ct] = pk_max(__builtin_bit_cast(unsigned, h01), 0u);
+            o.u[2 * ct + 1] = pk_max(__builtin_bit_cast(unsigned, h23), 0u);
+        }
+        return o;
+    };
+
+    half_t* yg = reinterpret_cast<half_t*>(a.y);
+    const int py0 = wv * rows_per_wave;
+    Row8 prev[NTX];
+#pragma unroll
+    for (int tx = 0; tx < NTX; ++tx) prev[tx] = conv_tile(2 * py0 - 1, tx);
+    for (int py = py0; py < py0 + rows_per_wave; ++py) {
+        Row8 vleft;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) vleft.u[i] = 0u;
+#pragma unroll
+        for (int tx = 0; tx < NTX; ++tx) {
+            const Row8 b = conv_tile(2 * py, tx), c = conv_tile(2 * py + 1, tx);
+            Row8 v, hm;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                v.u[i] = pk_max(pk_max(prev[tx].u[i], b.u[i]), c.u[i]);
+                prev[tx].u[i] = c.u[i];
+                const unsigned rot = dpp<ROW_ROR1, false>(0u, vleft.u[i]);          // lane 0 <- pixel 15 of the tile to the left (0 at tx = 0)
+                const unsigned lf = dpp<ROW_SHR1, false>(rot, v.u[i]);               // lane r <- pixel r-1 (lane 0 keeps rot)
+                const unsigned rt = dpp<ROW_SHL1, true>(0u, v.u[i]);                 // lane r <- pixel r+1 (only even r are used)
+                hm.u[i] = pk_max(pk_max(lf, v.u[i]), rt);
+            }
+            vleft = v;
+            // even lane 2u: pooled pixel 8tx+u, channels of pair 0; odd lane 2u+1: same pixel, pair 1 (taken from lane 2u)
+            uint4 out;
+            unsigned* op = reinterpret_cast<unsigned*>(&out);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const unsigned nb = dpp<ROW_SHR1, true>(0u, hm.u[4 + i]);
+                op[i] = (r & 1) ? nb : hm.u[i];
+            }
+            const size_t pix = ((size_t)img * Hp + py) * Wp + 8 * tx + (r >> 1);
+            *reinterpret_cast<uint4*>(yg + pix * a.y_cs + a.y_coff + (r & 1) * 32 + 8 * q) = out;
+        }
+    }
+}
+
+void launch_reid_stem_pool(const void* x, const void* w, const float* bias, void* y, int n, int H, int W, int Kp, int y_cs,
+                           int y_coff, hipStream_t s) {
+    if (n <= 0) return;
+    StemArgs a{x, w, bias, y, n, H, W, Kp, y_cs, y_coff};
+    static const bool v1 = [] { const char* e = getenv("AICAM_STEM"); return e && e[0] == 'v' && e[1] == '1'; }();
+    const size_t lds2 = (size_t)(H + 2) * 66 * 8;
+    if (!v1 && W == 64 && H % 16 == 0 && lds2 <= 160 * 1024) {
+        static bool attr2 = false;
+        if (!attr2) {
+            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(reid_stem_pool2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr2 = true;
+        }
+        hipLaunchKernelGGL(reid_stem_pool2_kernel, dim3(n), dim3(512), lds2, s, a);
+        KCHECK();
+        return;
+    }
+    const size_t lds = ((11 * 66 * 8 + 15) / 16) * 16 + (size_t)9 * 64 * 128;
+    static bool attr = false;
+    if (!attr) {
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(reid_stem_pool_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = true;
+    }
+    hipLaunchKernelGGL(reid_stem_pool_kernel, dim3(n * (H / 2 / 4)), dim3(256), lds, s, a);
+    KCHECK();
+}
+
+
+}  // namespace aic

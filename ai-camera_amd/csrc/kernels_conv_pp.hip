@@ -1,0 +1,498 @@
+// kernels_conv_pp.hip -- the one-block-per-CU "ping-pong" members of the conv class (v4 im2col, v5 patch): 8 waves,
+// every K-step split into a load and a compute segment, waves 4..7 one barrier behind waves 0..3.
+#include "conv_common.hpp"
+
+namespace aic {
+
+// ------------------------------------------------------------------------------------------------
+// v4 "ping-pong": the v2 tile, operand ring and source-side swizzle, but every K-step is split into a LOAD
+// segment (issue the LDS-DMA of step k+NSTAGE-2, ds_read the fragments of step k) and a COMPUTE segment (the
+// MFMAs of step k), each closed by a raw s_barrier, and waves 4..7 run ONE barrier behind waves 0..3.  Each SIMD
+// hosts one wave of either half, so while one half's MFMAs own the matrix pipe the other half is reading LDS
+// and issuing DMA (MI355X_MICROARCH.md "Two waves per SIMD", cdna_hip_programming.md T3/T5).  In v2 all eight
+// waves leave the barrier together, read together and then fight for the pipe together.
+// Hazards, in program segments (L_k = 2k, C_k = 2k+1; a wave of the late half executes segment s one global
+// barrier after the early half):
+//   RAW  step j is waited for (counted vmcnt) in L_{j-1} and read in L_j: two barriers later, so the late half's
+//        waits have also passed a barrier every reader has passed;
+//   WAR  the ring slot read in L_k (data in registers by C_k) is re-filled by the DMA issued in L_{k+2}: three
+//        segments after the read was issued, hence after the late half's C_k.
+// Needs Cin % K-step == 0 (uniform tap per K-step) and 8 waves; one block per CU (LDS: NSTAGE stages).
+// Optional per-block phase timestamps (100 MHz wall clock) for tools/conv_bench.py: AICAM_PP_TIMES=1.
+__device__ unsigned long long g_pp_times[4 * 4096];
+__device__ int g_pp_times_on;
+#define PP_STAMP(k) do { if (g_pp_times_on && threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 4096) g_pp_times[4 * blockIdx.x + (k)] = wall_clock64(); } while (0)
+
+template <typename T, int MT, int NT, int WM, int WN, int NSTAGE>
+__global__ __launch_bounds__(512) void conv_igemm_pp_kernel(const ConvArgs a) {
+    PP_STAMP(0);
+    constexpr int CH = 16 / (int)sizeof(T);
+    constexpr int BKE = 4 * CH;
+    constexpr int NTHR = 512;
+    constexpr int RP = NTHR / 4;
+    constexpr int BM = WM * MT * 16;
+    constexpr int BN = WN * NT * 16;
+    constexpr int BNP = (BN + RP - 1) / RP * RP;
+    constexpr int A_PER = BM / RP;
+    constexpr int B_PER = BNP / RP;
+    constexpr int LPS = A_PER + B_PER;
+    constexpr int STAGE = (BM + BNP) * 64;
+    static_assert(WM * WN == 8 && BM % RP == 0 && NSTAGE >= 4, "geometry");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int slot = t & 3, r0 = t >> 2;
+    const int kc = slot ^ lds_swz(r0);
+    const int m0 = blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+    const bool late = wv >= 4;
+
+    const T* __restrict__ xg = reinterpret_cast<const T*>(a.x);
+    const T* __restrict__ wg = reinterpret_cast<const T*>(a.w);
+    const T* zero = reinterpret_cast<const T*>(a.zero);
+
+    const T* rowp[A_PER];
+    unsigned vmask[A_PER];
+    const int HoWo = a.Ho * a.Wo;
+    const int ntap = a.KH * a.KW;
+    const float inv_howo = 1.0f / (float)HoWo, inv_wo = 1.0f / (float)a.Wo;
+#pragma unroll
+    for (int i = 0; i < A_PER; ++i) {
+        const int m = m0 + r0 + RP * i;
+        unsigned mk = 0;
+        const T* rp = zero;
+        if (m < a.M) {
+            int img, rem, oh, ow;
+            fast_divmod(m, HoWo, inv_howo, img, rem);
+            fast_divmod(rem, a.Wo, inv_wo, oh, ow);
+            const int ih0 = oh * a.stride - a.pad, iw0 = ow * a.stride - a.pad;
+            rp = xg + (((long)img * a.H + ih0) * a.W + iw0) * a.x_cs + a.x_coff;
+            const int lo_w = max(0, -iw0), hi_w = min(a.KW, a.W - iw0);
+            const int lo_h = max(0, -ih0), hi_h = min(a.KH, a.H - ih0);
+            if (hi_w > lo_w && hi_h > lo_h) {
+                const unsigned vw = ((1u << hi_w) - 1u) & ~((1u << lo_w) - 1u);
+                const unsigned rows = (((1u << (hi_h * a.KW)) - 1u) & ~((1u << (lo_h * a.KW)) - 1u)) & a.tap_rows;
+                mk = vw * rows;
+            }
+        }
+        rowp[i] = rp;
+        vmask[i] = mk;
+    }
+    const int nsteps = a.Kp / BKE;
+    const int wm = wv / WN, wn = wv % WN;
+    const int q = lane >> 4, r = lane & 15;
+
+    floatx4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    int xoff[MT], woff[NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) xoff[i] = lds_off((wm * MT + i) * 16 + r, q);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) woff[j] = BM * 64 + lds_off(wn * NT * 16 + perm_row<NT>(j, r), q);
+    typedef typename Frag<T>::type frag_t;
+    char* const sdst = smem + (16 * wv) * 64;
+
+    const int csteps = a.Cin / BKE;
+    const T* aptr[A_PER];
+    int ainc[A_PER];
+    const T* wptr[B_PER];
+    int winc[B_PER];
+#pragma unroll
+    for (int j = 0; j < B_PER; ++j) {
+        const bool okr = r0 + RP * j < BN;
+        wptr[j] = okr ? wg + (size_t)(n0 + r0 + RP * j) * a.Kp + kc * CH : zero;
+        winc[j] = okr ? BKE : 0;
+    }
+    int tap = 0, kh = 0, kw = 0, cc = 0;
+    auto set_tap = [&] {
+        const long toff = ((long)kh * a.W + kw) * a.x_cs + kc * CH;
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) {
+            const bool ok = tap < ntap && ((vmask[i] >> (tap & 31)) & 1u);
+            aptr[i] = ok ? rowp[i] + toff : zero;
+            ainc[i] = ok ? BKE : 0;
+        }
+    };
+    set_tap();
+    auto issue = [&](int stage) {
+        char* sbase = sdst + stage * STAGE;
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) {
+            __builtin_amdgcn_global_load_lds((gptr_t)aptr[i], (lptr_t)(sbase + i * (RP * 64)), 16, 0, 0);
+            aptr[i] += ainc[i];
+        }
+#pragma unroll
+        for (int j = 0; j < B_PER; ++j) {
+            __builtin_amdgcn_global_load_lds((gptr_t)wptr[j], (lptr_t)(sbase + BM * 64 + j * (RP * 64)), 16, 0, 0);
+            wptr[j] += winc[j];
+        }
+        if (++cc == csteps) {
+            cc = 0;
+            ++tap;
+            if (++kw == a.KW) { kw = 0; ++kh; }
+            set_tap();
+        }
+    };
+#pragma unroll
+    for (int st = 0; st < NSTAGE - 2; ++st) issue(st);
+    wait_vmcnt<(NSTAGE - 3) * LPS>();          // step 0 has landed (this wave's part)
+    __builtin_amdgcn_s_barrier();              // ... everyone's
+    PP_STAMP(1);
+    if (late) __builtin_amdgcn_s_barrier();    // waves 4..7 now run one segment behind
+
+    for (int step0 = 0; step0 < nsteps; step0 += NSTAGE) {
+#pragma unroll
+        for (int u = 0; u < NSTAGE; ++u) {
+            if (step0 + u < nsteps) {
+                // ---- LOAD segment
+                issue((u + NSTAGE - 2) % NSTAGE);
+                const char* base = smem + u * STAGE;
+                frag_t xf[MT], wf[NT];
+#pragma unroll
+                for (int j = 0; j < NT; ++j) wf[j] = *reinterpret_cast<const frag_t*>(base + woff[j]);
+#pragma unroll
+                for (int i = 0; i < MT; ++i) xf[i] = *reinterpret_cast<const frag_t*>(base + xoff[i]);
+                wait_vmcnt<(NSTAGE - 3) * LPS>();      // step+1 has landed (this wave's part)
+                __builtin_amdgcn_s_barrier();
+                // ---- COMPUTE segment
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc[i][j] = Frag<T>::mma(wf[j], xf[i], acc[i][j]);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+            }
+        }
+    }
+    if (!late) __builtin_amdgcn_s_barrier();   // every wave executes the same number of barriers
+    wait_vmcnt<0>();
+    PP_STAMP(2);
+
+    int mrow[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int m = m0 + (wm * MT + i) * 16 + r;
+        mrow[i] = m < a.M ? m : -1;
+    }
+    epilogue_dispatch<T, MT, NT, true>(a, acc, mrow, n0 + wn * NT * 16, q);
+    if (g_pp_times_on) { wait_vmcnt<0>(); PP_STAMP(3); }
+}
+
+static void pp_times_report(hipStream_t s, int nblk) {
+    static std::vector<unsigned long long> h(4 * 4096);
+    HIP_CHECK(hipStreamSynchronize(s));
+    HIP_CHECK(hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_pp_times), sizeof(unsigned long long) * 4 * 4096));
+    nblk = std::min(nblk, 4096);
+    unsigned long long t0 = ~0ull, t3 = 0;
+    double d[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
+    for (int b = 0; b < nblk; ++b) {
+        t0 = std::min(t0, h[4 * b]);
+        t3 = std::max(t3, h[4 * b + 3]);
+        for (int k = 0; k < 3; ++k) {
+            const double v = (double)(h[4 * b + k + 1] - h[4 * b + k]) * 0.01;
+            d[k] += v / nblk;
+            mx[k] = std::max(mx[k], v);
+        }
+    }
+    double start_spread = 0, end_spread = 0;
+    for (int b = 0; b < nblk; ++b) {
+        start_spread = std::max(start_spread, (double)(h[4 * b] - t0) * 0.01);
+        end_spread = std::max(end_spread, (double)(t3 - h[4 * b + 3]) * 0.01);
+    }
+    fprintf(stderr, "[pp_times] blocks %d: prologue %.2f (max %.2f) us, k-loop %.2f (max %.2f), epilogue+drain %.2f (max %.2f); first start -> last end %.2f us; start spread %.2f, end spread %.2f\n",
+            nblk, d[0], mx[0], d[1], mx[1], d[2], mx[2], (double)(t3 - t0) * 0.01, start_spread, end_spread);
+}
+
+template <typename T, int MT, int NT, int WM, int WN, int NSTAGE>
+static void launch_pp(const ConvArgs& a, hipStream_t s) {
+    constexpr int RP = 128;
+    constexpr int BM = WM * MT * 16, BN = WN * NT * 16, BNP = (BN + RP - 1) / RP * RP;
+    dim3 grid(ceil_div(a.M, BM), ceil_div(a.Cout, BN));
+    constexpr size_t lds = (size_t)NSTAGE * (BM + BNP) * 64;
+    static_assert(lds <= 160 * 1024, "ring does not fit the LDS");
+    auto kfn = conv_igemm_pp_kernel<T, MT, NT, WM, WN, NSTAGE>;
+    static bool attr = false;
+    if (!attr) {
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = true;
+    }
+    static const bool times = getenv("AICAM_PP_TIMES") != nullptr;
+    if (times) {
+        const int on = 1;
+        HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_pp_times_on), &on, sizeof(int)));
+    }
+    hipLaunchKernelGGL(kfn, grid, dim3(512), lds, s, a);
+    KCHECK();
+    if (times) pp_times_report(s, (int)grid.x);
+}
+
+// ------------------------------------------------------------------------------------------------
+// v5 "ping-pong patch" for 3x3 / stride 1 / pad 1 with Cin a multiple of the K-step: the v4 schedule (load / compute
+// segments, late half one barrier behind, NSTAGE-deep weight ring), but the pixel operand no longer travels as an
+// im2col tile (every input chunk fetched 9x through L2 -> LDS: 80 % of v4's LDS-DMA bytes on ReID layer2).  K is walked
+// (channel chunk, tap): for one chunk of BKE input channels the (TH+2) x (TW+2) halo patches of the tile's NI images
+// sit in LDS and the nine taps are ds_read at shifted addresses; the next chunk's patch streams into the second
+// buffer one LDS-DMA per thread per K-step while this one is consumed.
+//  * patch image: four PLANES (one per 16-byte K sub-chunk q), plane q holds chunk q of every patch pixel at
+//    pixel*16: a lane group (16 consecutive pixels, fixed q) reads 256 contiguous bytes -- conflict-free with no
+//    swizzle -- and the tap shift (kh*PW + kw)*16 is a ds_read immediate: ONE address register per pixel tile;
+//  * LDS-DMA stays lane-linear: wave w of a pass writes plane w&3, 64 consecutive pixels;
+//  * every L segment issues exactly B_PER weight loads + 1 patch load (a zero-page load into a dummy slot when no
+//    patch pass is due), so the counted vmcnt of v4 is unchanged.
+// Hazards (segments as in v4): patch passes of chunk c+1 are issued in L_{9c+1} .. L_{9c+NPASS} (NPASS <= 7): the
+// buffer was last read in L_{9c-1} (WAR: 4 segments), and the last pass is waited for in L_{9c+8}, read in L_{9c+9}.
+template <typename T, int MT, int NT, int WM, int WN, int TH, int TW, int NSTAGE>
+__global__ __launch_bounds__(512) void conv3x3_pp_patch_kernel(const ConvArgs a, int tiles_x, int tiles_y) {
+    constexpr int CH = 16 / (int)sizeof(T);
+    constexpr int BKE = 4 * CH;
+    constexpr int RP = 128;
+    constexpr int BM = WM * MT * 16;
+    constexpr int BN = WN * NT * 16;
+    constexpr int BNP = (BN + RP - 1) / RP * RP;
+    constexpr int B_PER = BNP / RP;
+    constexpr int LPS = B_PER + 1;
+    constexpr int TPIX = TH * TW, NI = BM / TPIX;
+    constexpr int PW = TW + 2, PH = TH + 2, IPIX = PW * PH, NPIX = NI * IPIX;
+    constexpr int NPASS = (NPIX + 127) / 128, NPIXP = NPASS * 128;
+    constexpr int PLANE = NPIXP * 16, PBUF = 4 * PLANE, DUMMY = 8192, WSTAGE = BNP * 64;
+    constexpr int RING = 2 * PBUF + DUMMY;
+    static_assert(WM * WN == 8 && BM % TPIX == 0 && NPASS <= 11 - NSTAGE && TW % 4 == 0 && NSTAGE >= 4, "geometry");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const bool late = wv >= 4;
+    int bx = blockIdx.x;
+    const int tx = bx % tiles_x; bx /= tiles_x;
+    const int ty = bx % tiles_y;
+    const int img0 = (bx / tiles_y) * NI;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int n0 = blockIdx.y * BN;
+    const int n_img = a.M / (a.Ho * a.Wo);
+
+    const T* __restrict__ xg = reinterpret_cast<const T*>(a.x);
+    const T* __restrict__ wg = reinterpret_cast<const T*>(a.w);
+    const T* zero = reinterpret_cast<const T*>(a.zero);
+
+    // ---- patch passes: pass i, wave w -> plane w&3, pixels i*128 + (w>>2)*64 + lane
+    const int plane = wv & 3;
+    int poff[NPASS];                       // element offset of this thread's chunk at channel chunk 0, or -1 (zero page)
+#pragma unroll
+    for (int i = 0; i < NPASS; ++i) {
+        const int p = i * 128 + (wv >> 2) * 64 + lane;
+        const int il = p / IPIX, rem = p - il * IPIX;
+        const int py = rem / PW, px = rem - py * PW;
+        const int img = img0 + il, iy = oy0 + py - 1, ix = ox0 + px - 1;
+        const bool ok = p < NPIX && img < n_img && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        poff[i] = ok ? (((img * a.H + iy) * a.W + ix) * a.x_cs + a.x_coff + plane * CH) : -1;
+    }
+    char* const pdst = smem + plane * PLANE + (wv >> 2) * 1024;     // + buffer*PBUF + pass*2048 (+ lane*16 by the DMA)
+    auto issue_patch = [&](int i, int buf, int chunk_off) {        // i: compile-time pass index
+        const T* src = poff[i] >= 0 ? xg + poff[i] + chunk_off : zero;
+        asm volatile("" : "+v"(src));
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(pdst + buf * PBUF + i * 2048), 16, 0, 0);
+    };
+    auto issue_dummy = [&] {
+        const T* src = zero;
+        asm volatile("" : "+v"(src));
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + 2 * PBUF + wv * 1024), 16, 0, 0);
+    };
+
+    // ---- weight stream: row r0 + RP*j of the block's channel tile, K offset of step (chunk c, tap) = tap*Cin + c*BKE
+    const int slot = t & 3, r0 = t >> 2;
+    const int kc = slot ^ lds_swz(r0);
+    int wofs[B_PER];                          // element offset of this thread's weight chunk at K = 0, or -1 (zero page)
+#pragma unroll
+    for (int j = 0; j < B_PER; ++j) wofs[j] = (r0 + RP * j < BN) ? (n0 + r0 + RP * j) * a.Kp + kc * CH : -1;
+    const int nchunks = a.Cin / BKE, nsteps = 9 * nchunks;
+    char* const wdst = smem + RING + (16 * wv) * 64;
+    int is_c = 0, is_tap = 0, is_k = 0, is_st = 0;   // the step whose weights are fetched next (and its ring stage)
+    auto issue_w = [&] {
+        const int koff = is_tap * a.Cin + is_c * BKE;
+        char* sbase = wdst + is_st * WSTAGE;
+#pragma unroll
+        for (int j = 0; j < B_PER; ++j) {
+            const T* src = (wofs[j] >= 0 && is_k < nsteps) ? wg + wofs[j] + koff : zero;
+            asm volatile("" : "+v"(src));
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sbase + j * (RP * 64)), 16, 0, 0);
+        }
+        ++is_k;
+        if (++is_st == NSTAGE) is_st = 0;
+        if (++is_tap == 9) { is_tap = 0; ++is_c; }
+    };
+
+    const int wm = wv / WN, wn = wv % WN;
+    const int q = lane >> 4, r = lane & 15;
+    // LDS byte address of (this lane's pixel of tile 0, tap (0,0)) in buffer 0; tile i sits a compile-time distance away
+    // because a wave's MT*16 pixels either tile whole images or lie inside one (static_assert below)
+    static_assert((MT * 16) % TPIX == 0 || TPIX % (MT * 16) == 0, "a wave's pixels must not straddle images irregularly");
+    static_assert(TW % 16 == 0 || 16 % TW == 0, "a 16-pixel MFMA tile is whole rows or a piece of one row");
+    auto patch_pix = [](int m) constexpr { return (m / TPIX) * IPIX + ((m % TPIX) / TW) * PW + (m % TPIX) % TW; };
+    int xa0;
+    {
+        const int ml = wm * MT * 16 + r;
+        const int il = ml / TPIX, rem = ml - il * TPIX;
+        const int ly = rem / TW, lx = rem - ly * TW;
+        xa0 = q * PLANE + (il * IPIX + ly * PW + lx) * 16;
+    }
+    // weight fragment addresses: tiles j and j+2 are 32 rows (2048 B) apart, j and j+1 differ in the swizzle term
+    int woff2[2];
+#pragma unroll
+    for (int j = 0; j < 2 && j < NT; ++j) woff2[j] = RING + lds_off(wn * NT * 16 + perm_row<NT>(j, r), q);
+    static_assert(NT % 2 == 0, "tile pairs");
+
+    floatx4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+    typedef typename Frag<T>::type frag_t;
+
+    // ---- prologue: patch chunk 0, weights of steps 0 and 1
+#pragma unroll
+    for (int i = 0; i < NPASS; ++i) issue_patch(i, 0, 0);
+#pragma unroll
+    for (int st = 0; st < NSTAGE - 2; ++st) {
+        issue_w();
+        if (st) issue_dummy();                 // every set in flight has LPS loads: the counted waits below rely on it
+    }
+    wait_vmcnt<(NSTAGE - 3) * LPS>();          // patch chunk 0 and the weights of step 0 have landed (this wave's part)
+    __builtin_amdgcn_s_barrier();
+    if (late) __builtin_amdgcn_s_barrier();
+
+    int rd_st = 0;                             // ring stage of the step being computed
+    auto chunk = [&](int c, auto bufc) {       // bufc: compile-time parity of the patch buffer read in this chunk
+        constexpr int BUF = decltype(bufc)::value;
+        const bool more = c + 1 < nchunks;
+        const int noff = (c + 1) * BKE;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            // ---- LOAD segment
+            issue_w();
+            if (tap >= 1 && tap <= NPASS && more) issue_patch(tap >= 1 && tap <= NPASS ? tap - 1 : 0, BUF ^ 1, noff);
+            else issue_dummy();
+            const int so = rd_st * WSTAGE;
+            if (++rd_st == NSTAGE) rd_st = 0;
+            const int tapoff = BUF * PBUF + ((tap / 3) * PW + tap % 3) * 16;
+            frag_t xf[MT], wf[NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) wf[j] = *reinterpret_cast<const frag_t*>(smem + woff2[j & 1] + so + (j >> 1) * 2048);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) xf[i] = *reinterpret_cast<const frag_t*>(smem + xa0 + tapoff + patch_pix(16 * i) * 16);
+            wait_vmcnt<(NSTAGE - 3) * LPS>();
+            __builtin_amdgcn_s_barrier();
+            // ---- COMPUTE segment
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = Frag<T>::mma(wf[j], xf[i], acc[i][j]);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+        }
+    };
+    for (int c = 0; c < nchunks; c += 2) {     // Cin / BKE is even for every layer that reaches this kernel
+        chunk(c, std::integral_constant<int, 0>{});
+        chunk(c + 1, std::integral_constant<int, 1>{});
+    }
+    if (!late) __builtin_amdgcn_s_barrier();
+    wait_vmcnt<0>();
+
+    int mrow[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int ml = (wm * MT + i) * 16 + r;
+        const int il = ml / TPIX, rem = ml - il * TPIX;
+        const int ly = rem / TW, lx = rem - ly * TW;
+        const int img = img0 + il;
+        mrow[i] = img < n_img ? (img * a.Ho + oy0 + ly) * a.Wo + ox0 + lx : -1;
+    }
+    epilogue_dispatch<T, MT, NT, true>(a, acc, mrow, n0 + wn * NT * 16, q);
+}
+
+template <typename T, int MT, int NT, int WM, int WN, int TH, int TW, int NSTAGE>
+static bool launch_pp_patch(const ConvArgs& a, hipStream_t s) {
+    constexpr int BM = WM * MT * 16, BN = WN * NT * 16, BNP = (BN + 127) / 128 * 128;
+    constexpr int NI = BM / (TH * TW), NPIX = NI * (TH + 2) * (TW + 2), NPASS = (NPIX + 127) / 128;
+    constexpr size_t lds = (size_t)2 * 4 * NPASS * 128 * 16 + 8192 + (size_t)NSTAGE * BNP * 64;
+    static_assert(lds <= 160 * 1024, "does not fit the LDS");
+    if (a.H % TH || a.W % TW || a.Ho != a.H || a.Wo != a.W) return false;
+    const int tiles_x = a.W / TW, tiles_y = a.H / TH;
+    const int n_img = a.M / (a.Ho * a.Wo);
+    auto kfn = conv3x3_pp_patch_kernel<T, MT, NT, WM, WN, TH, TW, NSTAGE>;
+    static bool attr = false;
+    if (!attr) {
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = true;
+    }
+    dim3 grid(ceil_div(n_img, NI) * tiles_x * tiles_y, ceil_div(a.Cout, BN));
+    hipLaunchKernelGGL(kfn, grid, dim3(512), lds, s, a, tiles_x, tiles_y);
+    KCHECK();
+    return true;
+}
+
+// 3x3/s1/p1 layers whose map tiles exactly: pick the tile by map shape and Cout (ReID layer1..4 shapes and their multiples).
+template <typename T>
+static bool try_pp_patch(const ConvArgs& a, hipStream_t s) {
+    // bit 0: Cout 64 (slower than the 4-wave patch kernel: 16 MFMAs per segment), 1: Cout 128, 2: Cout % 256, 3: deeper ring (no gain)
+    static const int mode = [] { const char* e = getenv("AICAM_PPP"); return e ? atoi(e) : 6; }();
+    static const int pp_min = [] { const char* e = getenv("AICAM_PP_MIN"); return e ? atoi(e) : 200; }();
+    constexpr int BKE = 64 / (int)sizeof(T);
+    if (!mode || a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.Cin % (2 * BKE)) return false;
+    if ((long)a.M * a.x_cs >= (1l << 31)) return false;                       // 32-bit element offsets inside the kernel
+    const int c = a.Cout;
+    const bool deep = mode & 8;
+    if (c == 64 && (mode & 1) && a.M / 512 >= pp_min) return deep ? launch_pp_patch<T, 4, 4, 8, 1, 16, 32, 6>(a, s) : launch_pp_patch<T, 4, 4, 8, 1, 16, 32, 4>(a, s);
+    if (c == 128 && (mode & 2) && a.M / 512 >= pp_min) return deep ? launch_pp_patch<T, 8, 4, 4, 2, 32, 16, 6>(a, s) : launch_pp_patch<T, 8, 4, 4, 2, 32, 16, 4>(a, s);
+    if (c % 256 == 0 && (mode & 4) && (long)(a.M / 256) * (c / 256) >= pp_min) {
+        if (a.H % 16 == 0 && a.W % 8 == 0) return deep ? launch_pp_patch<T, 8, 4, 2, 4, 16, 8, 6>(a, s) : launch_pp_patch<T, 8, 4, 2, 4, 16, 8, 4>(a, s);
+        return deep ? launch_pp_patch<T, 8, 4, 2, 4, 8, 4, 5>(a, s) : launch_pp_patch<T, 8, 4, 2, 4, 8, 4, 4>(a, s);
+    }
+    return false;
+}
+
+
+bool conv_try_pp_patch(int dtype, const ConvArgs& a, hipStream_t s) {
+    return dtype == AIC_F16 ? try_pp_patch<half_t>(a, s) : try_pp_patch<float>(a, s);
+}
+
+// Ping-pong kernels (one block per CU) where the K loop is long enough to amortise the tile's prologue/epilogue:
+// measured on MI355X (tools/conv_bench.py, profiles/): +17..19% on ReID layer3/4, +14% on layer2, a loss at K < 512.
+template <typename T>
+static bool try_pp(const ConvArgs& a, hipStream_t s) {
+    static const bool pp = getenv("AICAM_NO_PP") == nullptr;
+    static const int pp_min = [] { const char* e = getenv("AICAM_PP_MIN"); return e ? atoi(e) : 200; }();
+    static const int pp128_k = [] { const char* e = getenv("AICAM_PP128_K"); return e ? atoi(e) : 32; }();
+    constexpr int BKE_ = 64 / (int)sizeof(T);
+    const int c = a.Cout;
+    if (!pp || a.Cin % BKE_ != 0 || !(a.Kp >= 16 * BKE_ || pp_min == 0)) return false;
+    if (c % 256 == 0 && (long)ceil_div(a.M, 256) * (c / 256) >= pp_min) {                                  // 256 px x 256 ch
+        launch_pp<T, 8, 4, 2, 4, 4>(a, s);
+        return true;
+    }
+    if (c == 128 && (a.Kp >= pp128_k * BKE_ || pp_min == 0) && ceil_div(a.M, 512) >= pp_min) {              // 512 px x 128 ch
+        launch_pp<T, 8, 4, 4, 2, 4>(a, s);
+        return true;
+    }
+    return false;
+}
+
+bool conv_try_pp(int dtype, const ConvArgs& a, hipStream_t s) {
+    return dtype == AIC_F16 ? try_pp<half_t>(a, s) : try_pp<float>(a, s);
+}
+
+}  // namespace aic
