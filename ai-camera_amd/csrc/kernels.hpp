@@ -114,6 +114,9 @@ void launch_trk_assoc(float* mean, float* cov, const int* slots, int t, int do_p
                       const float* det_xyah, int n, float* app, float* d2, float* iouc, hipStream_t s);
 void launch_cosine_min_mfma(const float* gal_n, const int* slots, const int* glen, int t, int gmax, int dim, const float* det_n,
                             const unsigned char* has_feat, int n, float* cost, hipStream_t s);
+void launch_trk_assoc_all(float* mean, float* cov, const int* slots, const int* glen, int t, int do_predict, const float* det_tlwh,
+                          const float* det_xyah, const float* gal_n, int gmax, int dim, const float* det_n,
+                          const unsigned char* has_feat, int n, float* app, float* d2, float* iouc, hipStream_t s);
 void launch_trk_commit(float* mean, float* cov, const int* lists, int M, int U, int A, const float* xyah, float* out_tlwh,
                        float* gal_raw, float* gal_n, int gmax, int dim, const float* feat, const float* feat_n, hipStream_t s);
 

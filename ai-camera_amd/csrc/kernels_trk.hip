@@ -471,6 +471,146 @@ __global__ __launch_bounds__(256) void cosine_min_mfma_kernel(const float* __res
     }
 }
 
+// trk_assoc_all_kernel: ONE launch per frame for everything the host association needs about track t (one 512-thread
+// block per track): the lazy Kalman predict + squared Mahalanobis + IoU rows of trk_assoc_kernel (waves 0..1) and the
+// appearance row of cosine_min_mfma_kernel -- wave w takes the 16-row gallery slices w, w+8, ... and the per-slice minima
+// meet in LDS instead of atomicMin, so the three rows are plain stores and may go STRAIGHT to pinned host memory: no
+// init pass, no second launch, no device-to-host blit on the per-frame chain.  Same arithmetic, bit for bit.
+__global__ __launch_bounds__(512) void trk_assoc_all_kernel(float* mean, float* cov, const int* __restrict__ slots,
+                                                            const int* __restrict__ glen, int do_predict,
+                                                            const float* __restrict__ det_tlwh, const float* __restrict__ det_xyah,
+                                                            const float* __restrict__ gal_n, int gmax, int dim,
+                                                            const float* __restrict__ det_n, const unsigned char* __restrict__ has_feat,
+                                                            int n, float* app, float* d2, float* iouc) {
+    extern __shared__ float red[];                     // [8][n] per-wave minima
+    const int t = blockIdx.x;
+    const int slot = slots[t];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    float* P = cov + (size_t)slot * 64;
+    float* m = mean + (size_t)slot * 8;
+    if (do_predict && threadIdx.x < 64) {
+        const int i = lane >> 3, j = lane & 7;
+        const float h = m[3];
+        float t1 = P[i * 8 + j];
+        if (j < 4) t1 = t1 + P[i * 8 + j + 4];
+        float t2 = t1;
+        if (i < 4) {
+            float u = P[(i + 4) * 8 + j];
+            if (j < 4) u = u + P[(i + 4) * 8 + j + 4];
+            t2 = t1 + u;
+        }
+        if (i == j) t2 = t2 + q_diag(i, h);
+        float mi = 0.f;
+        if (j == 0) { mi = m[i]; if (i < 4) mi = mi + m[i + 4]; }
+        P[i * 8 + j] = t2;
+        if (j == 0) m[i] = mi;
+    }
+    // ---- appearance: per-wave minima over this wave's gallery slices
+    const int len = (gal_n != nullptr && dim > 0) ? glen[t] : 0;
+    for (int j = lane; j < n; j += 64) red[wv * n + j] = 3.0e38f;
+    if (len > 0) {
+        unsigned int dummy = 0; (void)dummy;
+        for (int g0 = wv * 16; g0 < len; g0 += 128) {
+            const float* grow = gal_n + ((size_t)slot * gmax + min(g0 + r, len - 1)) * dim;
+            for (int d0 = 0; d0 < n; d0 += 32) {
+                const int da = d0 + r, db = d0 + 16 + r;
+                const float* pa = det_n + (size_t)min(da, n - 1) * dim;
+                const float* pb = det_n + (size_t)min(db, n - 1) * dim;
+                floatx4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+                int k0 = 0;
+                for (; k0 + 64 <= dim; k0 += 64) {
+                    floatx4 a[4], b0[4], b1[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int k = k0 + 16 * u + 4 * q;
+                        a[u] = *reinterpret_cast<const floatx4*>(grow + k);
+                        b0[u] = *reinterpret_cast<const floatx4*>(pa + k);
+                        b1[u] = *reinterpret_cast<const floatx4*>(pb + k);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][e], b0[u][e], acc0, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][e], b1[u][e], acc1, 0, 0, 0);
+                        }
+                }
+                for (; k0 < dim; k0 += 16) {
+                    const int k = k0 + 4 * q;
+                    floatx4 a = {0.f, 0.f, 0.f, 0.f}, b0 = a, b1 = a;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (k + e < dim) { a[e] = grow[k + e]; b0[e] = pa[k + e]; b1[e] = pb[k + e]; }
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b0[e], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b1[e], acc1, 0, 0, 0);
+                    }
+                }
+                float m0 = 3.0e38f, m1 = 3.0e38f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (g0 + 4 * q + e < len) {
+                        float x0 = 1.0f - acc0[e], x1 = 1.0f - acc1[e];
+                        x0 = x0 > 0.f ? x0 : 0.f;
+                        x1 = x1 > 0.f ? x1 : 0.f;
+                        m0 = fminf(m0, x0);
+                        m1 = fminf(m1, x1);
+                    }
+                }
+                m0 = fminf(m0, __shfl_xor(m0, 16)); m0 = fminf(m0, __shfl_xor(m0, 32));
+                m1 = fminf(m1, __shfl_xor(m1, 16)); m1 = fminf(m1, __shfl_xor(m1, 32));
+                if (q == 0) {                       // this wave owns red[wv][*]: no race across its own slices
+                    if (da < n) red[wv * n + da] = fminf(red[wv * n + da], m0);
+                    if (db < n) red[wv * n + db] = fminf(red[wv * n + db], m1);
+                }
+            }
+        }
+    }
+    __syncthreads();   // predict's global writes and every wave's minima are visible to the whole block
+    for (int j = threadIdx.x; j < n; j += blockDim.x) {
+        float v = 1e5f;                              // INFTY_COST (matching.py:148,175): empty gallery / featureless detection
+        if (len > 0 && (!has_feat || has_feat[j])) {
+            float mn = red[j];
+#pragma unroll
+            for (int w = 1; w < 8; ++w) mn = fminf(mn, red[w * n + j]);
+            v = mn;
+        }
+        app[(size_t)t * n + j] = v;
+    }
+    // ---- gating distance + IoU rows (trk_assoc_kernel, threads 0..127)
+    if (threadIdx.x < 128) {
+        float S[4][4], L[4][4];
+        innovation_cov(P, m[3], S);
+        const bool ok = cholesky<4>(S, L);
+        float bw = 0.f, bh = m[3];
+        if (bh > 0.f) bw = m[2] * bh; else bh = fmaxf(0.f, bh);
+        const float bx = m[0] - bw / 2.0f, by = m[1] - bh / 2.0f;
+        const float brx = bx + bw, bry = by + bh;
+        for (int j = threadIdx.x; j < n; j += 128) {
+            const float* z = det_xyah + (size_t)j * 4;
+            float d[4], y[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) d[a] = z[a] - m[a];
+            fwd_solve<4>(L, d, y);
+            float acc = y[0] * y[0];
+            acc = acc + y[1] * y[1];
+            acc = acc + y[2] * y[2];
+            acc = acc + y[3] * y[3];
+            const size_t o = (size_t)t * n + j;
+            d2[o] = ok ? acc : __builtin_inff();
+            const float* c = det_tlwh + (size_t)j * 4;
+            const float crx = c[0] + c[2], cry = c[1] + c[3];
+            const float iw = fmaxf(0.f, fminf(brx, crx) - fmaxf(bx, c[0]));
+            const float ih = fmaxf(0.f, fminf(bry, cry) - fmaxf(by, c[1]));
+            const float inter = iw * ih;
+            const float uni = bw * bh + c[2] * c[3] - inter;
+            iouc[o] = 1.0f - inter / fmaxf(uni, 1e-7f);
+        }
+    }
+}
+
 // trk_commit_kernel: one wavefront-sized block per work item, three roles by block index:
 //   [0, M)        Kalman update of a matched track (kalman_filter.py:153-204) + its new tlwh
 //   [M, M+U)      initiate a new track (kalman_filter.py:55-83)
@@ -636,6 +776,14 @@ void launch_cosine_min_mfma(const float* gal_n, const int* slots, const int* gle
                             const unsigned char* has_feat, int n, float* cost, hipStream_t s) {
     if (t <= 0 || n <= 0 || gmax <= 0) return;
     hipLaunchKernelGGL(cosine_min_mfma_kernel, dim3(t, ceil_div(gmax, 64)), dim3(256), 0, s, gal_n, slots, glen, gmax, dim, det_n, has_feat, n, cost);
+    KCHECK();
+}
+void launch_trk_assoc_all(float* mean, float* cov, const int* slots, const int* glen, int t, int do_predict, const float* det_tlwh,
+                          const float* det_xyah, const float* gal_n, int gmax, int dim, const float* det_n,
+                          const unsigned char* has_feat, int n, float* app, float* d2, float* iouc, hipStream_t s) {
+    if (t <= 0 || n <= 0) return;
+    hipLaunchKernelGGL(trk_assoc_all_kernel, dim3(t), dim3(512), (size_t)8 * n * sizeof(float), s, mean, cov, slots, glen, do_predict,
+                       det_tlwh, det_xyah, gal_n, gmax, dim, det_n, has_feat, n, app, d2, iouc);
     KCHECK();
 }
 void launch_trk_commit(float* mean, float* cov, const int* lists, int M, int U, int A, const float* xyah, float* out_tlwh,

@@ -230,16 +230,25 @@ void Tracker::update(const float* det_tlwh, const float* conf, const int32_t* cl
         const size_t tn = (size_t)T * n;
         d_cost.ensure(3 * tn);
         h_cost.ensure(3 * tn);
+        static const bool fused = getenv("AICAM_TRK_SPLIT") == nullptr;   // one launch per frame; AICAM_TRK_SPLIT=1: the two-kernel form
         {
             Prof pr(*dev, PROF_TRK, s, any_feat ? 2.0 * T * gmax * (double)n * dim : 0.0,
                     any_feat ? ((double)T * gmax + n) * dim * 4 : 0.0);
-            launch_trk_assoc(d_mean.p, d_cov.p, d_slots, T, pending_predict ? 1 : 0, d_tl, d_xy, n, d_cost.p, d_cost.p + tn,
-                             d_cost.p + 2 * tn, s);
-            pending_predict = false;
-            if (any_feat && dim > 0)
-                launch_cosine_min_mfma(d_gal_n.p, d_slots, d_glen, T, gmax, dim, d_featn, d_has, n, d_cost.p, s);
+            if (fused) {
+                // gating + IoU + appearance rows of every track in ONE launch, written straight into pinned host memory
+                float* out = zero_copy ? h_cost.p : d_cost.p;
+                launch_trk_assoc_all(d_mean.p, d_cov.p, d_slots, d_glen, T, pending_predict ? 1 : 0, d_tl, d_xy,
+                                     (any_feat && dim > 0) ? d_gal_n.p : nullptr, gmax, dim, d_featn, d_has, n, out, out + tn, out + 2 * tn, s);
+                pending_predict = false;
+            } else {
+                launch_trk_assoc(d_mean.p, d_cov.p, d_slots, T, pending_predict ? 1 : 0, d_tl, d_xy, n, d_cost.p, d_cost.p + tn,
+                                 d_cost.p + 2 * tn, s);
+                pending_predict = false;
+                if (any_feat && dim > 0)
+                    launch_cosine_min_mfma(d_gal_n.p, d_slots, d_glen, T, gmax, dim, d_featn, d_has, n, d_cost.p, s);
+            }
         }
-        HIP_CHECK(hipMemcpyAsync(h_cost.p, d_cost.p, 3 * tn * 4, hipMemcpyDeviceToHost, s));
+        if (!(fused && zero_copy)) HIP_CHECK(hipMemcpyAsync(h_cost.p, d_cost.p, 3 * tn * 4, hipMemcpyDeviceToHost, s));
         HIP_CHECK(hipStreamSynchronize(s));
         resolve_pending(false);                // the previous frame's box read-back was queued ahead of this sync
         std::copy(h_cost.p, h_cost.p + tn, last_app.begin());
