@@ -34,7 +34,7 @@ def main(d, frames=16, crops=480, top=30, fused_stem=1, fused_yolo_stem=1):
     print(f"{'kernel':42s} {'calls':>7s} {'total ms':>9s} {'%':>6s} {'avg us':>8s}")
     for n, (c, us) in sorted(tot.items(), key=lambda kv: -kv[1][1])[:24]:
         print(f"{n[:42]:42s} {c:7d} {us / 1e3:9.2f} {100 * us / all_us:6.1f} {us / c:8.1f}")
-    conv = [r for r in rows if any(k in r["Kernel_Name"] for k in ("conv_igemm", "conv3x3_patch", "conv3x3_pp_patch", "conv3x3_c16", "conv3x3_rgb"))]
+    conv = [r for r in rows if any(k in r["Kernel_Name"] for k in ("conv_igemm", "conv3x3_patch", "conv3x3_pp_patch", "conv3x3_c16", "conv3x3_c64_resident"))]
     layers = []
     for name, g, n in (("yolo", ef.build_yolov8("n", calibrate=False), frames), ("reid", ef.build_reid(calibrate=False), crops)):
         for o in g.ops:
