@@ -471,21 +471,27 @@ __global__ __launch_bounds__(256) void cosine_min_mfma_kernel(const float* __res
     }
 }
 
-// trk_assoc_all_kernel: ONE launch per frame for everything the host association needs about track t (one 512-thread
+// trk_assoc_all_kernel: ONE launch per frame for everything the host association needs about track t (one 1024-thread
 // block per track): the lazy Kalman predict + squared Mahalanobis + IoU rows of trk_assoc_kernel (waves 0..1) and the
-// appearance row of cosine_min_mfma_kernel -- wave w takes the 16-row gallery slices w, w+8, ... and the per-slice minima
+// appearance row of cosine_min_mfma_kernel -- wave pair w>>1 takes the 16-row gallery slices, each wave half of K, and the per-slice minima
 // meet in LDS instead of atomicMin, so the three rows are plain stores and may go STRAIGHT to pinned host memory: no
-// init pass, no second launch, no device-to-host blit on the per-frame chain.  Same arithmetic, bit for bit.
-__global__ __launch_bounds__(512) void trk_assoc_all_kernel(float* mean, float* cov, const int* __restrict__ slots,
-                                                            const int* __restrict__ glen, int do_predict,
-                                                            const float* __restrict__ det_tlwh, const float* __restrict__ det_xyah,
-                                                            const float* __restrict__ gal_n, int gmax, int dim,
-                                                            const float* __restrict__ det_n, const unsigned char* __restrict__ has_feat,
-                                                            int n, float* app, float* d2, float* iouc) {
-    extern __shared__ float red[];                     // [8][n] per-wave minima
+// init pass, no second launch, no device-to-host blit on the per-frame chain.  Same products; the dot product is summed as
+// two K halves (fp32 rounding differs from the one-pass kernel in the last bit).
+__global__ __launch_bounds__(1024) void trk_assoc_all_kernel(float* mean, float* cov, const int* __restrict__ slots,
+                                                             const int* __restrict__ glen, int do_predict,
+                                                             const float* __restrict__ det_tlwh, const float* __restrict__ det_xyah,
+                                                             const float* __restrict__ gal_n, int gmax, int dim,
+                                                             const float* __restrict__ det_n, const unsigned char* __restrict__ has_feat,
+                                                             int n, float* app, float* d2, float* iouc) {
+    // 16 waves: wave w = (gallery slice lane w>>1, K half w&1).  The two K halves of a slice meet in LDS (the chain is
+    // latency-bound: half the dependent load batches per wave), then the per-slice minima meet in red[].
+    extern __shared__ float red[];                     // [8][n] per-slice minima, then [8][64][8] partial sums
+    float* part = red + 8 * n;
     const int t = blockIdx.x;
     const int slot = slots[t];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    const bool two = blockDim.x == 1024;                // 16 waves: K split in halves; 8 waves: one wave per slice
+    const int sl = two ? wv >> 1 : wv, ks = two ? wv & 1 : 0;
     float* P = cov + (size_t)slot * 64;
     float* m = mean + (size_t)slot * 8;
     if (do_predict && threadIdx.x < 64) {
@@ -505,20 +511,24 @@ __global__ __launch_bounds__(512) void trk_assoc_all_kernel(float* mean, float* 
         P[i * 8 + j] = t2;
         if (j == 0) m[i] = mi;
     }
-    // ---- appearance: per-wave minima over this wave's gallery slices
+    // ---- appearance
     const int len = (gal_n != nullptr && dim > 0) ? glen[t] : 0;
-    for (int j = lane; j < n; j += 64) red[wv * n + j] = 3.0e38f;
-    if (len > 0) {
-        unsigned int dummy = 0; (void)dummy;
-        for (int g0 = wv * 16; g0 < len; g0 += 128) {
-            const float* grow = gal_n + ((size_t)slot * gmax + min(g0 + r, len - 1)) * dim;
-            for (int d0 = 0; d0 < n; d0 += 32) {
-                const int da = d0 + r, db = d0 + 16 + r;
+    if (ks == 0)
+        for (int j = lane; j < n; j += 64) red[sl * n + j] = 3.0e38f;
+    const int kmid = two ? (dim / 2) / 64 * 64 : dim;   // K split on a 64-element boundary (the tail stays in the upper half)
+    const int k_lo = ks ? kmid : 0, k_hi = ks ? dim : kmid;
+    for (int gb = 0; gb < len; gb += 128) {             // block-uniform trip counts: the barriers below are safe
+        const int g0 = gb + sl * 16;
+        const bool live = g0 < len;
+        const float* grow = gal_n + ((size_t)slot * gmax + min(g0 + r, max(len - 1, 0))) * dim;
+        for (int d0 = 0; d0 < n; d0 += 32) {
+            const int da = d0 + r, db = d0 + 16 + r;
+            floatx4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            if (live) {
                 const float* pa = det_n + (size_t)min(da, n - 1) * dim;
                 const float* pb = det_n + (size_t)min(db, n - 1) * dim;
-                floatx4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-                int k0 = 0;
-                for (; k0 + 64 <= dim; k0 += 64) {
+                int k0 = k_lo;
+                for (; k0 + 64 <= k_hi; k0 += 64) {
                     floatx4 a[4], b0[4], b1[4];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
@@ -535,12 +545,12 @@ __global__ __launch_bounds__(512) void trk_assoc_all_kernel(float* mean, float* 
                             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][e], b1[u][e], acc1, 0, 0, 0);
                         }
                 }
-                for (; k0 < dim; k0 += 16) {
+                for (; k0 < k_hi; k0 += 16) {
                     const int k = k0 + 4 * q;
                     floatx4 a = {0.f, 0.f, 0.f, 0.f}, b0 = a, b1 = a;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        if (k + e < dim) { a[e] = grow[k + e]; b0[e] = pa[k + e]; b1[e] = pb[k + e]; }
+                        if (k + e < k_hi) { a[e] = grow[k + e]; b0[e] = pa[k + e]; b1[e] = pb[k + e]; }
                     }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -548,6 +558,20 @@ __global__ __launch_bounds__(512) void trk_assoc_all_kernel(float* mean, float* 
                         acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b1[e], acc1, 0, 0, 0);
                     }
                 }
+            }
+            float* ps = part + ((size_t)sl * 64 + lane) * 8;
+            if (two) {
+                if (ks == 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { ps[e] = acc0[e]; ps[4 + e] = acc1[e]; }
+                }
+                __syncthreads();
+                if (ks == 0) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { acc0[e] += ps[e]; acc1[e] += ps[4 + e]; }
+                }
+            }
+            if (ks == 0 && live) {
                 float m0 = 3.0e38f, m1 = 3.0e38f;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -561,11 +585,12 @@ __global__ __launch_bounds__(512) void trk_assoc_all_kernel(float* mean, float* 
                 }
                 m0 = fminf(m0, __shfl_xor(m0, 16)); m0 = fminf(m0, __shfl_xor(m0, 32));
                 m1 = fminf(m1, __shfl_xor(m1, 16)); m1 = fminf(m1, __shfl_xor(m1, 32));
-                if (q == 0) {                       // this wave owns red[wv][*]: no race across its own slices
-                    if (da < n) red[wv * n + da] = fminf(red[wv * n + da], m0);
-                    if (db < n) red[wv * n + db] = fminf(red[wv * n + db], m1);
+                if (q == 0) {                       // this wave owns red[sl][*]
+                    if (da < n) red[sl * n + da] = fminf(red[sl * n + da], m0);
+                    if (db < n) red[sl * n + db] = fminf(red[sl * n + db], m1);
                 }
             }
+            if (two) __syncthreads();               // part[] is reused by the next tile
         }
     }
     __syncthreads();   // predict's global writes and every wave's minima are visible to the whole block
@@ -782,7 +807,8 @@ void launch_trk_assoc_all(float* mean, float* cov, const int* slots, const int* 
                           const float* det_xyah, const float* gal_n, int gmax, int dim, const float* det_n,
                           const unsigned char* has_feat, int n, float* app, float* d2, float* iouc, hipStream_t s) {
     if (t <= 0 || n <= 0) return;
-    hipLaunchKernelGGL(trk_assoc_all_kernel, dim3(t), dim3(512), (size_t)8 * n * sizeof(float), s, mean, cov, slots, glen, do_predict,
+    static const int ks = [] { const char* e = getenv("AICAM_TRK_KS"); return e ? atoi(e) : 1; }();   // 2: K split over wave pairs (1024-thread blocks wait longer for a CU: 88 vs 83 us chain)
+    hipLaunchKernelGGL(trk_assoc_all_kernel, dim3(t), dim3(ks == 2 ? 1024 : 512), ((size_t)8 * n + 8 * 64 * 8) * sizeof(float), s, mean, cov, slots, glen, do_predict,
                        det_tlwh, det_xyah, gal_n, gmax, dim, det_n, has_feat, n, app, d2, iouc);
     KCHECK();
 }
