@@ -207,6 +207,12 @@ Model::Model(Device& d, const void* blob, size_t nbytes, int dtype_, int max_ite
     HIP_CHECK(hipStreamSynchronize(d.s_main));
 }
 
+bool Model::input_pix4_ok() const {
+    static const bool off = getenv("AICAM_NO_PIX4") != nullptr;
+    return !off && kind == KIND_REID && dtype == AIC_F16 && !ops.empty() && ops[0].fuse == 1 && !(lead_ops > 0 && sub_items > 0) &&
+           reid_stem2_usable(in_h, in_w);
+}
+
 void Model::run(int n, hipStream_t s) {
     AIC_REQUIRE(n >= 0 && n <= max_items, AIC_ERR_CAPACITY, "batch exceeds the engine's max_items");
     if (n == 0) return;
@@ -272,7 +278,7 @@ void Model::run_range(size_t op0, size_t op1, int i0, int n, hipStream_t s) {
             pb.p = at(pb);
             const double fl = 2.0 * n * sb.h * sb.w * 64.0 * 27.0;
             Prof pr(*dev, PROF_CONV_DIRECT, s, fl, (double)n * (sb.h * sb.w * 16.0 + pb.h * pb.w * 128.0));
-            launch_reid_stem_pool(sb.p, w.w.p, w.bias.p, pb.p, n, sb.h, sb.w, w.Kp, pb.c, pv[5], s);
+            launch_reid_stem_pool(sb.p, w.w.p, w.bias.p, pb.p, n, sb.h, sb.w, w.Kp, pb.c, pv[5], in_pix4 ? 4 : 8, s);
             continue;
         }
         if (v[0] == OP_CONV) {
@@ -369,6 +375,7 @@ void load_input_nchw(Model& m, const float* images, int n, int mem, hipStream_t 
         src = m.d_in_f32.p;
     }
     Prof pr(*m.dev, PROF_MISC, s);
+    m.in_pix4 = false;
     launch_nchw_to_nhwc8(m.dtype, src, m.input(), n, m.in_h, m.in_w, s);
 }
 
@@ -589,7 +596,8 @@ int aic_reid_embed(aic_model* mm, const uint8_t* frame, int h, int w, int mem, c
         HIP_CHECK(hipMemcpyAsync(m.d_crop_boxes.p, boxes, (size_t)n * 16, hipMemcpyHostToDevice, s));
         {
             Prof pr(*m.dev, PROF_CROP, s, 0, (double)n * m.in_h * m.in_w * 19);
-            launch_crop_resize(df, h, w, m.d_crop_boxes.p, nullptr, n, nullptr, m.in_h, m.in_w, 1, m.dtype, m.input(),
+            m.in_pix4 = m.input_pix4_ok();
+            launch_crop_resize(df, h, w, m.d_crop_boxes.p, nullptr, n, nullptr, m.in_h, m.in_w, m.in_pix4 ? 2 : 1, m.dtype, m.input(),
                                m.d_valid.p, s);
         }
         m.run(n, s);

@@ -37,6 +37,10 @@ struct Model {
 
     Model(Device& d, const void* blob, size_t nbytes, int dtype_, int max_items_);
     void* input() { return bufs[0].p; }
+    // fp16 ReID engines with the fused stem take NHWC4 crops (8 bytes per pixel: half the crop traffic); whoever fills
+    // input() says which layout it wrote
+    bool in_pix4 = false;
+    bool input_pix4_ok() const;
     void run(int n_items, hipStream_t s);
     // u8 BGR frames -> letterbox -> the whole graph; fp16 YOLO engines fuse the letterbox into the stem conv
     void run_frames(const uint8_t* frames, int n, const LetterboxGeom& g, hipStream_t s);

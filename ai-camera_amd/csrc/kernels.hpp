@@ -33,8 +33,10 @@ bool launch_yolo_stem_fused(const uint8_t* frames, int n, const LetterboxGeom& g
                             int y_cs, int y_coff, int Ho, int Wo, hipStream_t s);
 
 // conv 3x3/1 (3->64) + ReLU + max-pool 3x3/2 fused (fp16, W == 64, H % 8 == 0): ReID stem
+// in_stride: halves per input pixel, 8 (NHWC8) or 4 (NHWC4 = RGB0; only where reid_stem2_usable(H, W))
 void launch_reid_stem_pool(const void* x, const void* w, const float* bias, void* y, int n, int H, int W, int Kp, int y_cs,
-                           int y_coff, hipStream_t s);
+                           int y_coff, int in_stride, hipStream_t s);
+bool reid_stem2_usable(int H, int W);
 
 struct EltArgs {
     const void* src; void* dst;

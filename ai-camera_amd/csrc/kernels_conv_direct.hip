@@ -491,7 +491,8 @@ bool conv_try_c64_resident(const ConvArgs& a, hipStream_t s) { return try_c64_re
 // reaches HBM.  PyTorch semantics: conv zero-pads its input, the pool ignores out-of-image taps.
 struct StemArgs {
     const void* x; const void* w; const float* bias; void* y;
-    int n, H, W, Kp, y_cs, y_coff;   // input [n][H][W][8]; output [n][H/2][W/2][y_cs]
+    int n, H, W, Kp, y_cs, y_coff;   // input [n][H][W][in_stride]; output [n][H/2][W/2][y_cs]
+    int in_stride;                   // halves per input pixel: 8 (NHWC8) or 4 (NHWC4, RGB0)
 };
 
 __global__ __launch_bounds__(256) void reid_stem_pool_kernel(const StemArgs a) {
@@ -612,13 +613,13 @@ __global__ __launch_bounds__(512) void reid_stem_pool2_kernel(const StemArgs a) 
     const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6), r = lane & 15, q = lane >> 4;
     const int H = a.H, Hp = H / 2, Wp = CW / 2, rows_per_wave = Hp / 8;
     const int img = blockIdx.x;
-    const half_t* xg = reinterpret_cast<const half_t*>(a.x) + (size_t)img * H * CW * 8;
+    const half_t* xg = reinterpret_cast<const half_t*>(a.x) + (size_t)img * H * CW * a.in_stride;
 
     for (int idx = t; idx < (H + 2) * PW; idx += 512) {
         const int iy = idx / PW, ix = idx - iy * PW;
         const int gy = iy - 1, gx = ix - 1;
         uint2 v = make_uint2(0u, 0u);
-        if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)CW) v = *reinterpret_cast<const uint2*>(xg + ((size_t)gy * CW + gx) * 8);
+        if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)CW) v = *reinterpret_cast<const uint2*>(xg + ((size_t)gy * CW + gx) * a.in_stride);
         patch[idx] = v;
     }
 
@@ -704,13 +705,18 @@ __global__ __launch_bounds__(512) void reid_stem_pool2_kernel(const StemArgs a) 
     }
 }
 
-void launch_reid_stem_pool(const void* x, const void* w, const float* bias, void* y, int n, int H, int W, int Kp, int y_cs,
-                           int y_coff, hipStream_t s) {
-    if (n <= 0) return;
-    StemArgs a{x, w, bias, y, n, H, W, Kp, y_cs, y_coff};
+bool reid_stem2_usable(int H, int W) {
     static const bool v1 = [] { const char* e = getenv("AICAM_STEM"); return e && e[0] == 'v' && e[1] == '1'; }();
+    return !v1 && W == 64 && H % 16 == 0 && (size_t)(H + 2) * 66 * 8 <= 160 * 1024;
+}
+
+void launch_reid_stem_pool(const void* x, const void* w, const float* bias, void* y, int n, int H, int W, int Kp, int y_cs,
+                           int y_coff, int in_stride, hipStream_t s) {
+    if (n <= 0) return;
+    StemArgs a{x, w, bias, y, n, H, W, Kp, y_cs, y_coff, in_stride};
+    AIC_REQUIRE(in_stride == 8 || (in_stride == 4 && reid_stem2_usable(H, W)), AIC_ERR_INVALID, "NHWC4 input needs the second stem form");
     const size_t lds2 = (size_t)(H + 2) * 66 * 8;
-    if (!v1 && W == 64 && H % 16 == 0 && lds2 <= 160 * 1024) {
+    if (reid_stem2_usable(H, W)) {
         static bool attr2 = false;
         if (!attr2) {
             HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(reid_stem_pool2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

@@ -17,6 +17,7 @@
 namespace aic {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
 
 // ---- host: geometry of image_processing.py:33-67 (auto=False, scaleup=False as called at :92)
 static long py_round(double v) {   // Python round(): half to even
@@ -144,7 +145,6 @@ __global__ void letterbox_kernel(const uint8_t* __restrict__ frames, int n, Lett
 // as RGB0, even and odd columns apart (stride 2: 16 consecutive outputs read 16 consecutive entries), and the
 // convolution runs on the matrix cores exactly like the ReID stem: K = (tap, RGB0), taps 0..7 in one
 // v_mfma_f32_16x16x32_f16, tap 8 in a second one, bias as the accumulator's initial value.
-typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
 typedef float floatx4_t __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(256) void yolo_stem_fused_kernel(const uint8_t* __restrict__ frames, LetterboxGeom g,
@@ -296,6 +296,11 @@ __global__ __launch_bounds__(256) void crop_resize_kernel(const uint8_t* __restr
         if (mode == 0) {
             float* o = reinterpret_cast<float*>(out) + (size_t)crop * 3 * per + p;
             o[0] = v[0]; o[per] = v[1]; o[2 * per] = v[2];
+        } else if (mode == 2) {   // NHWC4 (RGB0, 8 bytes per pixel): what the fused fp16 ReID stem consumes, half the traffic of NHWC8
+            if constexpr (sizeof(T) == 2) {
+                const half4_t h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)0.f};
+                *reinterpret_cast<half4_t*>(reinterpret_cast<half_t*>(out) + ((size_t)crop * per + p) * 4) = h;
+            }
         } else {
             store_nhwc8<T>(reinterpret_cast<T*>(out) + ((size_t)crop * per + p) * 8, v[0], v[1], v[2]);
         }

@@ -187,8 +187,9 @@ struct Pipeline {
             HIP_CHECK(hipMemcpyAsync(c.d_frame_of.p, c.h_frame_of.p, (size_t)nc * 4, hipMemcpyHostToDevice, sr));
             {
                 Prof pr(*dev, PROF_CROP, sr, 0, (double)nc * reid->in_h * reid->in_w * 19);
+                reid->in_pix4 = reid->input_pix4_ok();
                 launch_crop_resize(f0, prm.frame_h, prm.frame_w, c.d_boxes.p, c.d_frame_of.p, nc, nullptr, reid->in_h,
-                                   reid->in_w, 1, reid->dtype, reid->input(), c.d_valid.p, sr);
+                                   reid->in_w, reid->in_pix4 ? 2 : 1, reid->dtype, reid->input(), c.d_valid.p, sr);
             }
             reid->run(nc, sr);
             HIP_CHECK(hipMemcpyAsync(c.d_emb.p, reid->embeddings(), (size_t)nc * dim * 4, hipMemcpyDeviceToDevice, sr));

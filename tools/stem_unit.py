@@ -3,9 +3,9 @@ import ctypes as C, os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 lib = C.CDLL(os.path.join(ROOT, "ai-camera_amd", "libaicam.so"))
-fn = getattr(lib, "_ZN3aic21launch_reid_stem_poolEPKvS1_PKfPviiiiiiP12ihipStream_t")
+fn = getattr(lib, "_ZN3aic21launch_reid_stem_poolEPKvS1_PKfPviiiiiiiP12ihipStream_t")
 fn.restype = None
-fn.argtypes = [C.c_void_p] * 4 + [C.c_int] * 6 + [C.c_void_p]
+fn.argtypes = [C.c_void_p] * 4 + [C.c_int] * 7 + [C.c_void_p]
 torch.manual_seed(0)
 n, H, W, Kp = 4, 128, 64, 96
 mode = sys.argv[1] if len(sys.argv) > 1 else "rand"
@@ -19,7 +19,7 @@ dev = "cuda"
 xd, wd, bd = xh.to(dev), wp.to(dev), b.to(dev)
 yd = torch.full((n, H // 2, W // 2, 64), -7.0, dtype=torch.float16, device=dev)
 torch.cuda.synchronize()
-fn(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), yd.data_ptr(), n, H, W, Kp, 64, 0, None)
+fn(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), yd.data_ptr(), n, H, W, Kp, 64, 0, 8, None)
 torch.cuda.synchronize()
 y = yd.cpu().float()
 ref = torch.nn.functional.conv2d(xh[..., :3].permute(0, 3, 1, 2).float(), wp[:, :72].view(64, 9, 8)[:, :, :3].reshape(64, 3, 3, 3).permute(0, 3, 1, 2).float(), b, padding=1)
