@@ -55,6 +55,69 @@ __global__ void sppf_pool_kernel(const EltArgs a) {
     *reinterpret_cast<V*>(o + 2 * a.c) = m13;
 }
 
+// Separable form of the three cascaded 5x5 max-pools of SPPF (windows 5, 9, 13 with -inf padding): one block per
+// (image, 16-byte channel chunk), the h x w map in LDS, a horizontal then a vertical pass of 13 taps each (26 LDS
+// reads per pixel instead of 169 global ones).
+template <typename T>
+__global__ __launch_bounds__(256) void sppf_pool_sep_kernel(const EltArgs a) {
+    typedef typename Vec<T>::type V;
+    constexpr int VN = Vec<T>::N;
+    extern __shared__ __attribute__((aligned(16))) char sm_raw[];
+    V* tile = reinterpret_cast<V*>(sm_raw);          // [4][h*w]: input, then the three horizontal maxima
+    const int cv = a.c / VN;
+    const int img = blockIdx.x / cv, cc = blockIdx.x - img * cv;
+    const int hw = a.h * a.w;
+    const T* src = reinterpret_cast<const T*>(a.src) + (size_t)img * hw * a.s_cs + a.s_coff + cc * VN;
+    T* dst = reinterpret_cast<T*>(a.dst) + (size_t)img * hw * a.d_cs + a.d_coff + cc * VN;
+    for (int p = threadIdx.x; p < hw; p += 256) tile[p] = *reinterpret_cast<const V*>(src + (size_t)p * a.s_cs);
+    __syncthreads();
+    for (int p = threadIdx.x; p < hw; p += 256) {
+        const int y = p / a.w, x = p - y * a.w;
+        V m5 = tile[p], m9, m13;
+#pragma unroll
+        for (int d = 1; d <= 2; ++d) {
+            if (x - d >= 0) m5 = vmax<T>(m5, tile[p - d]);
+            if (x + d < a.w) m5 = vmax<T>(m5, tile[p + d]);
+        }
+        m9 = m5;
+#pragma unroll
+        for (int d = 3; d <= 4; ++d) {
+            if (x - d >= 0) m9 = vmax<T>(m9, tile[p - d]);
+            if (x + d < a.w) m9 = vmax<T>(m9, tile[p + d]);
+        }
+        m13 = m9;
+#pragma unroll
+        for (int d = 5; d <= 6; ++d) {
+            if (x - d >= 0) m13 = vmax<T>(m13, tile[p - d]);
+            if (x + d < a.w) m13 = vmax<T>(m13, tile[p + d]);
+        }
+        tile[hw + p] = m5, tile[2 * hw + p] = m9, tile[3 * hw + p] = m13;
+    }
+    __syncthreads();
+    for (int p = threadIdx.x; p < hw; p += 256) {
+        const int y = p / a.w;
+        V m5 = tile[hw + p], m9 = tile[2 * hw + p], m13 = tile[3 * hw + p];
+#pragma unroll
+        for (int d = 1; d <= 6; ++d) {
+            const bool up = y - d >= 0, dn = y + d < a.h;
+            if (d <= 2) {
+                if (up) m5 = vmax<T>(m5, tile[hw + p - d * a.w]);
+                if (dn) m5 = vmax<T>(m5, tile[hw + p + d * a.w]);
+            }
+            if (d <= 4) {
+                if (up) m9 = vmax<T>(m9, tile[2 * hw + p - d * a.w]);
+                if (dn) m9 = vmax<T>(m9, tile[2 * hw + p + d * a.w]);
+            }
+            if (up) m13 = vmax<T>(m13, tile[3 * hw + p - d * a.w]);
+            if (dn) m13 = vmax<T>(m13, tile[3 * hw + p + d * a.w]);
+        }
+        T* o = dst + (size_t)p * a.d_cs;
+        *reinterpret_cast<V*>(o) = m5;
+        *reinterpret_cast<V*>(o + a.c) = m9;
+        *reinterpret_cast<V*>(o + 2 * a.c) = m13;
+    }
+}
+
 template <typename T>
 __global__ void upsample2x_kernel(const EltArgs a) {
     typedef typename Vec<T>::type V;
@@ -168,7 +231,18 @@ __global__ void copy_f32_kernel(const float* __restrict__ src, float* __restrict
 
 static inline int vecn(int dtype) { return dtype == AIC_F16 ? 8 : 4; }
 
-void launch_sppf_pool(int dtype, const EltArgs& a, hipStream_t s) { ELT_LAUNCH(sppf_pool_kernel, (long)a.n * a.h * a.w * (a.c / vecn(dtype))); }
+void launch_sppf_pool(int dtype, const EltArgs& a, hipStream_t s) {
+    const size_t lds = (size_t)4 * a.h * a.w * 16;
+    static const bool direct = getenv("AICAM_SPPF_DIRECT") != nullptr;
+    if (!direct && lds <= 64 * 1024 && a.n > 0) {      // in-place safe: a block reads its whole (image, chunk) map before it writes
+        const int blocks = a.n * (a.c / vecn(dtype));
+        if (dtype == AIC_F16) hipLaunchKernelGGL(sppf_pool_sep_kernel<half_t>, dim3(blocks), dim3(256), lds, s, a);
+        else hipLaunchKernelGGL(sppf_pool_sep_kernel<float>, dim3(blocks), dim3(256), lds, s, a);
+        KCHECK();
+        return;
+    }
+    ELT_LAUNCH(sppf_pool_kernel, (long)a.n * a.h * a.w * (a.c / vecn(dtype)));
+}
 void launch_upsample2x(int dtype, const EltArgs& a, hipStream_t s) { ELT_LAUNCH(upsample2x_kernel, (long)a.n * 4 * a.h * a.w * (a.c / vecn(dtype))); }
 void launch_maxpool3s2(int dtype, const EltArgs& a, hipStream_t s) {
     const int oh = (a.h - 1) / 2 + 1, ow = (a.w - 1) / 2 + 1;
