@@ -119,6 +119,14 @@ void launch_cosine_min_mfma(const float* gal_n, const int* slots, const int* gle
 void launch_trk_assoc_all(float* mean, float* cov, const int* slots, const int* glen, int t, int do_predict, const float* det_tlwh,
                           const float* det_xyah, const float* gal_n, int gmax, int dim, const float* det_n,
                           const unsigned char* has_feat, int n, float* app, float* d2, float* iouc, hipStream_t s);
+// the same launch preceded, per track, by the commit of the previous frame (Kalman update / initiate / gallery row);
+// c_kind == nullptr: association only; n == 0: commit only
+void launch_trk_step(float* mean, float* cov, const int* slots, const int* glen, int t, int do_predict, const float* det_tlwh,
+                     const float* det_xyah, const float* gal_n, int gmax, int dim, const float* det_n,
+                     const unsigned char* has_feat, int n, float* app, float* d2, float* iouc,
+                     const int* c_kind, const int* c_det, const int* c_kout, const int* c_appos, const int* c_apdet,
+                     const float* c_xyah, const float* c_feat, const float* c_feat_n, float* c_out_tlwh, float* c_gal_raw, float* c_gal_w,
+                     hipStream_t s);
 void launch_trk_commit(float* mean, float* cov, const int* lists, int M, int U, int A, const float* xyah, float* out_tlwh,
                        float* gal_raw, float* gal_n, int gmax, int dim, const float* feat, const float* feat_n, hipStream_t s);
 

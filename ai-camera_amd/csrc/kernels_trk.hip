@@ -471,6 +471,17 @@ __global__ __launch_bounds__(256) void cosine_min_mfma_kernel(const float* __res
     }
 }
 
+struct TrkCommit {   // per-track commit of the previous frame, folded into the next frame's association launch (kind == nullptr: none)
+    const int* kind;      // 0 none, 1 Kalman update, 2 initiate
+    const int* det;       // detection row (previous frame) for kind 1 / 2
+    const int* kout;      // row of out_tlwh for kind 1
+    const int* appos;     // gallery ring position to write, or -1
+    const int* apdet;     // detection row whose feature is appended
+    const float* xyah;    // previous frame's detections
+    const float* feat; const float* feat_n;
+    float* out_tlwh; float* gal_raw; float* gal_w;
+};
+
 // trk_assoc_all_kernel: ONE launch per frame for everything the host association needs about track t (one 1024-thread
 // block per track): the lazy Kalman predict + squared Mahalanobis + IoU rows of trk_assoc_kernel (waves 0..1) and the
 // appearance row of cosine_min_mfma_kernel -- wave pair w>>1 takes the 16-row gallery slices, each wave half of K, and the per-slice minima
@@ -480,9 +491,9 @@ __global__ __launch_bounds__(256) void cosine_min_mfma_kernel(const float* __res
 __global__ __launch_bounds__(1024) void trk_assoc_all_kernel(float* mean, float* cov, const int* __restrict__ slots,
                                                              const int* __restrict__ glen, int do_predict,
                                                              const float* __restrict__ det_tlwh, const float* __restrict__ det_xyah,
-                                                             const float* __restrict__ gal_n, int gmax, int dim,
+                                                             const float* gal_n, int gmax, int dim,
                                                              const float* __restrict__ det_n, const unsigned char* __restrict__ has_feat,
-                                                             int n, float* app, float* d2, float* iouc) {
+                                                             int n, float* app, float* d2, float* iouc, TrkCommit cm) {
     // 16 waves: wave w = (gallery slice lane w>>1, K half w&1).  The two K halves of a slice meet in LDS (the chain is
     // latency-bound: half the dependent load batches per wave), then the per-slice minima meet in red[].
     extern __shared__ float red[];                     // [8][n] per-slice minima, then [8][64][8] partial sums
@@ -494,6 +505,71 @@ __global__ __launch_bounds__(1024) void trk_assoc_all_kernel(float* mean, float*
     const int sl = two ? wv >> 1 : wv, ks = two ? wv & 1 : 0;
     float* P = cov + (size_t)slot * 64;
     float* m = mean + (size_t)slot * 8;
+    // ---- commit of the PREVIOUS frame for this track (pipelined form: one launch per frame): Kalman update or initiate on
+    // wave 0, the gallery row on the other waves; then the block continues with the next frame's rows
+    if (cm.kind != nullptr) {
+        const int kind = cm.kind[t];
+        if (threadIdx.x < 64) {
+            const int i = lane >> 3, j = lane & 7;
+            if (kind == 1) {
+                const float* zz = cm.xyah + (size_t)cm.det[t] * 4;
+                float S[4][4], L[4][4];
+                innovation_cov(P, m[3], S);
+                cholesky<4>(S, L);
+                float bi[4], bj[4], y[4], Ki[4], Kj[4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) { bi[a] = P[i * 8 + a]; bj[a] = P[j * 8 + a]; }
+                fwd_solve<4>(L, bi, y); bwd_solve(L, y, Ki);
+                fwd_solve<4>(L, bj, y); bwd_solve(L, y, Kj);
+                float acc = 0.f;
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    float u = 0.f;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) u = u + S[a][c] * Kj[c];
+                    acc = acc + Ki[a] * u;
+                }
+                const float pij = P[i * 8 + j] - acc;
+                float mi = m[i];
+                {
+                    float dot = 0.f;
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) dot = dot + Ki[a] * (zz[a] - m[a]);
+                    mi = mi + dot;
+                }
+                __builtin_amdgcn_s_waitcnt(0);      // every lane has read P / m before anyone overwrites them (one wave: lock-step, but loads are async)
+                P[i * 8 + j] = pij;
+                if (j == 0) m[i] = mi;
+                const float cx = __shfl(mi, 0), cy = __shfl(mi, 8), ar = __shfl(mi, 16), hh = __shfl(mi, 24);
+                if (lane == 0) {
+                    float w = 0.f, h2 = hh;
+                    if (hh > 0.f) w = ar * hh; else h2 = fmaxf(0.f, hh);
+                    float* o = cm.out_tlwh + (size_t)cm.kout[t] * 4;
+                    o[0] = cx - w / 2.0f; o[1] = cy - h2 / 2.0f; o[2] = w; o[3] = h2;
+                }
+            } else if (kind == 2) {
+                const float* zz = cm.xyah + (size_t)cm.det[t] * 4;
+                const float h = zz[3];
+                float v = 0.f;
+                if (i == j) {
+                    if (i == 2) v = (float)(1e-2 * 1e-2);
+                    else if (i == 6) v = (float)(1e-5 * 1e-5);
+                    else v = sq64((i < 4 ? 0.1f : 0.0625f) * h);
+                }
+                cov[(size_t)slot * 64 + lane] = v;
+                if (j == 0) mean[(size_t)slot * 8 + i] = i < 4 ? zz[i] : 0.f;
+            }
+        } else if (cm.appos[t] >= 0) {
+            const size_t dst = ((size_t)slot * gmax + cm.appos[t]) * dim;
+            const size_t src = (size_t)cm.apdet[t] * dim;
+            for (int c = threadIdx.x - 64; c < dim; c += blockDim.x - 64) {
+                cm.gal_raw[dst + c] = cm.feat[src + c];
+                cm.gal_w[dst + c] = cm.feat_n[src + c];
+            }
+        }
+        __syncthreads();                            // the block's own global writes are visible to all its waves from here on
+        if (n <= 0) return;                         // (block-uniform) commit only: no next frame to prepare
+    }
     if (do_predict && threadIdx.x < 64) {
         const int i = lane >> 3, j = lane & 7;
         const float h = m[3];
@@ -806,10 +882,20 @@ void launch_cosine_min_mfma(const float* gal_n, const int* slots, const int* gle
 void launch_trk_assoc_all(float* mean, float* cov, const int* slots, const int* glen, int t, int do_predict, const float* det_tlwh,
                           const float* det_xyah, const float* gal_n, int gmax, int dim, const float* det_n,
                           const unsigned char* has_feat, int n, float* app, float* d2, float* iouc, hipStream_t s) {
-    if (t <= 0 || n <= 0) return;
+    launch_trk_step(mean, cov, slots, glen, t, do_predict, det_tlwh, det_xyah, gal_n, gmax, dim, det_n, has_feat, n, app, d2, iouc,
+                    nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, s);
+}
+void launch_trk_step(float* mean, float* cov, const int* slots, const int* glen, int t, int do_predict, const float* det_tlwh,
+                     const float* det_xyah, const float* gal_n, int gmax, int dim, const float* det_n,
+                     const unsigned char* has_feat, int n, float* app, float* d2, float* iouc,
+                     const int* c_kind, const int* c_det, const int* c_kout, const int* c_appos, const int* c_apdet,
+                     const float* c_xyah, const float* c_feat, const float* c_feat_n, float* c_out_tlwh, float* c_gal_raw, float* c_gal_w,
+                     hipStream_t s) {
+    if (t <= 0 || (n <= 0 && c_kind == nullptr)) return;
+    const TrkCommit cm{c_kind, c_det, c_kout, c_appos, c_apdet, c_xyah, c_feat, c_feat_n, c_out_tlwh, c_gal_raw, c_gal_w};
     static const int ks = [] { const char* e = getenv("AICAM_TRK_KS"); return e ? atoi(e) : 1; }();   // 2: K split over wave pairs (1024-thread blocks wait longer for a CU: 88 vs 83 us chain)
-    hipLaunchKernelGGL(trk_assoc_all_kernel, dim3(t), dim3(ks == 2 ? 1024 : 512), ((size_t)8 * n + 8 * 64 * 8) * sizeof(float), s, mean, cov, slots, glen, do_predict,
-                       det_tlwh, det_xyah, gal_n, gmax, dim, det_n, has_feat, n, app, d2, iouc);
+    hipLaunchKernelGGL(trk_assoc_all_kernel, dim3(t), dim3(ks == 2 ? 1024 : 512), ((size_t)8 * std::max(n, 0) + 8 * 64 * 8) * sizeof(float), s, mean, cov, slots, glen, do_predict,
+                       det_tlwh, det_xyah, gal_n, gmax, dim, det_n, has_feat, n, app, d2, iouc, cm);
     KCHECK();
 }
 void launch_trk_commit(float* mean, float* cov, const int* lists, int M, int U, int A, const float* xyah, float* out_tlwh,

@@ -228,13 +228,26 @@ struct Pipeline {
                 if (track_conf) track_conf[(size_t)o * prm.max_persons + k] = t.conf;
             }
         };
+        std::vector<std::vector<uint8_t>> hasv(c.frames);
+        for (int f = 0; f < c.frames; ++f) {
+            const FrameDets& fd = c.dets[f];
+            hasv[f].resize(fd.n);
+            for (int i = 0; i < fd.n; ++i) hasv[f][i] = c.h_valid.p[fd.crop0 + i] ? 1 : 0;   // empty crop -> feature None
+        }
         for (int f = 0; f < c.frames; ++f) {
             FrameDets& fd = c.dets[f];
-            has.assign(fd.n, 1);
-            for (int i = 0; i < fd.n; ++i) has[i] = c.h_valid.p[fd.crop0 + i] ? 1 : 0;   // empty crop -> feature None
+            // the next frame of the group is known: its association rides on this frame's commit launch (one launch per frame)
+            NextDets nx{};
+            const bool have_next = f + 1 < c.frames;
+            if (have_next) {
+                const FrameDets& fn = c.dets[f + 1];
+                nx.tlwh = fn.tlwh.data(), nx.has = hasv[f + 1].data(), nx.n = fn.n;
+                nx.feat_n = fn.n ? c.d_emb_n.p + (size_t)fn.crop0 * dim : nullptr;
+            }
             trk.predict();
             trk.update(fd.tlwh.data(), fd.conf.data(), fd.cls.data(), fd.n ? c.d_emb.p + (size_t)fd.crop0 * dim : nullptr,
-                       AIC_DEVICE, has.data(), fd.n, dim, fd.n ? c.d_emb_n.p + (size_t)fd.crop0 * dim : nullptr);
+                       AIC_DEVICE, hasv[f].data(), fd.n, dim, fd.n ? c.d_emb_n.p + (size_t)fd.crop0 * dim : nullptr,
+                       have_next ? &nx : nullptr);
             const int o = out_base + f;
             if (f > 0) emit(o - 1);            // frame f-1's boxes came back behind frame f's cost-matrix sync
             if (n_dets) n_dets[o] = c.h_numdets.p[f];

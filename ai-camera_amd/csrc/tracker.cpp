@@ -12,6 +12,9 @@
 // one packed H2D, 3 kernels, one D2H of the updated boxes.
 #include "tracker.hpp"
 
+#include <chrono>
+#include <cstdio>
+
 #include <algorithm>
 #include <cmath>
 
@@ -42,6 +45,11 @@ void Tracker::ensure_dim(int d) {
 }
 
 void Tracker::predict() {   // tracker_core.py:44-49 -> track.py:76-80
+    if (pre_predicted) {                       // the device side of this predict already ran inside the previous frame's launch
+        pre_predicted = false;
+        for (auto& t : tracks) { t.age += 1; t.tsu += 1; }
+        return;
+    }
     if (pending_predict) flush_predict();      // two predicts in a row: run the first one now
     for (auto& t : tracks) { t.age += 1; t.tsu += 1; }
     pending_predict = !tracks.empty();         // the kernel runs fused into the next association launch
@@ -159,9 +167,23 @@ void Tracker::resolve_pending(bool need_sync) {
     pend.active = false;
 }
 
+namespace {
+struct TrkTimes {
+    double prep = 0, gpu = 0, host = 0, commit = 0; long n = 0;
+    bool on = getenv("AICAM_TRK_TIMES") != nullptr;
+    ~TrkTimes() {
+        if (on && n) fprintf(stderr, "[trk_times] frames %ld: prep+launch %.1f us, wait for the association rows %.1f, host match+lifecycle %.1f, commit issue %.1f\n",
+                             n, 1e6 * prep / n, 1e6 * gpu / n, 1e6 * host / n, 1e6 * commit / n);
+    }
+    static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+} g_trk_times;
+}  // namespace
+
 void Tracker::update(const float* det_tlwh, const float* conf, const int32_t* cls, const float* feat, int feat_mem,
-                     const uint8_t* has_feat, int n, int dim_in, const float* feat_n) {
+                     const uint8_t* has_feat, int n, int dim_in, const float* feat_n, const NextDets* nx) {
     dev->use();
+    const double tt0 = g_trk_times.on ? TrkTimes::now() : 0.0;
+    double tt1 = tt0, tt2 = tt0, tt3 = tt0;
     hipStream_t s = dev->s_trk;
     const int T = (int)tracks.size();
     const bool any_feat = feat != nullptr && n > 0;
@@ -206,6 +228,12 @@ void Tracker::update(const float* det_tlwh, const float* conf, const int32_t* cl
     last_app.assign((size_t)T * n, kInfty);
     last_maha.assign((size_t)T * n, 0.f);
     last_iou.assign((size_t)T * n, kInfty);
+    for (auto& tr : tracks) { tr.c_kind = 0; tr.c_appos = -1; }
+    const bool have_rows = pre_rows;           // requested by the previous frame's launch (pipelined form)
+    if (have_rows) {
+        AIC_REQUIRE(pre_T == T && pre_n == n && T > 0 && n > 0, AIC_ERR_RUNTIME, "pipelined tracker: the next frame differs from the one announced");
+        pre_rows = false;
+    }
     if (T > 0 && n > 0) {
         h_stage.ensure(stage_bytes + 16);
         d_stage.ensure(stage_bytes + 16);
@@ -234,7 +262,9 @@ void Tracker::update(const float* det_tlwh, const float* conf, const int32_t* cl
         {
             Prof pr(*dev, PROF_TRK, s, any_feat ? 2.0 * T * gmax * (double)n * dim : 0.0,
                     any_feat ? ((double)T * gmax + n) * dim * 4 : 0.0);
-            if (fused) {
+            if (have_rows) {
+                // nothing to launch
+            } else if (fused) {
                 // gating + IoU + appearance rows of every track in ONE launch, written straight into pinned host memory
                 float* out = zero_copy ? h_cost.p : d_cost.p;
                 launch_trk_assoc_all(d_mean.p, d_cov.p, d_slots, d_glen, T, pending_predict ? 1 : 0, d_tl, d_xy,
@@ -248,8 +278,10 @@ void Tracker::update(const float* det_tlwh, const float* conf, const int32_t* cl
                     launch_cosine_min_mfma(d_gal_n.p, d_slots, d_glen, T, gmax, dim, d_featn, d_has, n, d_cost.p, s);
             }
         }
-        if (!(fused && zero_copy)) HIP_CHECK(hipMemcpyAsync(h_cost.p, d_cost.p, 3 * tn * 4, hipMemcpyDeviceToHost, s));
+        if (!(fused && zero_copy) && !have_rows) HIP_CHECK(hipMemcpyAsync(h_cost.p, d_cost.p, 3 * tn * 4, hipMemcpyDeviceToHost, s));
+        if (g_trk_times.on) tt1 = TrkTimes::now();
         HIP_CHECK(hipStreamSynchronize(s));
+        if (g_trk_times.on) tt2 = TrkTimes::now();
         resolve_pending(false);                // the previous frame's box read-back was queued ahead of this sync
         std::copy(h_cost.p, h_cost.p + tn, last_app.begin());
         std::copy(h_cost.p + tn, h_cost.p + 2 * tn, last_maha.begin());
@@ -282,12 +314,14 @@ void Tracker::update(const float* det_tlwh, const float* conf, const int32_t* cl
             t.ghead = (t.ghead + 1) % gmax;
         }
         ap_slot.push_back(t.slot), ap_pos.push_back(pos), ap_det.push_back(det);
+        t.c_appos = pos, t.c_apdet = det;
     };
     std::vector<int> match_index_of_track(T, -1);
     for (int k = 0; k < M; ++k) {   // track.py:82-104
         TrackRec& t = tracks[matches[k].first];
         const int det = matches[k].second;
         upd_slot[k] = t.slot, upd_det[k] = det;
+        t.c_kind = 1, t.c_det = det, t.c_kout = k;
         match_index_of_track[matches[k].first] = k;
         push_feature(t, det);
         t.hits += 1;
@@ -313,13 +347,21 @@ void Tracker::update(const float* det_tlwh, const float* conf, const int32_t* cl
         free_slots.pop_back();
         t.glen = 0, t.ghead = 0;
         ini_slot[k] = t.slot, ini_det[k] = un_d[k];
+        t.c_kind = 2, t.c_det = un_d[k];
         push_feature(t, un_d[k]);
         tracks.push_back(t);
     }
 
+    if (g_trk_times.on) tt3 = TrkTimes::now();
     // ---- device: commit
     const int A = (int)ap_slot.size();
-    if (M + U + A > 0) {
+    static const bool step_ok = getenv("AICAM_TRK_NOSTEP") == nullptr;
+    const int tl_buf = out_parity;             // the pinned box buffer this frame's outputs will be resolved from
+    const bool stepped = nx != nullptr && defer_outputs && step_ok && getenv("AICAM_TRK_SPLIT") == nullptr && getenv("AICAM_TRK_COPY") == nullptr;
+    if (stepped) {                              // pipelined form: the commit rides in front of the next frame's association (below, after the prune)
+        d_tlwh.ensure((size_t)std::max(M, 1) * 4);
+        h_tlwh2[out_parity].ensure((size_t)std::max(M, 1) * 4);
+    } else if (M + U + A > 0) {
         const size_t words = (size_t)2 * M + 2 * U + 3 * A;
         const size_t xy_off = ((words * 4 + 15) / 16) * 16;
         const size_t bytes = xy_off + (size_t)n * 16;
@@ -386,6 +428,10 @@ void Tracker::update(const float* det_tlwh, const float* conf, const int32_t* cl
     } else {
         build(meta, h_tlwh.p, outputs);
     }
+    if (g_trk_times.on) {
+        const double tt4 = TrkTimes::now();
+        g_trk_times.prep += tt1 - tt0, g_trk_times.gpu += tt2 - tt1, g_trk_times.host += tt3 - tt2, g_trk_times.commit += tt4 - tt3, g_trk_times.n += 1;
+    }
     // ---- prune (tracker_core.py:75)
     std::vector<TrackRec> alive;
     alive.reserve(tracks.size());
@@ -394,6 +440,42 @@ void Tracker::update(const float* det_tlwh, const float* conf, const int32_t* cl
         else alive.push_back(t);
     }
     tracks.swap(alive);
+
+    if (stepped) {
+        // ---- ONE launch: per surviving track, this frame's commit (update / initiate / gallery row), then -- if the next
+        // frame has detections -- its lazy predict and association rows, straight into pinned host memory
+        const int T2 = (int)tracks.size(), n1 = nx->n;
+        if (T2 > 0) {
+            const bool feat1 = nx->feat_n != nullptr && n1 > 0 && dim > 0;
+            const size_t off_f = (size_t)7 * T2 * 4;
+            const size_t off_xy0 = ((off_f + 15) / 16) * 16, off_tl1 = off_xy0 + (size_t)n * 16, off_xy1 = off_tl1 + (size_t)n1 * 16;
+            const size_t off_has = off_xy1 + (size_t)n1 * 16, bytes = ((off_has + n1 + 15) / 16) * 16;
+            h_step.ensure(bytes + 16);
+            int* hi = reinterpret_cast<int*>(h_step.p);
+            for (int i = 0; i < T2; ++i) {
+                const TrackRec& tr = tracks[i];
+                hi[i] = tr.slot, hi[T2 + i] = tr.glen, hi[2 * T2 + i] = tr.c_kind, hi[3 * T2 + i] = tr.c_det, hi[4 * T2 + i] = tr.c_kout;
+                hi[5 * T2 + i] = tr.c_appos, hi[6 * T2 + i] = tr.c_apdet;
+            }
+            std::memcpy(h_step.p + off_xy0, xyah.data(), (size_t)n * 16);
+            float* tl1 = reinterpret_cast<float*>(h_step.p + off_tl1);
+            float* xy1 = reinterpret_cast<float*>(h_step.p + off_xy1);
+            for (int j = 0; j < n1; ++j) {   // detection.py:36-47
+                const float x = nx->tlwh[j * 4], y = nx->tlwh[j * 4 + 1], w = nx->tlwh[j * 4 + 2], h = nx->tlwh[j * 4 + 3];
+                tl1[j * 4] = x, tl1[j * 4 + 1] = y, tl1[j * 4 + 2] = w, tl1[j * 4 + 3] = h;
+                xy1[j * 4] = x + w / 2.0f, xy1[j * 4 + 1] = y + h / 2.0f, xy1[j * 4 + 2] = h > 0.f ? w / h : 0.f, xy1[j * 4 + 3] = h;
+            }
+            for (int j = 0; j < n1; ++j) h_step.p[off_has + j] = (feat1 && (!nx->has || nx->has[j])) ? 1 : 0;
+            const size_t tn1 = (size_t)T2 * n1;
+            h_cost.ensure(3 * std::max<size_t>(tn1, 1));
+            Prof pr(*dev, PROF_TRK, s, feat1 ? 2.0 * T2 * gmax * (double)n1 * dim : 0.0, feat1 ? ((double)T2 * gmax + n1) * dim * 4 : 0.0);
+            launch_trk_step(d_mean.p, d_cov.p, hi, hi + T2, T2, 1, tl1, xy1, feat1 ? d_gal_n.p : nullptr, gmax, dim, nx->feat_n,
+                            reinterpret_cast<const unsigned char*>(h_step.p + off_has), n1, h_cost.p, h_cost.p + tn1, h_cost.p + 2 * tn1,
+                            hi + 2 * T2, hi + 3 * T2, hi + 4 * T2, hi + 5 * T2, hi + 6 * T2,
+                            reinterpret_cast<const float*>(h_step.p + off_xy0), d_featp, d_featn, h_tlwh2[tl_buf].p, d_gal_raw.p, d_gal_n.p, s);
+            if (n1 > 0) pre_rows = true, pre_predicted = true, pre_T = T2, pre_n = n1;
+        }
+    }
 }
 
 }  // namespace aic

@@ -14,7 +14,11 @@ struct TrackRec {
     float conf;
     int slot;          // row in the device SoA
     int glen, ghead;   // gallery ring: oldest row = ghead, length glen
+    int c_kind = 0, c_det = 0, c_kout = 0, c_appos = -1, c_apdet = 0;   // this frame's commit (pipelined launch): 0 none, 1 update, 2 initiate
 };
+
+// Detections of the NEXT frame (pipelined form): lets update(f) launch commit(f) + association(f+1) as one kernel
+struct NextDets { const float* tlwh; const uint8_t* has; const float* feat_n; int n; };
 
 struct TrackOut { int x1, y1, x2, y2, id, cls; float conf; };
 
@@ -61,7 +65,12 @@ struct Tracker {
     void flush_predict();
     // feat_n: the same rows already normalised on the device (rows / max(||row||, 1e-7)), or NULL
     void update(const float* det_tlwh, const float* conf, const int32_t* cls, const float* feat, int feat_mem,
-                const uint8_t* has_feat, int n, int dim_in, const float* feat_n = nullptr);
+                const uint8_t* has_feat, int n, int dim_in, const float* feat_n = nullptr, const NextDets* nx = nullptr);
+    // pipelined form: the association rows of the coming frame were requested (and its Kalman predict applied) by the
+    // previous update's launch
+    bool pre_rows = false, pre_predicted = false;
+    int pre_T = 0, pre_n = 0;
+    PinBuf<char> h_step;
     void match(int T, int N, const float* app, const float* maha, const float* iou,
                std::vector<std::pair<int, int>>& matches, std::vector<int>& unmatched_t, std::vector<int>& unmatched_d);
 };
