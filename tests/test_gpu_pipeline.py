@@ -15,9 +15,9 @@ syn = pkg("synthetic")
 config = pkg("config")
 
 
-def oracle_tracks(sc, reid_eo, frames, n_frames):
+def oracle_tracks(sc, reid_eo, frames, n_frames, **trk_kw):
     """Oracle with planted detections (inject mode): crops -> fp32 ReID oracle -> DeepSORT oracle."""
-    trk = O.OracleTracker()
+    trk = O.OracleTracker(**trk_kw)
     out, embs = [], []
     for f in range(n_frames):
         boxes, conf, cls, _ = sc.detections(f)
@@ -143,3 +143,32 @@ def test_run_passes_equals_consecutive_calls(gpu, engines):
         assert np.array_equal(rows0[f][:nt0[f], 4:], rows1[f][:nt1[f], 4:])                      # ids, classes
         assert np.abs(rows0[f][:nt0[f], :4] - rows1[f][:nt1[f], :4]).max(initial=0) <= 1        # boxes (px)
     b.close()
+
+
+def test_pipeline_small_gallery_budget(gpu, engines):
+    """nn_budget 3, max_age 4: the gallery ring evicts on almost every frame and tracks die and are re-born inside one
+    launch group -- the pipelined tracker step (commit of frame f inside the association launch of f+1) must keep the
+    oracle's ids, states and Kalman means."""
+    n_frames, batch = 20, 10
+    sc = syn.Scene(seed=5, n_targets=9, gaps=[(1, 3, 10), (4, 8, 11), (6, 5, 7)], births={7: 6})
+    frames = sc.render_batch(0, n_frames)
+    TP = pkg("pipeline").TrackingPipeline
+    pipe = TP(engines[0], engines[1], (720, 1280), batch=batch, ring_frames=n_frames, max_persons=16, dtype="fp32", inject=True,
+              nn_budget=3, max_age=4)
+    pipe.upload(0, frames)
+    pipe.inject(0, [sc.detections(f)[:3] for f in range(n_frames)])
+    tracks, nd = pipe.run(0, n_frames)
+    torch.set_num_threads(8)
+    ref, embs, otrk = oracle_tracks(sc, N.EngineOracle(engines[1]), frames, n_frames, nn_budget=3, max_age=4)
+    for f in range(n_frames):
+        assert [t[4:] for t in tracks[f]] == [t[4:] for t in ref[f]], (f, tracks[f], ref[f])
+        if ref[f]:
+            assert np.abs(np.array([t[:4] for t in tracks[f]]) - np.array([t[:4] for t in ref[f]])).max() <= 1
+    a = pipe.tracker_core.export_arrays()
+    assert a["track_id"].tolist() == [t.track_id for t in otrk.tracks]
+    assert a["state"].tolist() == [t.state for t in otrk.tracks]
+    assert np.abs(a["mean"] - np.stack([t.mean for t in otrk.tracks])).max() < 1e-3
+    for tv, ot in zip(pipe.tracker_core.tracks, otrk.tracks):                     # gallery content and order after the evictions
+        assert len(tv.features) == len(ot.features) <= 3
+        assert np.abs(np.stack(tv.features) - np.stack(ot.features)).max() < 1e-3
+    pipe.close()
