@@ -41,6 +41,7 @@ struct Chunk {
     PinBuf<float> h_detboxes, h_scores;
     std::vector<FrameDets> dets;
     hipEvent_t done = nullptr, ev_yolo = nullptr, ev_det = nullptr, ev_reid = nullptr;
+    hipEvent_t t_begin = nullptr, t_end = nullptr, t_yolo = nullptr;   // AICAM_PIPE_TIMES: GPU timeline of the group on the main stream
 };
 
 struct Pipeline {
@@ -55,17 +56,20 @@ struct Pipeline {
     DevBuf<uint8_t> ring;
     std::vector<int> inj_count, inj_cls;
     std::vector<float> inj_boxes, inj_conf;
-    Chunk ck[2];
+    static constexpr int NCK = 2;   // launch groups in flight. 4 was measured: the GPU never idles, but the tracker chain then queues behind more conv work (84 -> 106 us/frame) and becomes the bound
+    Chunk ck[NCK];
     int dim;
     std::vector<float> last_emb;
     int last_emb_n = 0;
     // host-side wall time (seconds): issuing launch groups, waiting for a group, walking frames through the tracker
     double t_issue = 0, t_wait = 0, t_track = 0;
     long n_frames_done = 0;
-    bool split_streams = getenv("AICAM_SPLIT_STREAMS") != nullptr;   // measured: no gain on MI355X
+    bool split_streams = getenv("AICAM_SPLIT_STREAMS") != nullptr;
+    bool pipe_times = getenv("AICAM_PIPE_TIMES") != nullptr;
+    hipEvent_t prev_end = nullptr;   // measured: no gain on MI355X
     const uint8_t* host_frames = nullptr;   // run_from_host: frames of the current call in (pinned) host memory
     hipStream_t s_copy = nullptr;
-    hipEvent_t ev_copy[2] = {nullptr, nullptr};
+    hipEvent_t ev_copy[4] = {nullptr, nullptr, nullptr, nullptr};
     int host_slot0 = 0;
 
     Pipeline(Model* y, Model* r, const aic_pipeline_params& p)
@@ -97,6 +101,7 @@ struct Pipeline {
             c.h_detboxes.alloc((size_t)p.batch * p.max_det * 4), c.h_scores.alloc((size_t)p.batch * p.max_det);
             c.dets.resize(p.batch);
             HIP_CHECK(hipEventCreateWithFlags(&c.done, hipEventDisableTiming));
+            HIP_CHECK(hipEventCreate(&c.t_begin)); HIP_CHECK(hipEventCreate(&c.t_end)); HIP_CHECK(hipEventCreate(&c.t_yolo));
             HIP_CHECK(hipEventCreateWithFlags(&c.ev_yolo, hipEventDisableTiming));
             HIP_CHECK(hipEventCreateWithFlags(&c.ev_det, hipEventDisableTiming));
             HIP_CHECK(hipEventCreateWithFlags(&c.ev_reid, hipEventDisableTiming));
@@ -137,7 +142,7 @@ struct Pipeline {
         hipStream_t s = dev->s_main;
         c.frames = frames, c.first_slot = slot;
         if (host_frames) {   // PCIe-inclusive path: H2D of this group's frames on the copy stream, overlapped with the previous group's compute
-            const int ci = &c == &ck[0] ? 0 : 1;
+            const int ci = (int)(&c - &ck[0]);
             HIP_CHECK(hipMemcpyAsync(ring.p + (size_t)slot * frame_bytes, host_frames + (size_t)(slot - host_slot0) * frame_bytes,
                                      (size_t)frames * frame_bytes, hipMemcpyHostToDevice, s_copy));
             HIP_CHECK(hipEventRecord(ev_copy[ci], s_copy));
@@ -145,10 +150,12 @@ struct Pipeline {
             if (split_streams) HIP_CHECK(hipStreamWaitEvent(dev->s_reid, ev_copy[ci], 0));
         }
         const uint8_t* f0 = ring.p + (size_t)slot * frame_bytes;
+        if (pipe_times) HIP_CHECK(hipEventRecord(c.t_begin, s));
         yolo->run_frames(f0, frames, geom, s);
         // decode + NMS + read-back on the side stream: a few latency-bound blocks that overlap the
         // (CU-filling) ReID launch group instead of serialising the main stream
         hipStream_t sd = dev->s_det;
+        if (pipe_times) HIP_CHECK(hipEventRecord(c.t_yolo, s));
         HIP_CHECK(hipEventRecord(c.ev_yolo, s));
         HIP_CHECK(hipStreamWaitEvent(sd, c.ev_yolo, 0));
         yolo->decode_nms(frames, prm.conf_thresh, prm.iou_thresh, prm.max_det, &geom, sd);
@@ -204,6 +211,7 @@ struct Pipeline {
             HIP_CHECK(hipStreamWaitEvent(s, c.ev_reid, 0));
         }
         HIP_CHECK(hipStreamWaitEvent(s, c.ev_det, 0));   // join: the next chunk's YOLO reuses the head buffers
+        if (pipe_times) HIP_CHECK(hipEventRecord(c.t_end, s));
         HIP_CHECK(hipEventRecord(c.done, s));
         t_issue += now() - t0;
     }
@@ -212,6 +220,14 @@ struct Pipeline {
                  float* det_boxes, float* det_scores, int32_t* det_labels) {
         const double t0 = now();
         HIP_CHECK(hipEventSynchronize(c.done));
+        if (pipe_times) {
+            float a = 0, b = 0, g = 0;
+            (void)hipEventElapsedTime(&a, c.t_begin, c.t_yolo);
+            (void)hipEventElapsedTime(&b, c.t_yolo, c.t_end);
+            if (prev_end) (void)hipEventElapsedTime(&g, prev_end, c.t_begin);
+            fprintf(stderr, "[pipe_times] group of %d frames: idle before %.2f ms, letterbox+YOLO %.2f ms, crop+ReID %.2f ms\n", c.frames, g, a, b);
+            prev_end = c.t_end;
+        }
         const double t1 = now();
         t_wait += t1 - t0;
         std::vector<uint8_t> has;
@@ -310,9 +326,9 @@ struct Pipeline {
                 for (int k = 0; k < nchunks; ++k) {
                     {
                         std::unique_lock<std::mutex> lk(mu);
-                        cv.wait(lk, [&] { return k < consumed + 2; });
+                        cv.wait(lk, [&] { return k < consumed + NCK; });
                     }
-                    stage_a(ck[k & 1], slot + goff[k], glen[k]);
+                    stage_a(ck[k % NCK], slot + goff[k], glen[k]);
                     {
                         std::lock_guard<std::mutex> lk(mu);
                         issued = k + 1;
@@ -334,7 +350,7 @@ struct Pipeline {
                     cv.wait(lk, [&] { return issued > k; });
                     if (perr) break;
                 }
-                stage_b(ck[k & 1], goff[k], n_tracks, tracks6, track_conf, n_dets, det_boxes, det_scores, det_labels);
+                stage_b(ck[k % NCK], goff[k], n_tracks, tracks6, track_conf, n_dets, det_boxes, det_scores, det_labels);
                 {
                     std::lock_guard<std::mutex> lk(mu);
                     consumed = k + 1;
@@ -346,7 +362,7 @@ struct Pipeline {
         }
         {
             std::lock_guard<std::mutex> lk(mu);
-            consumed = nchunks + 2;   // never block the producer again
+            consumed = nchunks + NCK;   // never block the producer again
         }
         cv.notify_all();
         producer.join();
