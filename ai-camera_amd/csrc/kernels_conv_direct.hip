@@ -133,13 +133,21 @@ static bool try_c16(const ConvArgs& a, hipStream_t s) {
 // Here one 8-wave block per CU walks many 8 x 32-pixel tiles:
 //  * the weights never touch LDS: wave w keeps the A fragments of its 32 output channels (half w>>2) for all 18
 //    K-steps in 144 VGPRs, loaded once per kernel;
-//  * the input patch (10 x 34 pixels x 64 channels, eight 16-byte planes, conflict-free, tap shift = ds_read
-//    immediate) is triple-buffered: the LDS-DMA of tile t+2 is issued right after the one barrier of tile t and has
-//    two tiles of MFMAs (144 per wave each) to land; no barrier and no global load inside the K loop;
-//  * waves w and w+4 share a SIMD and a pixel group (same B fragments, other channel half), so one wave's ds_reads
-//    and epilogue sit under its partner's MFMAs.
+//  * the input patch (10 x 34 pixels x 64 channels, pixel-major: 128 bytes per pixel, the eight 16-byte channel chunks
+//    XOR-swizzled by the column so a fragment read is conflict-free) is triple-buffered; a wave's LDS-DMA instruction
+//    fetches 8 pixels x 128 contiguous bytes (8 cache lines; the planar layout used before touched 64 per
+//    instruction); no global load inside the K loop;
+//  * a wave owns 4 output rows x 16 pixels: an input-row fragment is read once per (tap column, channel half) and
+//    feeds up to three output rows (36 ds_reads per tile instead of 72), software-pipelined by one group of 24 MFMAs
+//    with hand-placed lgkmcnt waits;
+//  * waves w and w+4 share a SIMD and a pixel group (other channel half) and run half a tile apart (two barriers per
+//    tile), so one wave's barrier wait, DMA issue and epilogue sit under its partner's MFMAs.
+// Measured (tools/conv_bench.py, 7680 crops): 859 TFLOP/s without / 774 with residual; without stores 1150, with
+// L2-resident input and no stores 1275 -- the remaining gap is the 2 GB of output writes, which do not overlap.
 template <int ACT, int RES>
-__global__ __launch_bounds__(512) void conv3x3_c64_resident_kernel(const ConvArgs a, int n_tiles, int tiles_x, int tiles_y) {
+__global__ __launch_bounds__(512) void conv3x3_c64_resident_kernel(const ConvArgs a, int n_tiles, int tiles_x, int tiles_y, int nblk) {
+    // nblk = gridDim.x as an argument: read through the dispatch packet it is a scalar load inside the tile loop, and a
+    // scalar load in flight makes every compiler-made LDS wait an lgkmcnt(0)
     constexpr int TH = 8, TW = 32, PW = TW + 2, PH = TH + 2, NPIX = PW * PH, NPASS = (NPIX + 63) / 64, NPIXP = NPASS * 64;
     constexpr int PLANE = NPIXP * 16, PBUF = 8 * PLANE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -158,122 +166,213 @@ __global__ __launch_bounds__(512) void conv3x3_c64_resident_kernel(const ConvArg
 #pragma unroll
         for (int s2 = 0; s2 < 18; ++s2) wreg[s2][j] = *reinterpret_cast<const half8*>(wr + 32 * s2);
     }
-    floatx4 bi[2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int s2 = 0; s2 < 18; ++s2) asm volatile("" :: "v"(wreg[s2][0]), "v"(wreg[s2][1]));    // weights landed: no compiler-made vmcnt(0) inside the loop
+    // bias in this wave's accumulator order, parked in LDS behind the patch buffers (8 VGPRs the K loop needs more)
+    float* bias_l = reinterpret_cast<float*>(smem + 3 * PBUF) + (ch * 4 + q) * 8;
+    if (pg == 0 && r == 0) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) bi[j][e] = a.bias[32 * ch + perm_ch<2>(j, q, e)];
-
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bias_l[4 * j + e] = a.bias[32 * ch + perm_ch<2>(j, q, e)];
+    }
     // tile order: the tiles of one image stay on one XCD (blocks b, b+8, ... share an L2) so halo rows are L2 hits
     const int tpi = tiles_x * tiles_y;
     auto tile_of = [&](int k) -> int {
-        if (tpi == 8 && (gridDim.x & 63) == 0) {
-            const int xcd = blockIdx.x & 7, sl = blockIdx.x >> 3, per = gridDim.x >> 6;     // images in flight per XCD
+        if (tpi == 8 && (nblk & 63) == 0) {
+            const int xcd = blockIdx.x & 7, sl = blockIdx.x >> 3, per = nblk >> 6;     // images in flight per XCD
             const int im = ((sl >> 3) + per * k) * 8 + xcd;
             return im * 8 + (sl & 7);
         }
-        return blockIdx.x + k * gridDim.x;
+        return blockIdx.x + k * nblk;
     };
     auto issue_patch = [&](int tile, int buf) {
         const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, img = tile / tpi;
         const int oy0 = ty * TH, ox0 = tx * TW;
+        int ln = lane;
+        asm volatile("" : "+v"(ln));            // recompute the per-pass lane terms here: hoisted out of the tile loop they cost 12+ VGPRs
 #pragma unroll
         for (int i = 0; i < NPASS; ++i) {
-            const int p = i * 64 + lane;
+            const int sl = i * 512 + wv * 64 + ln;              // 16-byte slot of the patch image: pixel sl / 8, slot sl % 8
+            const int p = sl >> 3, j = sl & 7;
             const int py = p / PW, px = p - py * PW;
+            const int c = j ^ (px & 7);                         // source-side swizzle: slot j of a pixel holds channel chunk j ^ (column & 7)
             const int iy = oy0 + py - 1, ix = ox0 + px - 1;
             const bool ok = p < NPIX && tile < n_tiles && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-            const half_t* src = ok ? xg + ((size_t)(img * a.H + iy) * a.W + ix) * a.x_cs + a.x_coff + wv * 8 : zero;
+            const half_t* src = ok ? xg + ((size_t)(img * a.H + iy) * a.W + ix) * a.x_cs + a.x_coff + c * 8 : zero;
             asm volatile("" : "+v"(src));
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + buf * PBUF + wv * PLANE + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + buf * PBUF + i * 8192 + wv * 1024), 16, 0, 0);
         }
     };
 
-    int xa[4];                                  // this lane's pixel of MFMA tile i in plane q of buffer 0, tap (0,0)
+    // A wave owns 4 output rows x 16 pixels (row group rg, column half cx): an input-row fragment is read from LDS
+    // once per (tap column, channel half) and feeds the up-to-three output rows it is a tap row of -- 36 ds_reads per
+    // tile instead of 72, which takes the LDS pipe (shared by the CU's 8 waves) off the critical path.
+    const int rg = pg >> 1, cx = pg & 1;
+    int xk[3];                                  // byte address of (patch row 4 rg, column cx 16 + r + kw, channel chunk q) in buffer 0
 #pragma unroll
-    for (int i = 0; i < 4; ++i) xa[i] = q * PLANE + ((2 * pg + (i >> 1)) * PW + (i & 1) * 16 + r) * 16;
+    for (int kw = 0; kw < 3; ++kw) {
+        const int px = cx * 16 + r + kw;
+        xk[kw] = ((4 * rg * PW + px) * 8 + (q ^ (px & 7))) * 16;
+    }
 
     half_t* yg = reinterpret_cast<half_t*>(a.y);
-    const half_t* rg = reinterpret_cast<const half_t*>(a.res);
-    const int trips = (n_tiles + (int)gridDim.x - 1) / (int)gridDim.x;      // same trip count for every block
+    const half_t* resg = reinterpret_cast<const half_t*>(a.res);
+    const int trips = (n_tiles + nblk - 1) / nblk;                          // same trip count for every block
     issue_patch(tile_of(0), 0);
     issue_patch(tile_of(1), 1);                                             // (zero page when past the end)
-    int buf = 0;                                                            // k % 3
-    for (int k = 0; k < trips; ++k) {
-        const int tile = tile_of(k);
-        // In flight, oldest first: patch k | stores k-2 | patch k+1 | stores k-1.  Leaving NPASS operations
-        // outstanding retires patch k for certain (a conservative count: it also retires the head of patch k+1).
-        wait_vmcnt<NPASS>();
-        __builtin_amdgcn_s_barrier();           // patch k complete for everyone; everyone is done reading buffer (k+2) % 3
-        {
-            int nb = buf + 2; if (nb >= 3) nb -= 3;
-            issue_patch(tile_of(k + 2), nb);
-        }
-        if (tile < n_tiles) {
-            const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, img = tile / tpi;
-            const size_t pix0 = ((size_t)img * a.Ho + ty * TH) * a.Wo + tx * TW;
-            const int boff = buf * PBUF;
-            half8 rv[4];                        // residual vectors: requested now, they land under the K loop
-            if constexpr (RES == 1) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const size_t pix = pix0 + (size_t)(2 * pg + (i >> 1)) * a.Wo + (i & 1) * 16 + r;
-                    rv[i] = *reinterpret_cast<const half8*>(rg + pix * a.r_cs + a.r_coff + 32 * ch + 8 * q);
-                }
-            }
-            floatx4 acc[4][2];
+
+    floatx4 acc[4][2];
+    half8 rv[4];
+    size_t pix0 = 0;
+    // The residual vectors are fetched with inline-asm loads: an ordinary load inside this loop makes the compiler
+    // place s_waitcnt vmcnt(0) in front of the first ds_read of every tile (it then orders LDS reads behind the
+    // in-flight LDS-DMA), which exposes the whole DMA latency.  They are requested at the start of a tile and waited
+    // for (res_wait, counted like the patches) just before the epilogue.
+    // addresses = uniform 64-bit tile base (SGPRs) + one 32-bit lane offset (VGPR) + a uniform row step
+    const unsigned yl0 = (unsigned)(((4 * rg * a.Wo + cx * 16 + r) * a.y_cs + a.y_coff + 32 * ch + 8 * q) * 2);
+    const unsigned rl0 = (unsigned)(((4 * rg * a.Wo + cx * 16 + r) * a.r_cs + a.r_coff + 32 * ch + 8 * q) * 2);
+    const unsigned ystep = (unsigned)(a.Wo * a.y_cs * 2), rstep = (unsigned)(a.Wo * a.r_cs * 2);
+    auto begin = [&](int tile) {
+        const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, img = tile / tpi;
+        pix0 = ((size_t)img * a.Ho + ty * TH) * a.Wo + tx * TW;
+        if constexpr (RES == 1) {
+            const char* rb = reinterpret_cast<const char*>(resg) + pix0 * a.r_cs * 2;
 #pragma unroll
             for (int i = 0; i < 4; ++i)
+                asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(rv[i]) : "v"(rl0 + i * rstep), "s"(rb) : "memory");
+        }
+    };
+    auto init_acc = [&]() {
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = bi[j];
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int s2 = 0; s2 < 18; ++s2) {
-                const int tap = s2 >> 1, cc = s2 & 1, kh = tap / 3, kw = tap - 3 * kh;
-                const int off = cc * 4 * PLANE + (kh * PW + kw) * 16;
-                half8 xf[4];
+            for (int j = 0; j < 2; ++j) acc[i][j] = *reinterpret_cast<const floatx4*>(bias_l + 4 * j);
+    };
+    // K loop: six (tap column, channel half) groups of six input-row fragments.  Fragment ir of group g feeds the
+    // output rows ir - kh (2, 4, 6, 6, 4, 2 MFMAs) and is refilled with group g+1's fragment as soon as those are
+    // issued, so every ds_read has a whole group of MFMAs (24) to land under, with 24 VGPRs of fragments in all.
+    // The reads and their waits are inline asm: with a global_load_lds in flight the compiler turns every wait it
+    // places itself into lgkmcnt(0) / vmcnt(0) (it treats the LDS-DMA as a FLAT access that may touch both), i.e.
+    // one fully exposed LDS round trip per group.  LDS returns in order and the rotation leaves exactly five newer
+    // reads behind the fragment about to be used (5 - ir in the last group, which refills nothing).
+    half8 xf[6];
+    int xb[3];                                  // xk + buffer offset of the current tile
+    auto xread = [&xf, &xb](auto g, auto ir) {
+        constexpr int gg = decltype(g)::value, ii = decltype(ir)::value, kw = gg >> 1;
+        const int ad = (gg & 1) ? (xb[kw] ^ 64) : xb[kw];      // channel half 1: chunk q + 4, i.e. slot ^ 4
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xf[ii]) : "v"(ad), "n"(ii * PW * 128));
+    };
+    auto xwait = [&xf](auto n, auto ir) {
+        asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(xf[decltype(ir)::value]) : "n"(decltype(n)::value));
+    };
+    auto kfirst = [&]() {
+        static_for<6>([&](auto ir) { xread(std::integral_constant<int, 0>{}, ir); });
+    };
+    auto kpart = [&](auto part) {               // groups 3 part .. 3 part + 2: 72 MFMAs
+        static_for<3>([&](auto gi) {
+            constexpr int g = 3 * decltype(part)::value + decltype(gi)::value, kw = g >> 1, cc = g & 1;
+            static_for<6>([&](auto ir_c) {
+                constexpr int ir = decltype(ir_c)::value;
+                xwait(std::integral_constant<int, (g == 5 ? 5 - ir : 5)>{}, ir_c);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) xf[i] = *reinterpret_cast<const half8*>(smem + xa[i] + boff + off);
+                for (int kh = 0; kh < 3; ++kh) {
+                    const int i = ir - kh;
+                    if (i < 0 || i > 3) continue;
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[s2][j], xf[i], acc[i][j], 0, 0, 0);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const size_t pix = pix0 + (size_t)(2 * pg + (i >> 1)) * a.Wo + (i & 1) * 16 + r;
-                const int n = 32 * ch + 8 * q;
-                float v[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = acc[i][e >> 2][e & 3];
-                if constexpr (RES == 1) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += (float)rv[i][e];
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[(kh * 3 + kw) * 2 + cc][j], xf[ir], acc[i][j], 0, 0, 0);
                 }
+                if constexpr (g + 1 < 6) xread(std::integral_constant<int, g + 1>{}, ir_c);
+                __builtin_amdgcn_sched_barrier(0);          // keep the read / MFMA interleave as written
+            });
+        });
+    };
+    auto finish = [&](bool valid) {
+        char* yb = reinterpret_cast<char*>(yg) + pix0 * a.y_cs * 2;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = act_fast<ACT>(v[e]);
-                const half8 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3], (half_t)v[4], (half_t)v[5], (half_t)v[6], (half_t)v[7]};
-                *reinterpret_cast<half8*>(yg + pix * a.y_cs + a.y_coff + n) = o;
+        for (int i = 0; i < 4; ++i) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = acc[i][e >> 2][e & 3];
+            if constexpr (RES == 1) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += (float)rv[i][e];
             }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = act_fast<ACT>(v[e]);
+            const half8 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3], (half_t)v[4], (half_t)v[5], (half_t)v[6], (half_t)v[7]};
+            if (valid) *reinterpret_cast<half8*>(yb + (size_t)(yl0 + i * ystep)) = o;
+        }
+    };
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+
+    // Two barriers per tile; the waves of channel half 1 run HALF A TILE behind those of half 0 (they pass one extra
+    // barrier first, the early ones one extra at the end).  A SIMD holds one wave of each group, so one wave's barrier
+    // wait, LDS-DMA issue, first ds_reads and epilogue sit under its partner's 72-MFMA half instead of both waves
+    // leaving the matrix pipe idle together.  Barrier 2k: early group starts tile k, late group is mid tile k-1;
+    // barrier 2k+1: late group starts tile k (patch k is complete since barrier 2k), early group is mid tile k and
+    // nobody reads buffer (k+2) % 3 any more: the late group issues its planes of patch k+2 right there, the early
+    // group after its epilogue (no accumulators live while the addresses are formed).
+    // vmcnt, oldest first -- early group at the top of tile k: patch k | stores k-1 | patch k+1; late group mid tile
+    // k: patch k+1 | stores k-1 | (residual k |) patch k+2: the patch that must have landed before the barrier is the
+    // oldest, NPASS + 4 may stay in flight (NPASS in the first trip, which has no stores yet).
+    const bool late = ch == 1;
+    if (late) {
+        wait_vmcnt<NPASS>();
+        __builtin_amdgcn_s_barrier();
+    }
+    int buf = 0;                                                            // k % 3
+    for (int k = 0; k < trips; ++k) {
+        const bool valid = tile_of(k) < n_tiles;            // a tile past the end (last trip only) computes on the zero
+        const int tile = valid ? tile_of(k) : n_tiles - 1;  // page and stores nothing: no divergent control flow around the barriers
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) xb[kw] = xk[kw] + buf * PBUF;
+        int nb = buf + 2; if (nb >= 3) nb -= 3;
+        if (!late) {
+            if (k == 0) wait_vmcnt<NPASS>(); else wait_vmcnt<NPASS + 4>();
+            __builtin_amdgcn_s_barrier();
+            begin(tile); kfirst(); init_acc(); kpart(P0{});
+            __builtin_amdgcn_s_barrier();
+            kpart(P1{});
+            if constexpr (RES == 1)                         // residual landed (behind it only patch k+1, a whole tile old)
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(rv[0]), "+v"(rv[1]), "+v"(rv[2]), "+v"(rv[3]) :: "memory");
+            finish(valid);
+            issue_patch(tile_of(k + 2), nb);
+        } else {
+            __builtin_amdgcn_s_barrier();
+            begin(tile);
+            issue_patch(tile_of(k + 2), nb);
+            kfirst(); init_acc(); kpart(P0{});
+            if (k == 0) wait_vmcnt<NPASS>(); else wait_vmcnt<NPASS + 4>();
+            __builtin_amdgcn_s_barrier();
+            kpart(P1{});
+            if constexpr (RES == 1)                         // residual landed; patch k+2 (issued after it) may stay in flight
+                asm volatile("s_waitcnt vmcnt(%4)" : "+v"(rv[0]), "+v"(rv[1]), "+v"(rv[2]), "+v"(rv[3]) : "n"(NPASS) : "memory");
+            finish(valid);
         }
         if (++buf == 3) buf = 0;
     }
+    if (!late) __builtin_amdgcn_s_barrier();
     wait_vmcnt<0>();
 }
 
 static bool try_c64_resident(const ConvArgs& a, hipStream_t s) {
-    static const int on = [] { const char* e = getenv("AICAM_C64R"); return e ? atoi(e) : 1; }();   // 0: off, 1 (default): layers without residual (+6 % on them), 2: also with residual (slower: its loads are exposed)
+    static const int on = [] { const char* e = getenv("AICAM_C64R"); return e ? atoi(e) : 2; }();   // 0: off, 1: layers without residual only, 2 (default): also with residual (612 -> 774 TFLOP/s against the 4-wave patch kernel)
     if (!on || (a.res_mode != 0 && on < 2) || a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.Cin != 64 || a.Cout != 64 || a.out_f32 || a.Kp != 576) return false;
-    if (a.W % 32 || a.H % 8 || a.Ho != a.H || a.Wo != a.W || a.M < 1500000 || (long)a.M * a.x_cs >= (1l << 31)) return false;
+    if (a.W % 32 || a.H % 8 || a.Ho != a.H || a.Wo != a.W || a.M < 1500000 || (long)a.M * a.x_cs >= (1l << 31) ||
+        (long)a.M * a.y_cs >= (1l << 31) || (a.res_mode != 0 && (long)a.M * a.r_cs >= (1l << 31))) return false;
     if ((a.x_cs | a.x_coff | a.y_cs | a.y_coff | a.r_cs | a.r_coff) % 8) return false;
     const int tiles_x = a.W / 32, tiles_y = a.H / 8, n_img = a.M / (a.H * a.W), n_tiles = n_img * tiles_x * tiles_y;
-    constexpr size_t lds = (size_t)3 * 8 * 384 * 16;
+    constexpr size_t lds = (size_t)3 * 8 * 384 * 16 + 256;
     auto launch = [&](auto kfn) {
         static bool attr = false;
         if (!attr) {
             HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             attr = true;
         }
-        hipLaunchKernelGGL(kfn, dim3(256), dim3(512), lds, s, a, n_tiles, tiles_x, tiles_y);
+        hipLaunchKernelGGL(kfn, dim3(256), dim3(512), lds, s, a, n_tiles, tiles_x, tiles_y, 256);
         KCHECK();
     };
     if (a.act == 2 && a.res_mode == 0) launch(conv3x3_c64_resident_kernel<2, 0>);
