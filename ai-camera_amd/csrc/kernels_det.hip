@@ -117,19 +117,22 @@ __global__ __launch_bounds__(NMS_THREADS) void select_sort_nms_kernel(const DetA
     // counters live at the end of the dynamic region: a static __shared__ in front of it would shift
     // the 16-byte alignment of the dynamic base (cdna_hip_programming.md Guideline 17)
     int& s_count = flags[NMS_THREADS];
-    int& s_kept = flags[NMS_THREADS + 1];
 
     const int img = blockIdx.x, t = threadIdx.x;
     const float* ml = a.max_logit + (size_t)img * a.n_anchors;
-    if (t == 0) { s_count = 0; s_kept = 0; }
+    if (t == 0) s_count = 0;
     __syncthreads();
-    // 1. select (unordered append; the sort fixes the order)
-    for (int i = t; i < a.n_anchors; i += NMS_THREADS) {
-        const float v = ml[i];
-        if (v >= a.logit_thr) {
-            const int pos = atomicAdd(&s_count, 1);
-            keys[pos] = ((unsigned long long)ordered_bits(v) << 32) | (unsigned int)(0xFFFFFFFFu - (unsigned int)i);
-        }
+    // 1. select (unordered append; the sort fixes the order): one LDS atomic per wave and round, not one per candidate
+    for (int i0 = 0; i0 < a.n_anchors; i0 += NMS_THREADS) {
+        const int i = i0 + t;
+        const float v = i < a.n_anchors ? ml[i] : 0.f;
+        const bool pass = i < a.n_anchors && v >= a.logit_thr;
+        const unsigned long long bal = __ballot(pass);
+        int base = 0;
+        if ((t & 63) == 0 && bal) base = atomicAdd(&s_count, __popcll(bal));
+        base = __shfl(base, 0);
+        if (pass) keys[base + __popcll(bal & ((1ull << (t & 63)) - 1ull))] =
+            ((unsigned long long)ordered_bits(v) << 32) | (unsigned int)(0xFFFFFFFFu - (unsigned int)i);
     }
     __syncthreads();
     const int n = s_count;
@@ -152,11 +155,17 @@ __global__ __launch_bounds__(NMS_THREADS) void select_sort_nms_kernel(const DetA
         }
     }
     if (t == 0) a.n_cand[img] = n;
-    // 3. greedy NMS in chunks of NMS_THREADS candidates
+    // 3. greedy NMS in chunks of NMS_THREADS candidates (thread = candidate, sorted order = chunk, wave, lane).  A chunk
+    //    first drops what the boxes kept so far suppress; then its 16 wave tiles take turns: everyone still waiting tests
+    //    against the boxes the previous tile kept, and the tile's own 64 candidates are walked greedily with ballot /
+    //    readlane only.  One block barrier per tile instead of two per kept box (16-wave barriers and the instruction
+    //    issue of 1024 threads made each kept box cost ~3 500 cycles: half of this kernel with ~270 boxes kept).
     const float4* boxes = reinterpret_cast<const float4*>(a.boxes) + (size_t)img * a.n_anchors;
     const int* labels = a.labels + (size_t)img * a.n_anchors;
-    for (int c0 = 0; c0 < n; c0 += NMS_THREADS) {
-        if (s_kept >= a.max_det) break;
+    int* s_nk = flags;                          // two alternating slots: kept count after wave tile w lives in s_nk[w & 1]
+    const int wv = t >> 6, lane = t & 63;
+    int nk = 0;                                 // boxes kept so far (block-uniform register copy)
+    for (int c0 = 0; c0 < n && nk < a.max_det; c0 += NMS_THREADS) {
         const int ci = c0 + t;
         const bool have = ci < n;
         int anchor = 0, lab = -1;
@@ -167,41 +176,54 @@ __global__ __launch_bounds__(NMS_THREADS) void select_sort_nms_kernel(const DetA
             lab = labels[anchor];
         }
         bool alive = have;
-        const int nk0 = s_kept;
-        for (int k = 0; k < nk0 && alive; ++k)
-            if (klab[k] == lab && iou_xyxy(kbox[k], bx) > a.iou_thr) alive = false;
-        flags[t] = alive ? 1 : 0;
-        __syncthreads();
-        const int lim = min(NMS_THREADS, n - c0);
-        for (int i = 0; i < lim; ++i) {
-            if (!flags[i]) continue;            // block-uniform (LDS broadcast)
-            const int slot = s_kept;            // uniform: only thread i updates it below, after the barrier
-            if (slot >= a.max_det) break;
-            if (t == i) {
-                kbox[slot] = bx;
-                klab[slot] = lab;
-                const size_t o = (size_t)img * a.max_det + slot;
-                reinterpret_cast<float4*>(a.out_boxes)[o] = bx;
-                a.out_scores[o] = 1.0f / (1.0f + expf(-ml[anchor]));
-                a.out_labels[o] = lab;
-                if (a.out_boxes_orig) {
-                    // image_processing.py:161-181: remove padding, divide by ratio, clip
-                    float4 ob;
-                    ob.x = fminf(fmaxf((bx.x - a.pad_w) / a.ratio, 0.f), (float)a.orig_w);
-                    ob.y = fminf(fmaxf((bx.y - a.pad_h) / a.ratio, 0.f), (float)a.orig_h);
-                    ob.z = fminf(fmaxf((bx.z - a.pad_w) / a.ratio, 0.f), (float)a.orig_w);
-                    ob.w = fminf(fmaxf((bx.w - a.pad_h) / a.ratio, 0.f), (float)a.orig_h);
-                    reinterpret_cast<float4*>(a.out_boxes_orig)[o] = ob;
-                }
+        int seen = 0;                           // this candidate has been tested against kbox[0 .. seen)
+        for (int w = 0; w < NMS_THREADS / 64 && nk < a.max_det; ++w) {
+            if (wv >= w) {                      // (wave-uniform) earlier tiles of this chunk are settled
+                for (int k = seen; k < nk && alive; ++k)
+                    if (klab[k] == lab && iou_xyxy(kbox[k], bx) > a.iou_thr) alive = false;
+                seen = nk;
             }
-            __syncthreads();
-            if (t == i) s_kept = slot + 1;
-            if (t > i && flags[t] && lab == klab[slot] && iou_xyxy(kbox[slot], bx) > a.iou_thr) flags[t] = 0;
-            __syncthreads();
+            if (wv == w) {                      // this wave's 64 candidates: greedy walk with wave operations only
+                unsigned long long m = __ballot(alive);
+                int cnt = nk;
+                while (m && cnt < a.max_det) {
+                    const int l = __builtin_amdgcn_readfirstlane(__ffsll((long long)m) - 1);
+                    float4 kb;
+                    kb.x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bx.x), l));
+                    kb.y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bx.y), l));
+                    kb.z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bx.z), l));
+                    kb.w = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bx.w), l));
+                    const int kl = __builtin_amdgcn_readlane(lab, l);
+                    if (lane == l) {
+                        kbox[cnt] = bx;
+                        klab[cnt] = lab;
+                        const size_t o = (size_t)img * a.max_det + cnt;
+                        reinterpret_cast<float4*>(a.out_boxes)[o] = bx;
+                        a.out_scores[o] = 1.0f / (1.0f + expf(-ml[anchor]));
+                        a.out_labels[o] = lab;
+                        if (a.out_boxes_orig) {
+                            // image_processing.py:161-181: remove padding, divide by ratio, clip
+                            float4 ob;
+                            ob.x = fminf(fmaxf((bx.x - a.pad_w) / a.ratio, 0.f), (float)a.orig_w);
+                            ob.y = fminf(fmaxf((bx.y - a.pad_h) / a.ratio, 0.f), (float)a.orig_h);
+                            ob.z = fminf(fmaxf((bx.z - a.pad_w) / a.ratio, 0.f), (float)a.orig_w);
+                            ob.w = fminf(fmaxf((bx.w - a.pad_h) / a.ratio, 0.f), (float)a.orig_h);
+                            reinterpret_cast<float4*>(a.out_boxes_orig)[o] = ob;
+                        }
+                        alive = false;
+                    }
+                    if (alive && lab == kl && iou_xyxy(kb, bx) > a.iou_thr) alive = false;
+                    m = __ballot(alive);
+                    ++cnt;
+                }
+                if (lane == 0) s_nk[w & 1] = cnt;
+            }
+            __syncthreads();                    // the tile's kept boxes and count are visible
+            nk = s_nk[w & 1];
         }
-        __syncthreads();
+        __syncthreads();                        // (slot reuse across chunks)
     }
-    if (t == 0) a.num_dets[img] = min(s_kept, a.max_det);
+    if (t == 0) a.num_dets[img] = min(nk, a.max_det);
 }
 
 void launch_decode(const DetArgs& a, hipStream_t s) {
