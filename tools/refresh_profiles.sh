@@ -7,8 +7,6 @@ R=$PWD
 O=$R/gpurun_out/refresh
 rm -rf $O && mkdir -p $O
 TAG=${1:-r01}
-python bench.py > $O/bench.json 2> $O/bench.err
-tail -1 $O/bench.json | cut -c1-300
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --cpu-frames 0 --no-pcie > $O/bench_under_rocprof.json 2> $O/trace.log
 AICAM_NO_TAPER=1 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -- python3 $R/bench.py --steps 1 --warmup 1 --cpu-frames 0 --no-pcie > /dev/null 2> $O/fetch.log
@@ -20,5 +18,8 @@ head -24 $O/conv_layers.txt > $O/kernel_summary.txt
 cp $(ls $T/*_kernel_stats.csv | head -1) $O/kernel_stats.csv
 python tools/pmc_traffic.py $O/fetch $O/write "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --steps 1 --warmup 1 with AICAM_NO_TAPER=1 (full 512-frame launch groups only); FETCH_SIZE x2 (gfx950 correction of MI355X_MICROARCH.md)" > $O/pmc_traffic.txt
 cp profiles/pmc_traffic.json $O/pmc_traffic.json
+# the bench line last: its roofline.traffic reads the profiles/pmc_traffic.json written just above
+python bench.py > $O/bench.json 2> $O/bench.err
+tail -1 $O/bench.json | cut -c1-300
 rm -rf $O/trace $O/fetch $O/write          # the raw traces stay on the box (tens of MB); the summaries travel back
 ls -la $O
