@@ -467,7 +467,11 @@ static void launch_conv_t(const ConvArgs& a, hipStream_t s) {
         else if (blocks128 * ceil_div(c, 128) >= 128) launch_variant<T, 4, 4, 2, 2>(a, s);   // 128 px x 128 ch
         else launch_variant<T, 2, 2, 2, 2>(a, s);                                       // 64 px x 64 ch (small maps)
     } else if (c % 80 == 0) {
-        launch_variant<T, 2, 5, 4, 1>(a, s);                                            // 128 px x 80 ch
+        // YOLOv8's class branches (Cout = nc = 80).  512 px x 80 ch on 8 waves once there are tiles for every CU:
+        // 428 -> 499 TFLOP/s on cls0.1 (80 -> 80, 3x3 at 80 x 80), +7..16 % on the others (tools/conv_bench.py); AICAM_C80=0: off
+        static const bool big80 = [] { const char* e = getenv("AICAM_C80"); return !e || atoi(e) != 0; }();
+        if (big80 && conv_impl() == 2 && ceil_div(a.M, 512) >= 256) launch_dma<T, 4, 5, 8, 1, 3>(a, s);
+        else launch_variant<T, 2, 5, 4, 1>(a, s);                                       // 128 px x 80 ch
     } else if (c % 64 == 0) {
         if (blocks128 >= 512) launch_variant<T, 4, 4, 4, 1>(a, s);                      // 256 px x 64 ch
         else launch_variant<T, 2, 4, 4, 1>(a, s);                                       // 128 px x 64 ch

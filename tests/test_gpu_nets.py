@@ -212,6 +212,26 @@ def test_reid_large_batch_kernels(gpu, engines, dtype, tol_split, tol, n_crops):
     big.close(), small.close()
 
 
+@pytest.mark.parametrize("dtype,tol", [("fp32", 5e-4), ("fp16", 6e-2)])
+def test_yolo_large_batch_kernels(gpu, engines, dtype, tol):
+    """The detector's big-tile kernels (512 x 80 class-branch tiles, 16-channel direct kernel, patch forms) engage only
+    when a launch group has tiles for every CU: the raw head of 48 frames in ONE group must equal the head of the same
+    frames run 4 at a time (small tiles; differences = K summation order and fp16 rounding of intermediate tensors)."""
+    rng = np.random.default_rng(11)
+    x = rng.uniform(0, 1, (48, 3, 640, 640)).astype(np.float32)
+    big = HipEngine(engines[0], dtype=dtype, max_items=48, warm_up=False)
+    small = HipEngine(engines[0], dtype=dtype, max_items=4, warm_up=False)
+    dfl_b, cls_b = big.yolo_head_np(x)
+    worst = 0.0
+    for i in (0, 20, 44):
+        dfl_s, cls_s = small.yolo_head_np(x[i:i + 4])
+        worst = max(worst, np.abs(dfl_b[i:i + 4] - dfl_s).max(), np.abs(cls_b[i:i + 4] - cls_s).max())
+    print(f"[{dtype}] 48-frame group vs 4-frame groups: max |diff| of the raw head {worst:.2e}")
+    assert worst < tol and np.isfinite(dfl_b).all() and np.isfinite(cls_b).all()
+    assert cls_b.std() > 0.05 and dfl_b.std() > 0.05          # a real head, not zeros
+    big.close(), small.close()
+
+
 def test_hip_engine_trt_surface(gpu, engines):
     """TRTEngine-compatible dict API on torch tensors (trt_engine.py:151-216)."""
     eng = HipEngine(engines[0], dtype="fp32", max_items=2)
