@@ -372,7 +372,9 @@ static bool try_c64_resident(const ConvArgs& a, hipStream_t s) {
             HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             attr = true;
         }
-        hipLaunchKernelGGL(kfn, dim3(256), dim3(512), lds, s, a, n_tiles, tiles_x, tiles_y, 256);
+        static const int split = [] { const char* e = getenv("AICAM_C64R_SPLIT"); return e ? std::max(1, atoi(e)) : 1; }();
+        const int nblk = 256 * split;
+        hipLaunchKernelGGL(kfn, dim3(nblk), dim3(512), lds, s, a, n_tiles, tiles_x, tiles_y, nblk);
         KCHECK();
     };
     if (a.act == 2 && a.res_mode == 0) launch(conv3x3_c64_resident_kernel<2, 0>);
