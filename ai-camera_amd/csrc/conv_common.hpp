@@ -282,6 +282,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
     else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
     else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
     else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
     else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");

@@ -282,25 +282,48 @@ void Model::run_range(size_t op0, size_t op1, int i0, int n, hipStream_t s) {
             continue;
         }
         if (v[0] == OP_CONV) {
-            const ConvWeights& w = weights[v[15]];
-            ConvArgs a{};
-            a.x = sb.p, a.w = w.w.p, a.bias = w.bias.p, a.y = db.p;
-            a.x_cs = sb.c, a.x_coff = v[2], a.H = sb.h, a.W = sb.w, a.Cin = w.cin_eff;
-            a.y_cs = db.c, a.y_coff = v[5], a.Ho = db.h, a.Wo = db.w, a.Cout = w.cout;
-            a.res = nullptr, a.r_cs = 0, a.r_coff = 0, a.res_mode = v[14], a.act = v[11];
-            if (v[14]) { a.res = at(bufs[v[12]]), a.r_cs = bufs[v[12]].c, a.r_coff = v[13]; }
-            a.KH = w.kh, a.KW = w.kw, a.stride = v[9], a.pad = v[10];
-            a.Kp = w.Kp, a.M = n * db.h * db.w, a.out_f32 = db.f32, a.cout_pad = w.cout_pad, a.zero = d_zero.p;
-            a.tap_rows = 0;
-            for (int kh = 0; kh < w.kh; ++kh) a.tap_rows |= 1u << (kh * w.kw);
-            AIC_REQUIRE(w.kh * w.kw <= 25, AIC_ERR_FORMAT, "kernel window larger than 5x5");
-            const double fl = 2.0 * a.M * (double)w.cout * w.cin * w.kh * w.kw;
-            const double by = ((double)n * sb.h * sb.w * w.cin + (double)a.M * w.cout) * (dtype == AIC_F16 ? 2 : 4) +
-                              (double)w.cout * w.cin * w.kh * w.kw * (dtype == AIC_F16 ? 2 : 4);
-            if (prof_conv) {
-                if (!span_open) { dev->prof_begin(PROF_CONV, s, 0, 0); span_open = true; }
-                dev->prof_account(PROF_CONV, fl, by);
+            double fl = 0, by = 0;
+            auto conv_args = [&](size_t k) {
+                const int* u = ops[k].v;
+                BufDesc xb = bufs[u[1]], yb = bufs[u[4]];
+                xb.p = at(xb), yb.p = at(yb);
+                const ConvWeights& w = weights[u[15]];
+                ConvArgs a{};
+                a.x = xb.p, a.w = w.w.p, a.bias = w.bias.p, a.y = yb.p;
+                a.x_cs = xb.c, a.x_coff = u[2], a.H = xb.h, a.W = xb.w, a.Cin = w.cin_eff;
+                a.y_cs = yb.c, a.y_coff = u[5], a.Ho = yb.h, a.Wo = yb.w, a.Cout = w.cout;
+                a.res = nullptr, a.r_cs = 0, a.r_coff = 0, a.res_mode = u[14], a.act = u[11];
+                if (u[14]) { a.res = at(bufs[u[12]]), a.r_cs = bufs[u[12]].c, a.r_coff = u[13]; }
+                a.KH = w.kh, a.KW = w.kw, a.stride = u[9], a.pad = u[10];
+                a.Kp = w.Kp, a.M = n * yb.h * yb.w, a.out_f32 = yb.f32, a.cout_pad = w.cout_pad, a.zero = d_zero.p;
+                a.tap_rows = 0;
+                for (int kh = 0; kh < w.kh; ++kh) a.tap_rows |= 1u << (kh * w.kw);
+                AIC_REQUIRE(w.kh * w.kw <= 25, AIC_ERR_FORMAT, "kernel window larger than 5x5");
+                fl += 2.0 * a.M * (double)w.cout * w.cin * w.kh * w.kw;
+                by += ((double)n * xb.h * xb.w * w.cin + (double)a.M * w.cout) * (dtype == AIC_F16 ? 2 : 4) +
+                      (double)w.cout * w.cin * w.kh * w.kw * (dtype == AIC_F16 ? 2 : 4);
+                return a;
+            };
+            const ConvArgs a = conv_args(oi);
+            // a 64-channel BasicBlock (this conv and the next, which adds this one's input) runs as ONE kernel where it applies;
+            // FLOPs and algorithmic bytes are accounted as for the two convs
+            bool pair = false;
+            ConvArgs a2{};
+            if (dtype == AIC_F16 && oi + 1 < op1 && ops[oi + 1].v[0] == OP_CONV && ops[oi + 1].fuse == 0 && a.Cin == 64 && a.Cout == 64 &&
+                a.res_mode == 0 && ops[oi + 1].v[14] == 1) {
+                const double fl0 = fl, by0 = by;
+                a2 = conv_args(oi + 1);
+                pair = a2.res == a.x && a2.x == a.y;
+                if (!pair) fl = fl0, by = by0;
             }
+            if (prof_conv && !span_open) { dev->prof_begin(PROF_CONV, s, 0, 0); span_open = true; }
+            if (pair && conv_try_c64_block(a, a2, s)) {
+                if (prof_conv) dev->prof_account(PROF_CONV, fl, by);
+                ++oi;
+                continue;
+            }
+            if (pair) { fl = 0, by = 0; (void)conv_args(oi); }          // not fused after all: account this conv alone
+            if (prof_conv) dev->prof_account(PROF_CONV, fl, by);
             launch_conv_igemm(dtype, a, s);
         } else {
             EltArgs a{};

@@ -26,6 +26,9 @@ struct ConvArgs {
 };
 // dtype: AIC_F16 or AIC_F32 (type of x / w / res and, unless out_f32, y)
 void launch_conv_igemm(int dtype, const ConvArgs& a, hipStream_t s);
+// a whole 64-channel BasicBlock (c1: conv3x3+ReLU, c2: conv3x3 + block input, ReLU) in one fp16 kernel with the intermediate in
+// LDS (kernels_conv_block.hip); false = pattern / geometry not supported, nothing launched
+bool conv_try_c64_block(const ConvArgs& c1, const ConvArgs& c2, hipStream_t s);
 
 // letterbox + conv 3x3/2 (3->16) + SiLU fused (fp16 YOLOv8 stem); false = geometry not supported, nothing launched
 struct LetterboxGeom;
