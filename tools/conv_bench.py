@@ -24,6 +24,14 @@ def graph(H, W, cin, cout, k, reps, res, stride=1):
     a, b = g.buf(H, W, cin), g.buf(H // stride, W // stride, cout)
     g.conv("stem", inp, a, 3, cin, 1, 1, ef.ACT_RELU, wb=wg(cin, 3, 1, ef.ACT_RELU))
     src = a
+    if res == 2:        # BasicBlock pairs: conv1 src -> mid, conv2 mid -> dst adding src (the fused 64-channel block kernel's pattern)
+        mid = g.buf(H, W, cout)
+        for i in range(reps // 2):
+            dst = b if src == a else a
+            g.conv(f"b{i}c1", src, mid, cin, cout, k, 1, ef.ACT_RELU, wb=wg(cout, cin, k, ef.ACT_RELU))
+            g.conv(f"b{i}c2", mid, dst, cout, cout, k, 1, ef.ACT_RELU, wb=wg(cout, cout, k, ef.ACT_RELU, 0.5), res=(src, 0), res_mode=ef.RES_ADD_THEN_ACT)
+            src = dst
+        reps = 0
     for i in range(reps):
         dst = b if src == a else a
         if (cin != cout or stride != 1) and i:

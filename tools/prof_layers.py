@@ -15,7 +15,7 @@ sys.path.insert(0, ROOT)
 ef = importlib.import_module("ai-camera_amd.engine_file")
 
 
-def main(d, frames=16, crops=480, top=30, fused_stem=1, fused_yolo_stem=1):
+def main(d, frames=16, crops=480, top=30, fused_stem=1, fused_yolo_stem=1, fused_block=1):
     trace = glob.glob(os.path.join(d, "*kernel_trace.csv"))[0]
     rows = list(csv.DictReader(open(trace)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
@@ -34,7 +34,7 @@ def main(d, frames=16, crops=480, top=30, fused_stem=1, fused_yolo_stem=1):
     print(f"{'kernel':42s} {'calls':>7s} {'total ms':>9s} {'%':>6s} {'avg us':>8s}")
     for n, (c, us) in sorted(tot.items(), key=lambda kv: -kv[1][1])[:24]:
         print(f"{n[:42]:42s} {c:7d} {us / 1e3:9.2f} {100 * us / all_us:6.1f} {us / c:8.1f}")
-    conv = [r for r in rows if any(k in r["Kernel_Name"] for k in ("conv_igemm", "conv3x3_patch", "conv3x3_pp_patch", "conv3x3_c16", "conv3x3_c64_resident"))]
+    conv = [r for r in rows if any(k in r["Kernel_Name"] for k in ("conv_igemm", "conv3x3_patch", "conv3x3_pp_patch", "conv3x3_c16", "conv3x3_c64_resident", "conv3x3_c64_block"))]
     layers = []
     for name, g, n in (("yolo", ef.build_yolov8("n", calibrate=False), frames), ("reid", ef.build_reid(calibrate=False), crops)):
         for o in g.ops:
@@ -42,17 +42,38 @@ def main(d, frames=16, crops=480, top=30, fused_stem=1, fused_yolo_stem=1):
                     and not (name == "yolo" and g.names[o[15]] == "0.conv" and fused_yolo_stem):
                 h, w, _, _ = g.buffers[o[4]]
                 layers.append((name, g.names[o[15]], n * h * w, o[6], o[3] * o[7] * o[8]))
+    if fused_block:     # a 64-channel BasicBlock (layer1.N.conv1 + conv2) is ONE launch of conv3x3_c64_block_kernel: K doubled = both convs' FLOPs
+        merged = []
+        for L in layers:
+            if merged and L[0] == "reid" and L[1].startswith("layer1.") and L[1].endswith(".conv2") and merged[-1][1] == L[1][:-1] + "1":
+                p = merged.pop()
+                merged.append((p[0], L[1][:-6] + " (block)", p[2], p[3], p[4] + L[4]))
+            else:
+                merged.append(L)
+        layers = merged
     per = len(layers)
-    groups = len(conv) // per
-    conv = conv[len(conv) - groups * per:]
-    # launch groups may differ in size (the last batch of a call is tapered): keep the groups of the modal (full) size
-    gkey = [int(conv[g * per].get("Grid_Size_X", conv[g * per].get("Grid_Size", 0))) for g in range(groups)]
+    # a launch group starts at its (fused) YOLO stem; groups of other sizes (tapered tail of a call: fewer frames, and below
+    # the fused-block threshold two more launches) are dropped: keep the groups with `per` conv launches and the modal grid
+    is_conv = lambda r: any(k in r["Kernel_Name"] for k in ("conv_igemm", "conv3x3_patch", "conv3x3_pp_patch", "conv3x3_c16", "conv3x3_c64_resident", "conv3x3_c64_block"))
+    glist, cur = [], None
+    for r in rows:
+        if "yolo_stem_fused" in r["Kernel_Name"] or "letterbox" in r["Kernel_Name"]:
+            if cur:
+                glist.append(cur)
+            cur = []
+        elif cur is not None and is_conv(r):
+            cur.append(r)
+    if cur:
+        glist.append(cur)
+    glist = [g for g in glist if len(g) == per]
+    gkey = [int(g[0].get("Grid_Size_X", g[0].get("Grid_Size", 0))) for g in glist]
     modal = collections.Counter(gkey).most_common(1)[0][0]
     dur = [[] for _ in range(per)]
-    for i, r in enumerate(conv):
-        if gkey[i // per] != modal:
+    for g, k in zip(glist, gkey):
+        if k != modal:
             continue
-        dur[i % per].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+        for i, r in enumerate(g):
+            dur[i].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     groups = sum(1 for k in gkey if k == modal)
     out = []
     for (name, ln, m, co, k), ts in zip(layers, dur):
