@@ -66,20 +66,23 @@ __global__ __launch_bounds__(512) void conv3x3_c64_block_kernel(const BlockArgs 
     // ---- LDS-DMA of row group g (rows 4g .. 4g+3 of this block's stream) into ring slot g mod 5: 17 wave-instructions of
     // 64 x 16 bytes cover the 4 x 34 x 8 chunks exactly; every wave issues three (the surplus ones hit a dummy page) so
     // that the counted waits see the same number of operations on every wave
+    int doff[3];                                // element offset of this lane's chunk inside a row group, or -1 (pad column / surplus instruction)
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        const int sl = (p * 8 + wv) * 64 + lane;
+        const int rr = sl / 272, rem = sl - rr * 272;
+        const int px = rem >> 3, c = (rem & 7) ^ (px & 7);              // slot of a pixel holds channel chunk slot ^ (column & 7)
+        doff[p] = (p * 8 + wv < 17 && (unsigned)(px - 1) < 32u) ? (rr * 32 + (px - 1)) * a.x_cs + a.x_coff + c * 8 : -1;
+    }
     auto issue = [&](int g) {
         int gs = g % 5; if (gs < 0) gs += 5;
         const int jl = g >= 0 ? g / gpi : 0, gy = g - jl * gpi;
         const bool real = g >= 0 && jl < n_loc && gy < gpi - 1;
-        int ln = lane;
-        asm volatile("" : "+v"(ln));
+        const half_t* gbase = xg + ((size_t)(img0 + jl) * a.H + gy * 4) * 32 * a.x_cs;     // (block-uniform)
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
             const int j = p * 8 + wv;
-            const int sl = j * 64 + ln;
-            const int rr = sl / 272, rem = sl - rr * 272;
-            const int px = rem >> 3, c = (rem & 7) ^ (px & 7);          // slot of a pixel holds channel chunk slot ^ (column & 7)
-            const bool ok = real && j < 17 && (unsigned)(px - 1) < 32u;
-            const half_t* src = ok ? xg + (((size_t)(img0 + jl) * a.H + gy * 4 + rr) * 32 + (px - 1)) * a.x_cs + a.x_coff + c * 8 : zero;
+            const half_t* src = (real && doff[p] >= 0) ? gbase + doff[p] : zero;
             asm volatile("" : "+v"(src));
             char* dst = j < 17 ? smem + gs * 4 * ROWB + j * 1024 : smem + DUMMY_OFF;
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
