@@ -2,6 +2,8 @@
 fp32 mode (v_mfma_f32_16x16x4_f32) is the parity gate (north_star: boxes / embeddings within
 1e-3), fp16 mode reports its deviation against documented bounds; decode and NMS integer outcomes
 are compared exactly on identical head tensors."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -14,6 +16,7 @@ pytestmark = pytest.mark.gpu
 ef = pkg("engine_file")
 syn = pkg("synthetic")
 HipEngine = pkg("hip_engine").HipEngine
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
@@ -210,6 +213,30 @@ def test_reid_large_batch_kernels(gpu, engines, dtype, tol_split, tol, n_crops):
     assert d < tol_split and err < tol
     assert np.allclose(np.linalg.norm(e_big, axis=1), 1, atol=1e-3)
     big.close(), small.close()
+
+
+def test_reid_large_batch_unfused_layer1(gpu, engines):
+    """With the fused BasicBlock kernel switched off (AICAM_C64_BLOCK=0, read once per process: hence a child process) layer1
+    runs on the persistent weights-resident kernel, with and without residual; same check as above on 950 crops."""
+    import subprocess
+    import sys
+    code = r"""
+import importlib, sys, numpy as np
+sys.path.insert(0, %r)
+he = importlib.import_module("ai-camera_amd.hip_engine")
+rng = np.random.default_rng(7)
+x = rng.standard_normal((950, 3, 128, 64)).astype(np.float32)
+big = he.HipEngine(%r, dtype="fp16", max_items=950, warm_up=False)
+small = he.HipEngine(%r, dtype="fp16", max_items=16, warm_up=False)
+e_big = big.reid_infer_np(x)
+d = max(np.abs(e_big[i:i + 16] - small.reid_infer_np(x[i:i + 16])).max() for i in (0, 472, 934))
+print("DIFF", d)
+sys.exit(0 if d < 3e-3 and np.allclose(np.linalg.norm(e_big, axis=1), 1, atol=1e-3) else 1)
+""" % (ROOT, engines[1], engines[1])
+    env = dict(os.environ, AICAM_C64_BLOCK="0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    print(r.stdout[-300:], r.stderr[-300:])
+    assert r.returncode == 0
 
 
 @pytest.mark.parametrize("dtype,tol", [("fp32", 5e-4), ("fp16", 6e-2)])
