@@ -229,15 +229,20 @@ bool launch_yolo_stem_fused(const uint8_t* frames, int n, const LetterboxGeom& g
     return true;
 }
 
-// One block = 16 output rows of one crop. The tap tables (fp64 coordinate math of the cv2 spec) are
+#ifndef CROP_ROWS
+#define CROP_ROWS 16
+#endif
+// One block = CROP_ROWS output rows of one crop (32 / 64 / 128 rows per block: same 1.75 ms per 15 360 crops; staging the source
+// rows in LDS: slower, 2.16 ms -- the kernel is bound by its 12 byte-granular taps per pixel either way). The tap tables (fp64 coordinate math of the cv2 spec) are
 // computed once per block into LDS -- 64 + 16 entries instead of once per output pixel.
 template <typename T>
 __global__ __launch_bounds__(256) void crop_resize_kernel(const uint8_t* __restrict__ frames, int fh, int fw, const float* __restrict__ boxes,
                                                           const int* __restrict__ frame_of, int n, const int* __restrict__ n_dev, int oh, int ow,
                                                           int mode, void* out, int* __restrict__ valid) {
-    constexpr int ROWS = 16, MAXW = 256;
+    constexpr int ROWS = CROP_ROWS, MAXW = 256;
     __shared__ Taps xt[MAXW];
     __shared__ Taps yt[ROWS];
+    __shared__ float lut[3][256];               // (v/255 - mean)/std for the 256 pixel values: the same fp32 divisions, once per block
     const int crop = blockIdx.y;
     const int row0 = blockIdx.x * ROWS;
     const int live = n_dev ? min(*n_dev, n) : n;
@@ -257,15 +262,19 @@ __global__ __launch_bounds__(256) void crop_resize_kernel(const uint8_t* __restr
     const bool area2 = ok && is_area2(sw, sh, ow, oh);
     if (ok && !area2) {
         if (t < ow) xt[t] = taps_x(t, 1.0 / ((double)ow / (double)sw), sw);
-        else if (t >= MAXW - ROWS && row0 + (t - (MAXW - ROWS)) < oh)
-            yt[t - (MAXW - ROWS)] = taps_y(row0 + t - (MAXW - ROWS), 1.0 / ((double)oh / (double)sh), sh);
+        const int ty_i = (t + ROWS) % 256;          // the y taps on the threads that have no x tap to compute, where there are such
+        if (ty_i < ROWS && row0 + ty_i < oh) yt[ty_i] = taps_y(row0 + ty_i, 1.0 / ((double)oh / (double)sh), sh);
+    }
+    {
+        const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) lut[c][t] = ((float)t / 255.0f - mean[c]) / stdv[c];      // image_processing.py:126-131 (fp32)
     }
     __syncthreads();
     const int per = oh * ow;
     const int fi = (ok && frame_of) ? frame_of[crop] : 0;
     const uint8_t* f = frames + (size_t)fi * fh * fw * 3;
     const int pitch = fw * 3;
-    const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
     for (int idx = t; idx < ROWS * ow; idx += 256) {
         const int ry = idx / ow, ox = idx - ry * ow, oy = row0 + ry;
         if (oy >= oh) break;
@@ -290,7 +299,7 @@ __global__ __launch_bounds__(256) void crop_resize_kernel(const uint8_t* __restr
             }
             // image_processing.py:126-131: BGR->RGB, (x/255 - mean)/std in fp32
 #pragma unroll
-            for (int c = 0; c < 3; ++c) v[c] = ((float)px[2 - c] / 255.0f - mean[c]) / stdv[c];
+            for (int c = 0; c < 3; ++c) v[c] = lut[c][px[2 - c]];
         }
         const int p = oy * ow + ox;
         if (mode == 0) {
@@ -319,7 +328,7 @@ void launch_crop_resize(const uint8_t* frames, int h, int w, const float* boxes,
                         const int* n_dev, int out_h, int out_w, int mode, int dtype, void* out, int* valid, hipStream_t s) {
     if (n <= 0) return;
     AIC_REQUIRE(out_w <= 240, AIC_ERR_CAPACITY, "crop width above 240 is not supported");
-    dim3 grid(ceil_div(out_h, 16), n);
+    dim3 grid(ceil_div(out_h, CROP_ROWS), n);
     if (dtype == AIC_F16)
         hipLaunchKernelGGL(crop_resize_kernel<half_t>, grid, dim3(256), 0, s, frames, h, w, boxes, frame_of, n, n_dev, out_h, out_w, mode, out, valid);
     else
