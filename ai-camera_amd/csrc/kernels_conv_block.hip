@@ -229,8 +229,11 @@ bool conv_try_c64_block(const ConvArgs& c1, const ConvArgs& c2, hipStream_t s) {
     a.x = c1.x, a.y = c2.y, a.w1 = c1.w, a.b1 = c1.bias, a.w2 = c2.w, a.b2 = c2.bias, a.zero = c1.zero;
     a.x_cs = c1.x_cs, a.x_coff = c1.x_coff, a.y_cs = c2.y_cs, a.y_coff = c2.y_coff, a.H = c1.H;
     a.n_img = c1.M / (c1.H * c1.W);
+    // images per block: n_img / 256 = one persistent block per CU, or AICAM_BLK_IPB for shorter-lived blocks (each pays 3 steps
+    // of pipeline fill and a weight reload; in exchange the CU takes other streams' waiting blocks in between)
+    static const int ipb_env = [] { const char* e = getenv("AICAM_BLK_IPB"); return e ? atoi(e) : 0; }();
     const int grid = std::min(256, a.n_img);
-    a.ipb = (a.n_img + grid - 1) / grid;
+    a.ipb = ipb_env > 0 ? ipb_env : (a.n_img + grid - 1) / grid;
     constexpr size_t lds = (size_t)(20 + 16) * 34 * 128 + 1024 + 512;
     static bool attr = false;
     if (!attr) {
