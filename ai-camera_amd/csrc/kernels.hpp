@@ -67,9 +67,10 @@ void launch_letterbox(const uint8_t* frames, int n, const LetterboxGeom& g, int 
                       hipStream_t s);
 // boxes [n,4] xyxy (device), frame_of[n] (device, may be NULL = frame 0), frames u8 [*,h,w,3].
 // n_dev (device int, may be NULL) caps the number of live crops. valid[n] written.
+// slack: the caller owns >= 16 readable bytes behind the last frame (12-byte tap loads instead of byte loads; same bytes used)
 void launch_crop_resize(const uint8_t* frames, int h, int w, const float* boxes, const int* frame_of, int n,
                         const int* n_dev, int out_h, int out_w, int mode, int dtype, void* out, int* valid,
-                        hipStream_t s);
+                        hipStream_t s, bool slack = false);
 
 // ------------------------------------------------------------------ detection head (kernels_det.hip)
 struct HeadLevel { const float* box; const float* cls; int h, w, stride, a0; };

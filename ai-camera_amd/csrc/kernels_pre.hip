@@ -238,7 +238,7 @@ bool launch_yolo_stem_fused(const uint8_t* frames, int n, const LetterboxGeom& g
 template <typename T>
 __global__ __launch_bounds__(256) void crop_resize_kernel(const uint8_t* __restrict__ frames, int fh, int fw, const float* __restrict__ boxes,
                                                           const int* __restrict__ frame_of, int n, const int* __restrict__ n_dev, int oh, int ow,
-                                                          int mode, void* out, int* __restrict__ valid) {
+                                                          int mode, void* out, int* __restrict__ valid, int wide) {
     constexpr int ROWS = CROP_ROWS, MAXW = 256;
     __shared__ Taps xt[MAXW];
     __shared__ Taps yt[ROWS];
@@ -286,6 +286,27 @@ __global__ __launch_bounds__(256) void crop_resize_kernel(const uint8_t* __restr
                 const uint8_t* p1 = p0 + pitch;
 #pragma unroll
                 for (int c = 0; c < 3; ++c) px[c] = ((int)p0[c] + (int)p0[3 + c] + (int)p1[c] + (int)p1[3 + c] + 2) >> 2;
+            } else if (wide) {
+                // both taps of a row are 6 consecutive bytes (3 when the right tap is clamped onto the left one): one aligned
+                // 12-byte load per row and v_alignbyte instead of six byte loads -- the kernel is bound by its tap loads
+                const Taps tx = xt[ox], ty = yt[ry];
+                const bool two = tx.i1 != tx.i0;
+                int b0[2][3], b1[2][3];                                 // [row][channel] of the left / right tap
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr) {
+                    const uintptr_t A = reinterpret_cast<uintptr_t>(f + (size_t)(y1 + (rr ? ty.i1 : ty.i0)) * pitch + (size_t)(x1 + tx.i0) * 3);
+                    const uint3 w = *reinterpret_cast<const uint3*>(A & ~(uintptr_t)3);
+                    const unsigned sh = (unsigned)(A & 3);
+                    const unsigned q0 = __builtin_amdgcn_alignbyte(w.y, w.x, sh), q1 = __builtin_amdgcn_alignbyte(w.z, w.y, sh);
+                    b0[rr][0] = q0 & 255u, b0[rr][1] = (q0 >> 8) & 255u, b0[rr][2] = (q0 >> 16) & 255u;
+                    b1[rr][0] = two ? (q0 >> 24) : b0[rr][0], b1[rr][1] = two ? (q1 & 255u) : b0[rr][1], b1[rr][2] = two ? ((q1 >> 8) & 255u) : b0[rr][2];
+                }
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const int h0 = b0[0][c] * tx.w0 + b1[0][c] * tx.w1;
+                    const int h1 = b0[1][c] * tx.w0 + b1[1][c] * tx.w1;
+                    px[c] = (((ty.w0 * (h0 >> 4)) >> 16) + ((ty.w1 * (h1 >> 4)) >> 16) + 2) >> 2;
+                }
             } else {
                 const Taps tx = xt[ox], ty = yt[ry];
                 const uint8_t* r0 = f + (size_t)(y1 + ty.i0) * pitch + (size_t)x1 * 3;
@@ -325,14 +346,16 @@ void launch_letterbox(const uint8_t* frames, int n, const LetterboxGeom& g, int 
 }
 
 void launch_crop_resize(const uint8_t* frames, int h, int w, const float* boxes, const int* frame_of, int n,
-                        const int* n_dev, int out_h, int out_w, int mode, int dtype, void* out, int* valid, hipStream_t s) {
+                        const int* n_dev, int out_h, int out_w, int mode, int dtype, void* out, int* valid, hipStream_t s, bool slack) {
     if (n <= 0) return;
+    static const bool no_wide = getenv("AICAM_CROP_BYTES") != nullptr;
+    const int wide = slack && !no_wide;
     AIC_REQUIRE(out_w <= 240, AIC_ERR_CAPACITY, "crop width above 240 is not supported");
     dim3 grid(ceil_div(out_h, CROP_ROWS), n);
     if (dtype == AIC_F16)
-        hipLaunchKernelGGL(crop_resize_kernel<half_t>, grid, dim3(256), 0, s, frames, h, w, boxes, frame_of, n, n_dev, out_h, out_w, mode, out, valid);
+        hipLaunchKernelGGL(crop_resize_kernel<half_t>, grid, dim3(256), 0, s, frames, h, w, boxes, frame_of, n, n_dev, out_h, out_w, mode, out, valid, wide);
     else
-        hipLaunchKernelGGL(crop_resize_kernel<float>, grid, dim3(256), 0, s, frames, h, w, boxes, frame_of, n, n_dev, out_h, out_w, mode, out, valid);
+        hipLaunchKernelGGL(crop_resize_kernel<float>, grid, dim3(256), 0, s, frames, h, w, boxes, frame_of, n, n_dev, out_h, out_w, mode, out, valid, wide);
     KCHECK();
 }
 

@@ -85,7 +85,7 @@ struct Pipeline {
         dev->use();
         geom = letterbox_geometry(p.frame_h, p.frame_w, y->in_h, y->in_w);
         frame_bytes = (size_t)p.frame_h * p.frame_w * 3;
-        ring.alloc(frame_bytes * p.ring_frames);
+        ring.alloc(frame_bytes * p.ring_frames + 64);     // + slack: the crop kernel's 12-byte tap loads may run past the last frame's last byte
         dim = r->out_dim;
         inj_count.assign(p.ring_frames, 0);
         inj_boxes.assign((size_t)p.ring_frames * p.max_persons * 4, 0.f);
@@ -196,7 +196,7 @@ struct Pipeline {
                 Prof pr(*dev, PROF_CROP, sr, 0, (double)nc * reid->in_h * reid->in_w * 19);
                 reid->in_pix4 = reid->input_pix4_ok();
                 launch_crop_resize(f0, prm.frame_h, prm.frame_w, c.d_boxes.p, c.d_frame_of.p, nc, nullptr, reid->in_h,
-                                   reid->in_w, reid->in_pix4 ? 2 : 1, reid->dtype, reid->input(), c.d_valid.p, sr);
+                                   reid->in_w, reid->in_pix4 ? 2 : 1, reid->dtype, reid->input(), c.d_valid.p, sr, true);
             }
             reid->run(nc, sr);
             HIP_CHECK(hipMemcpyAsync(c.d_emb.p, reid->embeddings(), (size_t)nc * dim * 4, hipMemcpyDeviceToDevice, sr));

@@ -49,6 +49,12 @@ def test_pipeline_inject_matches_oracle(gpu, engines, dtype):
     emb_err = np.abs(pipe.last_embeddings() - embs[-1]).max()
     print(f"[{dtype}] pipeline embedding err vs oracle {emb_err:.2e}")
     assert emb_err < (1e-3 if dtype == "fp32" else 3e-2)
+    # the pipeline's crop kernel takes its taps with 12-byte loads, the single-frame entry point with byte loads: same bytes,
+    # so the embeddings of the last frame's detections must be IDENTICAL
+    boxes, conf, cls = sc.detections(n_frames - 1)[:3]
+    keep = O.filter_detections(boxes, conf, cls, config.CLASSES, config.CLASSES_TO_TRACK, 0.3)
+    emb1, _ = pipe.reid.embed_boxes_np(frames[n_frames - 1], boxes[keep])
+    assert emb1.shape == pipe.last_embeddings().shape and np.array_equal(emb1, pipe.last_embeddings())
     for f in range(n_frames):
         got, exp = tracks[f], ref[f]
         assert [t[4] for t in got] == [t[4] for t in exp], (f, got, exp)            # identical track ids
