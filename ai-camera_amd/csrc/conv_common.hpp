@@ -274,6 +274,25 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 template <typename F, int... I> __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
 template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
+// Workgroups go to the 8 XCDs round-robin (block b -> XCD b % 8), each with its own L2.  Tiles that are neighbours in the
+// image share halo rows and weights: this bijection gives XCD x one contiguous run of tiles, so a halo fetched by one block is an
+// L2 hit for the next instead of a second HBM / Infinity-Cache read through another XCD.  (g_xcd_map: AICAM_NO_XCD_MAP=1 -> identity)
+__device__ __forceinline__ int xcd_tile(int b, int nb, int on) {
+    if (!on) return b;
+    const int x = b & 7, base = nb >> 3, rem = nb & 7;
+    return x * base + (x < rem ? x : rem) + (b >> 3);
+}
+// linear block id -> (tile x, tile y) of a gridDim.x x gridDim.y tile grid
+__device__ __forceinline__ void xcd_tile_xy(int on, int& bx, int& by) {
+    const int nbx = (int)gridDim.x, lin = (int)blockIdx.y * nbx + (int)blockIdx.x;
+    const int t = xcd_tile(lin, nbx * (int)gridDim.y, on);
+    by = t / nbx, bx = t - by * nbx;
+}
+inline int xcd_map_on() {
+    static const int v = getenv("AICAM_NO_XCD_MAP") == nullptr;
+    return v;
+}
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
     if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");

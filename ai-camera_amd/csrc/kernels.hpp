@@ -23,6 +23,7 @@ struct ConvArgs {
     int cout_pad;       // rows in w / bias (multiple of 128)
     unsigned tap_rows;  // bit kh*KW set for kh < KH (replication pattern of the tap-validity mask)
     const void* zero;   // 64 bytes of zeros in HBM: LDS-DMA source for padded / out-of-range chunks
+    int xcd_map;        // 1: blocks take tiles through xcd_tile() (set by launch_conv_igemm)
 };
 // dtype: AIC_F16 or AIC_F32 (type of x / w / res and, unless out_f32, y)
 void launch_conv_igemm(int dtype, const ConvArgs& a, hipStream_t s);

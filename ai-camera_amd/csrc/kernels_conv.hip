@@ -237,8 +237,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const Conv
     const int lane = t & 63, wv = t >> 6;
     const int slot = t & 3, r0 = t >> 2;
     const int kc = slot ^ lds_swz(r0);         // K-chunk this thread fetches (source-side swizzle)
-    const int m0 = blockIdx.x * BM;
-    const int n0 = blockIdx.y * BN;
+    int tbx, tby;
+    xcd_tile_xy(a.xcd_map, tbx, tby);
+    const int m0 = tbx * BM;
+    const int n0 = tby * BN;
 
     const T* __restrict__ xg = reinterpret_cast<const T*>(a.x);
     const T* __restrict__ wg = reinterpret_cast<const T*>(a.w);
@@ -484,8 +486,10 @@ static void launch_conv_t(const ConvArgs& a, hipStream_t s) {
     }
 }
 
-void launch_conv_igemm(int dtype, const ConvArgs& a, hipStream_t s) {
-    if (a.M <= 0) return;
+void launch_conv_igemm(int dtype, const ConvArgs& a0, hipStream_t s) {
+    if (a0.M <= 0) return;
+    ConvArgs a = a0;
+    a.xcd_map = xcd_map_on();
     if (dtype == AIC_F16 && conv_try_c16(a, s)) return;
     if (dtype == AIC_F16 && conv_try_c64_resident(a, s)) return;
     if (dtype == AIC_F16) launch_conv_t<half_t>(a, s);

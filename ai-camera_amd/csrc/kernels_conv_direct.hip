@@ -22,7 +22,7 @@ __global__ __launch_bounds__(256) void conv3x3_c16_kernel(const ConvArgs a, int 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6, r = lane & 15, q = lane >> 4;
-    int bx = blockIdx.x;
+    int bx = xcd_tile((int)blockIdx.x, (int)gridDim.x, a.xcd_map);
     const int tx = bx % tiles_x; bx /= tiles_x;
     const int ty = bx % tiles_y;
     const int img = bx / tiles_y;
@@ -425,12 +425,13 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(const ConvA
     char* ring = smem + PATCH_BYTES;
 
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    int bx = blockIdx.x;
+    int bx, tby;
+    xcd_tile_xy(a.xcd_map, bx, tby);
     const int tx = bx % tiles_x; bx /= tiles_x;
     const int ty = bx % tiles_y;
     const int img = bx / tiles_y;
     const int oy0 = ty * TH, ox0 = tx * TW;
-    const int n0 = blockIdx.y * BN;
+    const int n0 = tby * BN;
 
     const T* __restrict__ wg = reinterpret_cast<const T*>(a.w);
     const T* zero = reinterpret_cast<const T*>(a.zero);

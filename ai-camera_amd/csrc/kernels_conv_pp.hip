@@ -45,8 +45,10 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(const ConvArgs a) {
     const int lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
     const int slot = t & 3, r0 = t >> 2;
     const int kc = slot ^ lds_swz(r0);
-    const int m0 = blockIdx.x * BM;
-    const int n0 = blockIdx.y * BN;
+    int tbx, tby;
+    xcd_tile_xy(a.xcd_map, tbx, tby);
+    const int m0 = tbx * BM;
+    const int n0 = tby * BN;
     const bool late = wv >= 4;
 
     const T* __restrict__ xg = reinterpret_cast<const T*>(a.x);
@@ -273,12 +275,13 @@ __global__ __launch_bounds__(512) void conv3x3_pp_patch_kernel(const ConvArgs a,
     const int t = threadIdx.x;
     const int lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
     const bool late = wv >= 4;
-    int bx = blockIdx.x;
+    int bx, tby;
+    xcd_tile_xy(a.xcd_map, bx, tby);
     const int tx = bx % tiles_x; bx /= tiles_x;
     const int ty = bx % tiles_y;
     const int img0 = (bx / tiles_y) * NI;
     const int oy0 = ty * TH, ox0 = tx * TW;
-    const int n0 = blockIdx.y * BN;
+    const int n0 = tby * BN;
     const int n_img = a.M / (a.Ho * a.Wo);
 
     const T* __restrict__ xg = reinterpret_cast<const T*>(a.x);
