@@ -253,6 +253,17 @@ static void launch_pp(const ConvArgs& a, hipStream_t s) {
 //    patch pass is due), so the counted vmcnt of v4 is unchanged.
 // Hazards (segments as in v4): patch passes of chunk c+1 are issued in L_{9c+1} .. L_{9c+NPASS} (NPASS <= 7): the
 // buffer was last read in L_{9c-1} (WAR: 4 segments), and the last pass is waited for in L_{9c+8}, read in L_{9c+9}.
+// Maps narrower than 16 pixels: a 16-pixel MFMA tile used to be 16 / TW consecutive ROWS of one image, whose 16-byte chunks
+// sit PW * 16 bytes apart in a plane -- bank conflicts on 40 % of the LDS cycles of ReID layers 3/4 (SQ_LDS_BANK_CONFLICT).
+// Now it is ONE row of G = 16 / TW consecutive IMAGES of the tile, and the image pitch is padded so that the G row pieces fall
+// into disjoint bank ranges (pitch * 16 B = TW * 16 B mod 256).
+constexpr int ppp_ipix_pad(int th, int tw) {
+    int ipix = (th + 2) * (tw + 2);
+    if (tw >= 16) return ipix;
+    while (ipix % 16 != tw && ipix % 16 != 16 - tw) ++ipix;
+    return ipix;
+}
+
 template <typename T, int MT, int NT, int WM, int WN, int TH, int TW, int NSTAGE>
 __global__ __launch_bounds__(512) void conv3x3_pp_patch_kernel(const ConvArgs a, int tiles_x, int tiles_y) {
     constexpr int CH = 16 / (int)sizeof(T);
@@ -264,7 +275,8 @@ __global__ __launch_bounds__(512) void conv3x3_pp_patch_kernel(const ConvArgs a,
     constexpr int B_PER = BNP / RP;
     constexpr int LPS = B_PER + 1;
     constexpr int TPIX = TH * TW, NI = BM / TPIX;
-    constexpr int PW = TW + 2, PH = TH + 2, IPIX = PW * PH, NPIX = NI * IPIX;
+    constexpr int PW = TW + 2, PH = TH + 2, IPIX = PW * PH, IPIXP = ppp_ipix_pad(TH, TW), NPIX = NI * IPIXP;
+    constexpr int G = TW >= 16 ? 1 : 16 / TW;                          // images per 16-pixel MFMA tile
     constexpr int NPASS = (NPIX + 127) / 128, NPIXP = NPASS * 128;
     constexpr int PLANE = NPIXP * 16, PBUF = 4 * PLANE, DUMMY = 8192, WSTAGE = BNP * 64;
     constexpr int RING = 2 * PBUF + DUMMY;
@@ -294,10 +306,10 @@ __global__ __launch_bounds__(512) void conv3x3_pp_patch_kernel(const ConvArgs a,
 #pragma unroll
     for (int i = 0; i < NPASS; ++i) {
         const int p = i * 128 + (wv >> 2) * 64 + lane;
-        const int il = p / IPIX, rem = p - il * IPIX;
+        const int il = p / IPIXP, rem = p - il * IPIXP;
         const int py = rem / PW, px = rem - py * PW;
         const int img = img0 + il, iy = oy0 + py - 1, ix = ox0 + px - 1;
-        const bool ok = p < NPIX && img < n_img && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        const bool ok = p < NPIX && rem < IPIX && img < n_img && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
         poff[i] = ok ? (((img * a.H + iy) * a.W + ix) * a.x_cs + a.x_coff + plane * CH) : -1;
     }
     char* const pdst = smem + plane * PLANE + (wv >> 2) * 1024;     // + buffer*PBUF + pass*2048 (+ lane*16 by the DMA)
@@ -341,13 +353,20 @@ __global__ __launch_bounds__(512) void conv3x3_pp_patch_kernel(const ConvArgs a,
     // because a wave's MT*16 pixels either tile whole images or lie inside one (static_assert below)
     static_assert((MT * 16) % TPIX == 0 || TPIX % (MT * 16) == 0, "a wave's pixels must not straddle images irregularly");
     static_assert(TW % 16 == 0 || 16 % TW == 0, "a 16-pixel MFMA tile is whole rows or a piece of one row");
-    auto patch_pix = [](int m) constexpr { return (m / TPIX) * IPIX + ((m % TPIX) / TW) * PW + (m % TPIX) % TW; };
+    static_assert(G == 1 || (NI % G == 0 && (MT % TH == 0 || TH % MT == 0)), "image groups");
+    // pixel (patch units) of 16-pixel tile number t of the block, and of a wave's tile i relative to its tile 0
+    auto tile_pix = [](int t) constexpr { return G == 1 ? (t * 16 / TPIX) * IPIXP + ((t * 16 % TPIX) / TW) * PW + (t * 16 % TPIX) % TW
+                                                        : (t / TH) * G * IPIXP + (t % TH) * PW; };
+    auto patch_pix = [tile_pix](int m) constexpr { return G == 1 ? tile_pix(m / 16) : (TH % MT == 0 ? (m / 16) * PW : tile_pix(m / 16)); };
     int xa0;
-    {
+    if constexpr (G == 1) {
         const int ml = wm * MT * 16 + r;
         const int il = ml / TPIX, rem = ml - il * TPIX;
         const int ly = rem / TW, lx = rem - ly * TW;
-        xa0 = q * PLANE + (il * IPIX + ly * PW + lx) * 16;
+        xa0 = q * PLANE + (il * IPIXP + ly * PW + lx) * 16;
+    } else {
+        const int t0 = wm * MT;
+        xa0 = q * PLANE + ((t0 / TH) * G * IPIXP + (t0 % TH) * PW + (r / TW) * IPIXP + r % TW) * 16;
     }
     // weight fragment addresses: tiles j and j+2 are 32 rows (2048 B) apart, j and j+1 differ in the swizzle term
     int woff2[2];
@@ -418,9 +437,16 @@ __global__ __launch_bounds__(512) void conv3x3_pp_patch_kernel(const ConvArgs a,
     int mrow[MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-        const int ml = (wm * MT + i) * 16 + r;
-        const int il = ml / TPIX, rem = ml - il * TPIX;
-        const int ly = rem / TW, lx = rem - ly * TW;
+        int il, ly, lx;
+        if constexpr (G == 1) {
+            const int ml = (wm * MT + i) * 16 + r;
+            il = ml / TPIX;
+            const int rem = ml - il * TPIX;
+            ly = rem / TW, lx = rem - ly * TW;
+        } else {
+            const int tl = wm * MT + i;
+            il = (tl / TH) * G + r / TW, ly = tl % TH, lx = r % TW;
+        }
         const int img = img0 + il;
         mrow[i] = img < n_img ? (img * a.Ho + oy0 + ly) * a.Wo + ox0 + lx : -1;
     }
@@ -430,7 +456,7 @@ __global__ __launch_bounds__(512) void conv3x3_pp_patch_kernel(const ConvArgs a,
 template <typename T, int MT, int NT, int WM, int WN, int TH, int TW, int NSTAGE>
 static bool launch_pp_patch(const ConvArgs& a, hipStream_t s) {
     constexpr int BM = WM * MT * 16, BN = WN * NT * 16, BNP = (BN + 127) / 128 * 128;
-    constexpr int NI = BM / (TH * TW), NPIX = NI * (TH + 2) * (TW + 2), NPASS = (NPIX + 127) / 128;
+    constexpr int NI = BM / (TH * TW), NPIX = NI * ppp_ipix_pad(TH, TW), NPASS = (NPIX + 127) / 128;
     constexpr size_t lds = (size_t)2 * 4 * NPASS * 128 * 16 + 8192 + (size_t)NSTAGE * BNP * 64;
     static_assert(lds <= 160 * 1024, "does not fit the LDS");
     if (a.H % TH || a.W % TW || a.Ho != a.H || a.Wo != a.W) return false;

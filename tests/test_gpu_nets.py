@@ -215,9 +215,11 @@ def test_reid_large_batch_kernels(gpu, engines, dtype, tol_split, tol, n_crops):
     big.close(), small.close()
 
 
-def test_reid_large_batch_unfused_layer1(gpu, engines):
-    """With the fused BasicBlock kernel switched off (AICAM_C64_BLOCK=0, read once per process: hence a child process) layer1
-    runs on the persistent weights-resident kernel, with and without residual; same check as above on 950 crops."""
+@pytest.mark.parametrize("env", [{"AICAM_C64_BLOCK": "0"}, {"AICAM_PP_MIN": "0"}], ids=["unfused_layer1", "pp_everywhere"])
+def test_reid_large_batch_kernel_switches(gpu, engines, env):
+    """Kernel choices that are read once per process, hence a child process: with the fused BasicBlock kernel off layer1 runs on
+    the persistent weights-resident kernel (with and without residual); with AICAM_PP_MIN=0 the ping-pong kernels take every
+    layer they apply to, including layer4's 8 x 4 maps (four images per 16-pixel MFMA tile).  Same check as above, 950 crops."""
     import subprocess
     import sys
     code = r"""
@@ -233,8 +235,7 @@ d = max(np.abs(e_big[i:i + 16] - small.reid_infer_np(x[i:i + 16])).max() for i i
 print("DIFF", d)
 sys.exit(0 if d < 3e-3 and np.allclose(np.linalg.norm(e_big, axis=1), 1, atol=1e-3) else 1)
 """ % (ROOT, engines[1], engines[1])
-    env = dict(os.environ, AICAM_C64_BLOCK="0")
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
     print(r.stdout[-300:], r.stderr[-300:])
     assert r.returncode == 0
 
