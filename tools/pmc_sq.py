@@ -1,5 +1,8 @@
-"""Per-kernel SQ counter summary from rocprofv3 --pmc passes (gpurun_out/pmc_sq*/).
-Groups dispatches by (kernel name, grid, workgroup) so that each conv layer shape is one row."""
+"""Per-kernel SQ counter summary from two rocprofv3 --pmc passes (pass A: SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU
+SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY; pass B: SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM SQ_WAIT_INST_LDS
+SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE).  Groups dispatches by (kernel name, grid, workgroup): each conv layer shape is one row.
+mfma_busy% = SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES / 32 (the busy counter is per shader engine, 32 of them; the MFMA counter per
+SIMD, 1024), lds_act% = SQ_LDS_IDX_ACTIVE / SQ_BUSY_CYCLES / 8 (per CU, 256); bankconf% = conflict cycles / LDS active cycles."""
 import csv, glob, sys, collections
 
 def load(d):
@@ -25,4 +28,4 @@ for k in keys[:int(sys.argv[3]) if len(sys.argv) > 3 else 30]:
     mf = max(x.get("SQ_INSTS_MFMA", 0), 1)
     wc = max(x.get("SQ_WAVE_CYCLES", 0), 1)
     busy = max(x.get("SQ_BUSY_CYCLES", 0), 1)
-    print(f"{k[0][:48]:48s} {k[1]:8d} {k[2]:4d} {int(x['_n']):4d} | {100*x.get('SQ_VALU_MFMA_BUSY_CYCLES',0)/busy:9.1f} {x.get('SQ_INSTS_VALU',0)/mf:9.2f} {y.get('SQ_INSTS_LDS',0)/mf:8.2f} {y.get('SQ_INSTS_SALU',0)/mf:9.2f} {y.get('SQ_INSTS_VMEM',0)/mf:9.2f} {100*x.get('SQ_WAIT_ANY',0)/wc:9.1f} {100*x.get('SQ_WAIT_INST_ANY',0)/wc:10.1f} {100*y.get('SQ_WAIT_INST_LDS',0)/wc:9.1f} {100*y.get('SQ_LDS_BANK_CONFLICT',0)/max(y.get('SQ_LDS_IDX_ACTIVE',1),1):9.1f} {100*y.get('SQ_LDS_IDX_ACTIVE',0)/busy:8.1f}")
+    print(f"{k[0][:48]:48s} {k[1]:8d} {k[2]:4d} {int(x['_n']):4d} | {100*x.get('SQ_VALU_MFMA_BUSY_CYCLES',0)/busy/32:9.1f} {x.get('SQ_INSTS_VALU',0)/mf:9.2f} {y.get('SQ_INSTS_LDS',0)/mf:8.2f} {y.get('SQ_INSTS_SALU',0)/mf:9.2f} {y.get('SQ_INSTS_VMEM',0)/mf:9.2f} {100*x.get('SQ_WAIT_ANY',0)/wc:9.1f} {100*x.get('SQ_WAIT_INST_ANY',0)/wc:10.1f} {100*y.get('SQ_WAIT_INST_LDS',0)/wc:9.1f} {100*y.get('SQ_LDS_BANK_CONFLICT',0)/max(y.get('SQ_LDS_IDX_ACTIVE',1),1):9.1f} {100*y.get('SQ_LDS_IDX_ACTIVE',0)/busy/8:8.1f}")

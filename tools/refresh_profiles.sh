@@ -11,7 +11,10 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --cpu-frames 0 --no-pcie > $O/bench_under_rocprof.json 2> $O/trace.log
 AICAM_NO_TAPER=1 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -- python3 $R/bench.py --steps 1 --warmup 1 --cpu-frames 0 --no-pcie > /dev/null 2> $O/fetch.log
 AICAM_NO_TAPER=1 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -- python3 $R/bench.py --steps 1 --warmup 1 --cpu-frames 0 --no-pcie > /dev/null 2> $O/write.log
+AICAM_NO_TAPER=1 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $O/sqa -- python3 $R/bench.py --steps 1 --warmup 1 --cpu-frames 0 --no-pcie > /dev/null 2> $O/sqa.log
+AICAM_NO_TAPER=1 rocprofv3 --pmc SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $O/sqb -- python3 $R/bench.py --steps 1 --warmup 1 --cpu-frames 0 --no-pcie > /dev/null 2> $O/sqb.log
 cd $R
+python tools/pmc_sq.py $O/sqa $O/sqb 40 > $O/sq_counters.txt
 T=$(ls -d $O/trace/*/ | head -1)
 python tools/prof_layers.py $T 512 15360 100 > $O/conv_layers.txt
 head -24 $O/conv_layers.txt > $O/kernel_summary.txt
@@ -21,5 +24,5 @@ cp profiles/pmc_traffic.json $O/pmc_traffic.json
 # the bench line last: its roofline.traffic reads the profiles/pmc_traffic.json written just above
 python bench.py > $O/bench.json 2> $O/bench.err
 tail -1 $O/bench.json | cut -c1-300
-rm -rf $O/trace $O/fetch $O/write          # the raw traces stay on the box (tens of MB); the summaries travel back
+rm -rf $O/trace $O/fetch $O/write $O/sqa $O/sqb          # the raw traces stay on the box (tens of MB); the summaries travel back
 ls -la $O
