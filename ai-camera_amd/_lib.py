@@ -73,6 +73,7 @@ _SIGS = {
     "aic_appearance_cost": (_I, [_I, _P, _P, _I, _I, _I, _P, _P, _I, _P]),
     "aic_lsap": (_I, [_P, _I, _I, _P, _P]),
     "aic_min_cost_matching": (_I, [_P, _I, _I, _D, _P, _P, _P]),
+    "aic_match_cascade": (_I, [_P, _P, _P, _I, _I, _P, _P, _D, _D, _I, _P, _P, _P, _P, _P, _P, _P]),
     "aic_tracker_create": (_I, [_I, _P, _P]),
     "aic_tracker_destroy": (_I, [_P]),
     "aic_tracker_predict": (_I, [_P]),
@@ -95,6 +96,9 @@ _SIGS = {
     "aic_pipeline_tracker": (_I, [_P, _P]),
     "aic_pipeline_stats": (_I, [_P, _P, _P, _P, _P, _I]),
     "aic_pipeline_last_embeddings": (_I, [_P, _P, _I, _P, _P]),
+    "aic_pipeline_option": (_I, [_P, C.c_char_p, _I]),
+    "aic_pipeline_counters": (_I, [_P, _P, _P]),
+    "aic_pipeline_group_embeddings": (_I, [_P, _P, _I, _P, _I, _P, _P, _P]),
     "aic_prof_enable": (_I, [_I, _I]),
     "aic_prof_reset": (_I, [_I]),
     "aic_prof_read": (_I, [_I, _I, _P, _P, _P, _P]),

@@ -13,20 +13,9 @@
 #include <vector>
 
 #include "../../include/aicam.h"
+#include "assoc_host.hpp"
 
 namespace aic {
-
-struct Error : std::runtime_error {
-    int code;
-    Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
-};
-
-void set_last_error(const std::string& m);
-
-#define AIC_REQUIRE(cond, code, msg)                                              \
-    do {                                                                          \
-        if (!(cond)) throw ::aic::Error((code), std::string(msg));                \
-    } while (0)
 
 #define HIP_CHECK(expr)                                                                        \
     do {                                                                                       \
@@ -35,21 +24,6 @@ void set_last_error(const std::string& m);
             throw ::aic::Error(AIC_ERR_RUNTIME, std::string(#expr) + ": " + hipGetErrorString(_e) + \
                                                     " (" __FILE__ ":" + std::to_string(__LINE__) + ")"); \
     } while (0)
-
-// Wraps the body of every extern "C" entry point.
-template <class F>
-static inline int guarded(F&& f) {
-    try {
-        f();
-        return AIC_OK;
-    } catch (const Error& e) {
-        set_last_error(e.what());
-        return e.code;
-    } catch (const std::exception& e) {
-        set_last_error(e.what());
-        return AIC_ERR_RUNTIME;
-    }
-}
 
 template <class T>
 struct DevBuf {

@@ -529,9 +529,15 @@ int aic_reid_infer(aic_model* mm, const float* crops, int n, int mem, float* emb
         AIC_REQUIRE(m.kind == KIND_REID, AIC_ERR_INVALID, "not a ReID engine");
         m.dev->use();
         hipStream_t s = m.dev->s_main;
-        load_input_nchw(m, crops, n, mem, s);
-        m.run(n, s);
-        copy_out(emb, m.embeddings(), (size_t)n * m.out_dim * 4, out_mem, s);
+        // more crops than the activation arena holds: launch groups of max_items (reid_model.py:80-101 passes every valid
+        // crop; a crowded frame must not fail or drop detections)
+        const size_t per_in = (size_t)3 * m.in_h * m.in_w;
+        for (int c0 = 0; c0 < n; c0 += m.max_items) {
+            const int k = std::min(m.max_items, n - c0);
+            load_input_nchw(m, crops + (size_t)c0 * per_in, k, mem, s);
+            m.run(k, s);
+            copy_out(emb + (size_t)c0 * m.out_dim, m.embeddings(), (size_t)k * m.out_dim * 4, out_mem, s);
+        }
         HIP_CHECK(hipStreamSynchronize(s));
     });
 }
@@ -610,21 +616,23 @@ int aic_reid_embed(aic_model* mm, const uint8_t* frame, int h, int w, int mem, c
         AIC_REQUIRE(frame && boxes && emb, AIC_ERR_INVALID, "NULL argument");
         Model& m = mm->m;
         AIC_REQUIRE(m.kind == KIND_REID, AIC_ERR_INVALID, "not a ReID engine");
-        AIC_REQUIRE(n <= m.max_items, AIC_ERR_CAPACITY, "crop count exceeds the engine's max_items");
         m.dev->use();
         hipStream_t s = m.dev->s_main;
         const uint8_t* df = stage_frames(m, frame, (size_t)h * w * 3, mem, s);
         m.d_crop_boxes.ensure((size_t)n * 4);
         m.d_valid.ensure(n);
         HIP_CHECK(hipMemcpyAsync(m.d_crop_boxes.p, boxes, (size_t)n * 16, hipMemcpyHostToDevice, s));
-        {
-            Prof pr(*m.dev, PROF_CROP, s, 0, (double)n * m.in_h * m.in_w * 19);
-            m.in_pix4 = m.input_pix4_ok();
-            launch_crop_resize(df, h, w, m.d_crop_boxes.p, nullptr, n, nullptr, m.in_h, m.in_w, m.in_pix4 ? 2 : 1, m.dtype, m.input(),
-                               m.d_valid.p, s);
+        m.in_pix4 = m.input_pix4_ok();
+        for (int c0 = 0; c0 < n; c0 += m.max_items) {   // launch groups of max_items: every detection is embedded (deepsort_tracker.py:104-113)
+            const int k = std::min(m.max_items, n - c0);
+            {
+                Prof pr(*m.dev, PROF_CROP, s, 0, (double)k * m.in_h * m.in_w * 19);
+                launch_crop_resize(df, h, w, m.d_crop_boxes.p + (size_t)c0 * 4, nullptr, k, nullptr, m.in_h, m.in_w, m.in_pix4 ? 2 : 1, m.dtype,
+                                   m.input(), m.d_valid.p + c0, s);
+            }
+            m.run(k, s);
+            copy_out(emb + (size_t)c0 * m.out_dim, m.embeddings(), (size_t)k * m.out_dim * 4, AIC_HOST, s);
         }
-        m.run(n, s);
-        copy_out(emb, m.embeddings(), (size_t)n * m.out_dim * 4, AIC_HOST, s);
         if (valid) HIP_CHECK(hipMemcpyAsync(valid, m.d_valid.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
         HIP_CHECK(hipStreamSynchronize(s));
     });

@@ -12,14 +12,15 @@
 //   (2) among equal reduced path costs the LAST visited unassigned column wins, otherwise the
 //       FIRST visited column;
 //   (3) the dual update and the back-tracking along `pred` follow the augmentation order.
-// Pinned against SciPy itself in tests/test_lsap.py (random, tied, quantised, constant and
-// partly infeasible matrices) and against the reference through tests/golden/assign.npz.
+// Pinned against SciPy itself in tests/test_host_logic.py::test_lsap_matches_scipy (random, tied, quantised, constant
+// and partly infeasible matrices) and against the reference through tests/golden/assign.npz
+// (test_min_cost_matching_matches_reference_fixtures); tools/asan_host.sh runs both under ASan/UBSan.
 #include <cmath>
 #include <limits>
 #include <numeric>
 #include <algorithm>
 
-#include "common.hpp"
+#include "assoc_host.hpp"
 
 namespace aic {
 

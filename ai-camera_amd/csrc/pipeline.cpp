@@ -64,6 +64,10 @@ struct Pipeline {
     // host-side wall time (seconds): issuing launch groups, waiting for a group, walking frames through the tracker
     double t_issue = 0, t_wait = 0, t_track = 0;
     long n_frames_done = 0;
+    bool taper = getenv("AICAM_NO_TAPER") == nullptr;   // aic_pipeline_option("taper")
+    int last_chunk = -1;             // chunk context of the most recently finished launch group (aic_pipeline_group_embeddings)
+    long n_grow = 0;                 // launch groups whose crop count outgrew the buffers sized from max_persons
+    long n_rows_clipped = 0;         // frames with more confirmed tracks than the caller's max_persons output rows
     bool split_streams = getenv("AICAM_SPLIT_STREAMS") != nullptr;
     bool pipe_times = getenv("AICAM_PIPE_TIMES") != nullptr;
     hipEvent_t prev_end = nullptr;   // measured: no gain on MI355X
@@ -79,8 +83,6 @@ struct Pipeline {
         AIC_REQUIRE(p.frame_h > 0 && p.frame_w > 0 && p.batch > 0 && p.ring_frames >= p.batch && p.max_persons > 0,
                     AIC_ERR_INVALID, "bad pipeline geometry");
         AIC_REQUIRE(p.batch <= y->max_items, AIC_ERR_CAPACITY, "batch exceeds the YOLO engine's max_items");
-        AIC_REQUIRE((long)p.batch * p.max_persons <= r->max_items, AIC_ERR_CAPACITY,
-                    "batch * max_persons exceeds the ReID engine's max_items");
         AIC_REQUIRE(p.max_det > 0 && p.max_det <= y->max_det_cap, AIC_ERR_CAPACITY, "max_det out of range");
         dev->use();
         geom = letterbox_geometry(p.frame_h, p.frame_w, y->in_h, y->in_w);
@@ -120,11 +122,12 @@ struct Pipeline {
 
     bool tracked_class(int c) const { return c >= 0 && c < 128 && ((prm.track_class_mask[c >> 6] >> (c & 63)) & 1ull); }
 
-    // deepsort_tracker.py:88-101: order-preserving confidence / class filter (+ capacity cap)
+    // deepsort_tracker.py:88-101: order-preserving confidence / class filter. EVERY surviving detection goes on to ReID and
+    // the tracker, as in the reference; max_persons only sizes the buffers a launch group starts with (they grow).
     void collect(FrameDets& fd, int n, const float* boxes_xyxy, const float* conf, const int* cls) {
         fd.n = 0;
         fd.tlwh.clear(), fd.xyxy.clear(), fd.conf.clear(), fd.cls.clear();
-        for (int i = 0; i < n && fd.n < prm.max_persons; ++i) {
+        for (int i = 0; i < n; ++i) {
             if (!(conf[i] >= prm.min_confidence) || !tracked_class(cls[i])) continue;
             const float* b = boxes_xyxy + (size_t)i * 4;
             fd.tlwh.insert(fd.tlwh.end(), {b[0], b[1], b[2] - b[0], b[3] - b[1]});   // deepsort_tracker.py:185-186
@@ -179,27 +182,40 @@ struct Pipeline {
                         c.h_labels.p + (size_t)f * prm.max_det);
             }
             fd.crop0 = nc;
-            for (int i = 0; i < fd.n; ++i) {
-                std::copy(fd.xyxy.begin() + i * 4, fd.xyxy.begin() + i * 4 + 4, c.h_boxes.p + (size_t)(nc + i) * 4);
-                c.h_frame_of.p[nc + i] = f;
-            }
             nc += fd.n;
         }
         c.n_crops = nc;
+        if ((size_t)nc > c.h_frame_of.n) {          // a crowded group: grow the crop buffers (this context is idle: stage B released it)
+            HIP_CHECK(hipStreamSynchronize(s));
+            const size_t cap = (size_t)nc + nc / 4;
+            c.h_boxes.alloc(cap * 4), c.h_frame_of.alloc(cap), c.h_valid.alloc(cap);
+            c.d_boxes.alloc(cap * 4), c.d_frame_of.alloc(cap), c.d_valid.alloc(cap), c.d_emb.alloc(cap * dim), c.d_emb_n.alloc(cap * dim);
+            n_grow += 1;
+        }
+        for (int f = 0; f < frames; ++f) {
+            const FrameDets& fd = c.dets[f];
+            for (int i = 0; i < fd.n; ++i) {
+                std::copy(fd.xyxy.begin() + i * 4, fd.xyxy.begin() + i * 4 + 4, c.h_boxes.p + (size_t)(fd.crop0 + i) * 4);
+                c.h_frame_of.p[fd.crop0 + i] = f;
+            }
+        }
         // crop + ReID on their own stream: in inject mode they do not depend on the detector, and their CU-filling
         // launches backfill the CUs that YOLO's thin layers (50-400 blocks per launch) leave idle
         hipStream_t sr = split_streams ? dev->s_reid : s;
         if (nc) {
             HIP_CHECK(hipMemcpyAsync(c.d_boxes.p, c.h_boxes.p, (size_t)nc * 16, hipMemcpyHostToDevice, sr));
             HIP_CHECK(hipMemcpyAsync(c.d_frame_of.p, c.h_frame_of.p, (size_t)nc * 4, hipMemcpyHostToDevice, sr));
-            {
-                Prof pr(*dev, PROF_CROP, sr, 0, (double)nc * reid->in_h * reid->in_w * 19);
-                reid->in_pix4 = reid->input_pix4_ok();
-                launch_crop_resize(f0, prm.frame_h, prm.frame_w, c.d_boxes.p, c.d_frame_of.p, nc, nullptr, reid->in_h,
-                                   reid->in_w, reid->in_pix4 ? 2 : 1, reid->dtype, reid->input(), c.d_valid.p, sr, true);
+            reid->in_pix4 = reid->input_pix4_ok();
+            for (int c0 = 0; c0 < nc; c0 += reid->max_items) {   // more crops than the ReID arena holds: several launch groups, nothing dropped
+                const int k = std::min(reid->max_items, nc - c0);
+                {
+                    Prof pr(*dev, PROF_CROP, sr, 0, (double)k * reid->in_h * reid->in_w * 19);
+                    launch_crop_resize(f0, prm.frame_h, prm.frame_w, c.d_boxes.p + (size_t)c0 * 4, c.d_frame_of.p + c0, k, nullptr, reid->in_h,
+                                       reid->in_w, reid->in_pix4 ? 2 : 1, reid->dtype, reid->input(), c.d_valid.p + c0, sr, true);
+                }
+                reid->run(k, sr);
+                HIP_CHECK(hipMemcpyAsync(c.d_emb.p + (size_t)c0 * dim, reid->embeddings(), (size_t)k * dim * 4, hipMemcpyDeviceToDevice, sr));
             }
-            reid->run(nc, sr);
-            HIP_CHECK(hipMemcpyAsync(c.d_emb.p, reid->embeddings(), (size_t)nc * dim * 4, hipMemcpyDeviceToDevice, sr));
             {   // matching.py:126-130 for every detection of the launch group at once
                 Prof pr(*dev, PROF_TRK, sr, 0, (double)nc * dim * 8);
                 launch_normalize_rows(c.d_emb.p, c.d_emb_n.p, nc, dim, sr);
@@ -234,7 +250,8 @@ struct Pipeline {
         trk.defer_outputs = true;
         auto emit = [&](int o) {               // the tracker's resolved outputs -> row o of the caller's arrays
             const std::vector<TrackOut>& outs = trk.resolved;
-            if (n_tracks) n_tracks[o] = (int32_t)outs.size();
+            if (n_tracks) n_tracks[o] = (int32_t)outs.size();       // the true count: rows beyond max_persons are not stored
+            if ((int)outs.size() > prm.max_persons) n_rows_clipped += 1;
             for (size_t k = 0; k < outs.size() && (int)k < prm.max_persons; ++k) {
                 const TrackOut& t = outs[k];
                 if (tracks6) {
@@ -282,6 +299,7 @@ struct Pipeline {
             }
         }
         trk.defer_outputs = false;             // direct users of the tracker handle get synchronous outputs
+        last_chunk = (int)(&c - &ck[0]);
         t_track += now() - t1;
         n_frames_done += c.frames;
     }
@@ -298,7 +316,6 @@ struct Pipeline {
         // final group cannot overlap any GPU work, so a short final group shortens the un-overlapped tail of the call.
         std::vector<int> goff, glen;
         {
-            static const bool taper = getenv("AICAM_NO_TAPER") == nullptr;
             for (int pass = 0; pass < passes; ++pass) {
                 const bool last = pass == passes - 1;
                 int done = 0;
@@ -482,6 +499,44 @@ int aic_pipeline_stats(aic_pipeline* p, double* issue_s, double* wait_s, double*
         if (track_s) *track_s = p->p.t_track;
         if (frames) *frames = p->p.n_frames_done;
         if (reset) p->p.t_issue = p->p.t_wait = p->p.t_track = 0, p->p.n_frames_done = 0;
+    });
+}
+
+int aic_pipeline_option(aic_pipeline* p, const char* key, int value) {
+    return guarded([&] {
+        AIC_REQUIRE(p && key, AIC_ERR_INVALID, "NULL argument");
+        const std::string k(key);
+        if (k == "taper") p->p.taper = value != 0;
+        else AIC_REQUIRE(false, AIC_ERR_INVALID, "unknown pipeline option: " + k);
+    });
+}
+
+int aic_pipeline_counters(aic_pipeline* p, int64_t* grown_groups, int64_t* clipped_frames) {
+    return guarded([&] {
+        AIC_REQUIRE(p, AIC_ERR_INVALID, "NULL pipeline");
+        if (grown_groups) *grown_groups = p->p.n_grow;
+        if (clipped_frames) *clipped_frames = p->p.n_rows_clipped;
+    });
+}
+
+int aic_pipeline_group_embeddings(aic_pipeline* p, float* emb, int cap_rows, int32_t* crops_per_frame, int cap_frames,
+                                  int32_t* n_rows, int32_t* n_frames, int32_t* dim) {
+    return guarded([&] {
+        AIC_REQUIRE(p && n_rows && n_frames && dim, AIC_ERR_INVALID, "NULL argument");
+        Pipeline& q = p->p;
+        *dim = q.dim, *n_rows = 0, *n_frames = 0;
+        if (q.last_chunk < 0) return;
+        const Chunk& c = q.ck[q.last_chunk];
+        *n_rows = c.n_crops, *n_frames = c.frames;
+        if (crops_per_frame) {
+            AIC_REQUIRE(c.frames <= cap_frames, AIC_ERR_CAPACITY, "frame capacity too small");
+            for (int f = 0; f < c.frames; ++f) crops_per_frame[f] = c.dets[f].n;
+        }
+        if (emb && c.n_crops) {
+            AIC_REQUIRE(c.n_crops <= cap_rows, AIC_ERR_CAPACITY, "embedding capacity too small");
+            q.dev->use();
+            HIP_CHECK(hipMemcpy(emb, c.d_emb.p, (size_t)c.n_crops * q.dim * 4, hipMemcpyDeviceToHost));
+        }
     });
 }
 

@@ -21,7 +21,6 @@
 namespace aic {
 
 static const float kInfty = 1e5f;                              // linear_assignment.py:9
-static const float kChi2_4 = (float)9.487729036781154;          // kalman_filter.py:16, compared in fp32
 
 Tracker::Tracker(Device& d, const aic_tracker_params& p) : dev(&d), prm(p) {
     cap = p.max_tracks > 0 ? p.max_tracks : 512;
@@ -42,6 +41,24 @@ void Tracker::ensure_dim(int d) {
     dim = d;
     d_gal_raw.alloc((size_t)cap * gmax * dim);
     d_gal_n.alloc((size_t)cap * gmax * dim);
+}
+
+// nn_budget=None (track.py:70-74 never pops): the rings never wrap, so growing = re-striding rows [slot][0..glen) in place
+// order. Doubles the per-track capacity; called BEFORE update() mutates anything, so a failure leaves the tracker intact.
+void Tracker::grow_galleries() {
+    const int kMaxRows = 16384;
+    AIC_REQUIRE(gmax < kMaxRows, AIC_ERR_CAPACITY, "unlimited gallery (nn_budget=None) reached 16384 rows per track: set an nn_budget");
+    const int g2 = gmax * 2;
+    dev->use();
+    hipStream_t s = dev->s_trk;
+    DevBuf<float> raw2((size_t)cap * g2 * dim), n2((size_t)cap * g2 * dim);
+    const size_t spitch = (size_t)gmax * dim * 4, dpitch = (size_t)g2 * dim * 4;
+    HIP_CHECK(hipMemcpy2DAsync(raw2.p, dpitch, d_gal_raw.p, spitch, spitch, cap, hipMemcpyDeviceToDevice, s));
+    HIP_CHECK(hipMemcpy2DAsync(n2.p, dpitch, d_gal_n.p, spitch, spitch, cap, hipMemcpyDeviceToDevice, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    d_gal_raw = std::move(raw2);
+    d_gal_n = std::move(n2);
+    gmax = g2;
 }
 
 void Tracker::predict() {   // tracker_core.py:44-49 -> track.py:76-80
@@ -71,80 +88,15 @@ void Tracker::flush_predict() {
     launch_kf_predict(d_mean.p, d_cov.p, d_slots.p, T, s);
 }
 
-// linear_assignment.py:91-157 + tracker_core.py:83-177 on precomputed full matrices.
+// linear_assignment.py:91-157 + tracker_core.py:83-177 on precomputed full matrices: assoc_host.cpp (HIP-free, built under
+// ASan/UBSan by tools/asan_host.sh).
 void Tracker::match(int T, int N, const float* app, const float* maha, const float* iou,
                     std::vector<std::pair<int, int>>& matches, std::vector<int>& unmatched_t,
                     std::vector<int>& unmatched_d) {
-    matches.clear();
-    unmatched_t.clear();
-    unmatched_d.clear();
-    std::vector<int> confirmed, tentative;
-    for (int i = 0; i < T; ++i) {
-        if (tracks[i].state == TRK_CONFIRMED) confirmed.push_back(i);
-        else if (tracks[i].state == TRK_TENTATIVE) tentative.push_back(i);
-    }
-    for (int j = 0; j < N; ++j) unmatched_d.push_back(j);
-    std::vector<char> got(T, 0);
-    std::vector<float> sub;
-    std::vector<int> mr, mc, rows;
-    // stage 1: cascade over time_since_update = 1 .. max_age, gated appearance cost
-    for (int level = 0; level < prm.max_age; ++level) {
-        if (unmatched_d.empty()) break;
-        rows.clear();
-        for (int i : confirmed)
-            if (tracks[i].tsu == level + 1) rows.push_back(i);
-        if (rows.empty()) continue;
-        const int nr = (int)rows.size(), nc = (int)unmatched_d.size();
-        sub.resize((size_t)nr * nc);
-        for (int r = 0; r < nr; ++r)
-            for (int c = 0; c < nc; ++c) {
-                const size_t k = (size_t)rows[r] * N + unmatched_d[c];
-                sub[(size_t)r * nc + c] = (maha[k] > kChi2_4) ? kInfty : app[k];   // linear_assignment.py:187-210
-            }
-        min_cost_matching(sub.data(), nr, nc, prm.max_cosine_distance, mr, mc);
-        std::vector<char> dead(nc, 0);
-        for (size_t k = 0; k < mr.size(); ++k) {
-            matches.emplace_back(rows[mr[k]], unmatched_d[mc[k]]);
-            got[rows[mr[k]]] = 1;
-            dead[mc[k]] = 1;
-        }
-        std::vector<int> keep;
-        for (int c = 0; c < nc; ++c)
-            if (!dead[c]) keep.push_back(unmatched_d[c]);
-        unmatched_d.swap(keep);
-    }
-    // stage 2: IoU on tentative + confirmed tracks that missed exactly one frame
-    std::vector<int> cand = tentative, stale;
-    for (int i : confirmed) {
-        if (got[i]) continue;
-        if (tracks[i].tsu == 1) cand.push_back(i);
-        else if (tracks[i].tsu > 1) stale.push_back(i);
-        else stale.push_back(i);   // tsu == 0 cannot occur after predict(); kept unmatched like the reference
-    }
-    // NB reference order: tentative first, then confirmed (tracker_core.py:138-141)
-    std::vector<int> un_cand = cand;
-    if (!cand.empty() && !unmatched_d.empty()) {
-        const int nr = (int)cand.size(), nc = (int)unmatched_d.size();
-        sub.resize((size_t)nr * nc);
-        for (int r = 0; r < nr; ++r)
-            for (int c = 0; c < nc; ++c) sub[(size_t)r * nc + c] = iou[(size_t)cand[r] * N + unmatched_d[c]];
-        min_cost_matching(sub.data(), nr, nc, prm.max_iou_distance, mr, mc);
-        std::vector<char> dead(nc, 0), rdead(nr, 0);
-        for (size_t k = 0; k < mr.size(); ++k) {
-            matches.emplace_back(cand[mr[k]], unmatched_d[mc[k]]);
-            dead[mc[k]] = 1;
-            rdead[mr[k]] = 1;
-        }
-        std::vector<int> keep;
-        for (int c = 0; c < nc; ++c)
-            if (!dead[c]) keep.push_back(unmatched_d[c]);
-        unmatched_d.swap(keep);
-        un_cand.clear();
-        for (int r = 0; r < nr; ++r)
-            if (!rdead[r]) un_cand.push_back(cand[r]);
-    }
-    unmatched_t = stale;
-    unmatched_t.insert(unmatched_t.end(), un_cand.begin(), un_cand.end());
+    std::vector<int> state(T), tsu(T);
+    for (int i = 0; i < T; ++i) state[i] = tracks[i].state, tsu[i] = tracks[i].tsu;
+    cascade_match(T, N, state.data(), tsu.data(), app, maha, iou, prm.max_cosine_distance, prm.max_iou_distance, prm.max_age,
+                  matches, unmatched_t, unmatched_d);
 }
 
 static inline int round_half_even(float v) { return (int)std::nearbyintf(v); }
@@ -189,6 +141,12 @@ void Tracker::update(const float* det_tlwh, const float* conf, const int32_t* cl
     const bool any_feat = feat != nullptr && n > 0;
     if (any_feat) ensure_dim(dim_in);
     AIC_REQUIRE(n >= 0, AIC_ERR_INVALID, "negative detection count");
+    AIC_REQUIRE(n <= 1536, AIC_ERR_CAPACITY, "more than 1536 detections in one frame (association kernel LDS rows)");
+    if (unlimited && dim > 0) {                // every capacity check happens before the first mutation of host or device state
+        int longest = 0;
+        for (const auto& t : tracks) longest = std::max(longest, t.glen);
+        if (longest + 1 > gmax) grow_galleries();
+    }
     std::vector<uint8_t> hf(n, any_feat ? 1 : 0);
     if (any_feat && has_feat) std::copy(has_feat, has_feat + n, hf.begin());
 
@@ -309,7 +267,7 @@ void Tracker::update(const float* det_tlwh, const float* conf, const int32_t* cl
             pos = (t.ghead + t.glen) % gmax;
             t.glen += 1;
         } else {
-            AIC_REQUIRE(!unlimited, AIC_ERR_CAPACITY, "unlimited gallery exceeded its 256-row capacity");
+            AIC_REQUIRE(!unlimited, AIC_ERR_RUNTIME, "unlimited gallery ring wrapped (grow_galleries runs before the lifecycle)");
             pos = t.ghead;
             t.ghead = (t.ghead + 1) % gmax;
         }

@@ -4,9 +4,6 @@
 
 namespace aic {
 
-void min_cost_matching(const float* cost, int nr, int nc, double max_distance, std::vector<int>& mrow,
-                       std::vector<int>& mcol);
-
 enum { TRK_TENTATIVE = 1, TRK_CONFIRMED = 2, TRK_DELETED = 3 };   // src/tracker/core/track.py:10-14
 
 struct TrackRec {
@@ -60,6 +57,7 @@ struct Tracker {
 
     Tracker(Device& d, const aic_tracker_params& p);
     void ensure_dim(int d);
+    void grow_galleries();
     void predict();
     // feat may be host or device memory ([n, dim] fp32)
     void flush_predict();

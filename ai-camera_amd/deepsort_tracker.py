@@ -13,11 +13,13 @@ class DeepSORT:
                  max_cosine_distance=config.DEEPSORT_MAX_DIST, nn_budget=config.DEEPSORT_NN_BUDGET,
                  max_iou_distance=config.DEEPSORT_MAX_IOU_DISTANCE, max_age=config.DEEPSORT_MAX_AGE,
                  n_init=config.DEEPSORT_N_INIT, min_detection_confidence=config.DEEPSORT_MIN_CONFIDENCE,
-                 device=None, dtype="fp16"):
+                 device=None, dtype="fp16", max_tracks=512, reid_max_batch=128):
         dev = config.resolve_device(device)
-        self.reid_model = ReIDModel(engine_path=reid_model_path, input_shape=reid_input_shape, device=device, dtype=dtype)
+        self.reid_model = ReIDModel(engine_path=reid_model_path, input_shape=reid_input_shape, device=device, dtype=dtype,
+                                    max_batch=reid_max_batch)
         self.tracker_core = TrackerCore(max_cosine_distance=max_cosine_distance, nn_budget=nn_budget,
-                                        max_iou_distance=max_iou_distance, max_age=max_age, n_init=n_init, device=dev)
+                                        max_iou_distance=max_iou_distance, max_age=max_age, n_init=n_init, device=dev,
+                                        max_tracks=max_tracks)
         self.min_detection_confidence = min_detection_confidence
         self.frame_count = 0
         print("DeepSORT Tracker initialized.")

@@ -135,6 +135,24 @@ class TrackingPipeline:
     def unpin(array):
         L.call("aic_host_unregister", L.ptr(array))
 
+    def option(self, key, value):
+        """Runtime option of the C pipeline (aic_pipeline_option): e.g. option("taper", 0) = full launch groups only."""
+        L.call("aic_pipeline_option", self._h, str(key).encode(), int(value))
+
+    def counters(self):
+        a, b = C.c_int64(), C.c_int64()
+        L.call("aic_pipeline_counters", self._h, C.byref(a), C.byref(b))
+        return dict(grown_groups=a.value, clipped_frames=b.value)
+
+    def group_embeddings(self):
+        """Embeddings of every crop of the most recently finished launch group: (emb [rows, dim], crops_per_frame [frames])."""
+        n, f, d = C.c_int32(), C.c_int32(), C.c_int32()
+        L.call("aic_pipeline_group_embeddings", self._h, None, 0, None, 0, C.byref(n), C.byref(f), C.byref(d))
+        emb, per = np.zeros((n.value, d.value), np.float32), np.zeros(f.value, np.int32)
+        L.call("aic_pipeline_group_embeddings", self._h, L.ptr(emb), max(n.value, 1), L.ptr(per), max(f.value, 1),
+               C.byref(n), C.byref(f), C.byref(d))
+        return emb, per
+
     def last_embeddings(self):
         n, d = C.c_int32(), C.c_int32()
         L.call("aic_pipeline_last_embeddings", self._h, None, 1 << 30, C.byref(n), C.byref(d))

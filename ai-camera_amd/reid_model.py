@@ -29,8 +29,9 @@ class ReIDModel:
 
     def extract_features_batched(self, image_crops_bgr):
         """reid_model.py:67-126: list of BGR crops -> fp32 [N_valid, feature_dim]; invalid crops are
-        skipped with a warning, an empty list gives [0, feature_dim].  All valid crops go in ONE batch
-        (the reference's intent; its engine profile capped at 8 made it fail silently)."""
+        skipped with a warning, an empty list gives [0, feature_dim].  All valid crops go in one call (the
+        reference's intent; its engine profile capped at 8 made it fail silently); the library runs them in launch
+        groups of `max_batch` (the activation arena), so a crowded frame neither fails nor drops detections."""
         if not image_crops_bgr:
             return np.empty((0, self.feature_dim), dtype=np.float32)
         tensors = []

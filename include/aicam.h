@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define AIC_ABI_VERSION 1
+#define AIC_ABI_VERSION 2
 
 #define AIC_OK 0
 #define AIC_ERR_INVALID (-1)   /* bad argument            (reference: ValueError / TypeError)  */
@@ -146,6 +146,16 @@ int aic_lsap(const double* cost, int nr, int nc, int64_t* row_ind, int64_t* col_
 int aic_min_cost_matching(const float* cost, int nr, int nc, double max_distance, int32_t* match_row,
                           int32_t* match_col, int32_t* n_match);
 
+/* matching_cascade + the IoU stage of TrackerCore._match (linear_assignment.py:91-157, tracker_core.py:83-177) on the
+ * full cost matrices of one frame: app/maha/iou[T,N] (appearance cost, squared Mahalanobis distance, 1-IoU), state[T]
+ * (1 tentative, 2 confirmed) and time_since_update[T] after predict().  HOST code.  Outputs: matches as (track index,
+ * detection index) in the reference's order, unmatched tracks, unmatched detections; capacities min(T,N), T, N. */
+int aic_match_cascade(const float* app, const float* maha, const float* iou, int t, int n, const int32_t* state,
+                      const int32_t* time_since_update, double max_cosine_distance, double max_iou_distance,
+                      int max_age, int32_t* match_track, int32_t* match_det, int32_t* n_match,
+                      int32_t* unmatched_tracks, int32_t* n_unmatched_tracks, int32_t* unmatched_dets,
+                      int32_t* n_unmatched_dets);
+
 /* ------------------------------------------------------------------ tracker
  * TrackerCore (src/tracker/core/tracker_core.py:11-198) + Track lifecycle
  * (src/tracker/core/track.py:16-171).  Kalman state and feature galleries live in HBM;
@@ -194,7 +204,9 @@ typedef struct aic_pipeline_params {
     int32_t frame_h, frame_w;
     int32_t batch;          /* frames per detection/ReID launch group                    */
     int32_t ring_frames;    /* frames kept resident in HBM                                */
-    int32_t max_persons;    /* detections kept per frame for ReID/association             */
+    int32_t max_persons;    /* rows per frame in the caller's track arrays; also sizes the crop buffers a launch
+                             * group starts with (they grow: EVERY detection that passes the filter of
+                             * deepsort_tracker.py:88-101 is embedded and tracked, none is dropped)      */
     float conf_thresh;      /* 0.3 src/config.py:17 */
     float iou_thresh;       /* 0.5 src/config.py:18 (unused by the reference, F4)        */
     int32_t max_det;        /* 300 (build decision D4)                                    */
@@ -213,7 +225,8 @@ int aic_pipeline_upload(aic_pipeline* p, int slot, const uint8_t* frames_bgr, in
 int aic_pipeline_inject(aic_pipeline* p, int slot, int count, const int32_t* counts,
                         const float* boxes_xyxy, const float* conf, const int32_t* cls);
 /* Process ring slots [slot, slot+count) in order. Per frame outputs (any may be NULL):
- * n_tracks[count], tracks[count,max_persons,6] + track_conf as aic_tracker_outputs;
+ * n_tracks[count] (the true number of confirmed tracks of the frame; when it exceeds max_persons only the first
+ * max_persons rows are stored), tracks[count,max_persons,6] + track_conf as aic_tracker_outputs;
  * n_dets[count], det_boxes[count,max_det,4], det_scores, det_labels from the detector. */
 int aic_pipeline_run(aic_pipeline* p, int slot, int count, int32_t* n_tracks, int32_t* tracks6,
                      float* track_conf, int32_t* n_dets, float* det_boxes, float* det_scores,
@@ -234,6 +247,16 @@ int aic_pipeline_tracker(aic_pipeline* p, aic_tracker** out);
 /* Host wall-clock split since the last reset (seconds): issuing launch groups (producer thread), waiting for
  * a group's GPU work, walking its frames through the tracker (association recurrence). */
 int aic_pipeline_stats(aic_pipeline* p, double* issue_s, double* wait_s, double* track_s, int64_t* frames, int reset);
+/* Runtime options (tests / measurements). "taper": 1 (default) = the last launch group of a call is split into
+ * shrinking groups so its un-overlapped tracker tail is short, 0 = full groups only. */
+int aic_pipeline_option(aic_pipeline* p, const char* key, int value);
+/* Launch groups whose crop count outgrew the buffers sized from max_persons (handled, not dropped), and frames
+ * whose confirmed tracks outnumbered the caller's max_persons rows (n_tracks reports the true count). */
+int aic_pipeline_counters(aic_pipeline* p, int64_t* grown_groups, int64_t* clipped_frames);
+/* ReID embeddings of every crop of the most recently finished launch group, frame-major (parity tests of the
+ * production-size kernel mix): emb[n_rows, dim] host, crops_per_frame[n_frames]. Any output pointer may be NULL. */
+int aic_pipeline_group_embeddings(aic_pipeline* p, float* emb, int cap_rows, int32_t* crops_per_frame, int cap_frames,
+                                  int32_t* n_rows, int32_t* n_frames, int32_t* dim);
 /* Embeddings of the last processed frame (parity tests): emb[n,dim] host. */
 int aic_pipeline_last_embeddings(aic_pipeline* p, float* emb, int cap_rows, int32_t* n, int32_t* dim);
 

@@ -191,6 +191,38 @@ def threshold_and_assign(cost, max_distance, rows, cols):
     return matches, ur, uc
 
 
+def cascade_on_matrices(full_app, full_gate, full_iou, state, tsu, max_cosine_distance, max_iou_distance, max_age):
+    """linear_assignment.py:91-157 + tracker_core.py:83-177 on the full [T,N] cost matrices of one frame.
+    Returns (matches [(track, det)], unmatched tracks, unmatched dets) in the reference's order."""
+    n_t, n = len(state), (full_app.shape[1] if len(state) else full_iou.shape[1] if full_iou.ndim == 2 else 0)
+    confirmed = [i for i in range(n_t) if state[i] == CONFIRMED]
+    tentative = [i for i in range(n_t) if state[i] == TENTATIVE]
+    # stage 1: matching cascade, linear_assignment.py:91-157
+    unmatched_d = list(range(n))
+    matches = []
+    for level in range(max_age):
+        if not unmatched_d:
+            break
+        rows = [i for i in confirmed if tsu[i] == level + 1]
+        if not rows:
+            continue
+        c = full_app[np.ix_(rows, unmatched_d)].copy()
+        c[full_gate[np.ix_(rows, unmatched_d)] > CHI2INV95[4]] = INFTY_COST
+        m, _, unmatched_d = threshold_and_assign(c, max_cosine_distance, rows, unmatched_d)
+        matches += m
+    got = {i for i, _ in matches}
+    unmatched_confirmed = [i for i in confirmed if i not in got]
+    # stage 2: IoU on tentative + just-missed confirmed, tracker_core.py:138-166
+    cand = tentative + [i for i in unmatched_confirmed if tsu[i] == 1]
+    stale = [i for i in unmatched_confirmed if tsu[i] > 1]
+    if cand and unmatched_d:
+        c = full_iou[np.ix_(cand, unmatched_d)]
+        m2, ut, unmatched_d = threshold_and_assign(c, max_iou_distance, cand, unmatched_d)
+    else:
+        m2, ut = [], cand
+    return matches + m2, stale + ut, unmatched_d
+
+
 class OracleTrack:
     """Plain record with the attribute surface of track.py:16-171."""
     __slots__ = ("track_id", "mean", "covariance", "class_name", "confidence", "hits", "age",
@@ -246,31 +278,8 @@ class OracleTracker:
         full_iou = iou_cost_matrix([t.to_tlwh() for t in tr], det_tlwh)
         self.last_costs = (full_app, full_gate, full_iou)
 
-        # stage 1: matching cascade, linear_assignment.py:91-157
-        unmatched_d = list(range(n))
-        matches = []
-        for level in range(self.max_age):
-            if not unmatched_d:
-                break
-            rows = [i for i in confirmed if tr[i].time_since_update == level + 1]
-            if not rows:
-                continue
-            c = full_app[np.ix_(rows, unmatched_d)].copy()
-            c[full_gate[np.ix_(rows, unmatched_d)] > CHI2INV95[4]] = INFTY_COST
-            m, _, unmatched_d = threshold_and_assign(c, self.max_cosine_distance, rows, unmatched_d)
-            matches += m
-        got = {i for i, _ in matches}
-        unmatched_confirmed = [i for i in confirmed if i not in got]
-
-        # stage 2: IoU on tentative + just-missed confirmed, tracker_core.py:138-166
-        cand = tentative + [i for i in unmatched_confirmed if tr[i].time_since_update == 1]
-        stale = [i for i in unmatched_confirmed if tr[i].time_since_update > 1]
-        if cand and unmatched_d:
-            c = full_iou[np.ix_(cand, unmatched_d)]
-            m2, ut, unmatched_d = threshold_and_assign(c, self.max_iou_distance, cand, unmatched_d)
-        else:
-            m2, ut = [], cand
-        return matches + m2, stale + ut, unmatched_d
+        return cascade_on_matrices(full_app, full_gate, full_iou, [t.state for t in tr], [t.time_since_update for t in tr],
+                                   self.max_cosine_distance, self.max_iou_distance, self.max_age)
 
     # tracker_core.py:51-81
     def update(self, det_tlwh, det_conf, det_class, det_feats):

@@ -30,7 +30,10 @@ OP_CONV, OP_SPPF_POOL, OP_UPSAMPLE2X, OP_MAXPOOL3S2, OP_AVGPOOL, OP_L2NORM = 1, 
 
 
 class EngineOracle:
-    def __init__(self, path_or_bytes):
+    def __init__(self, path_or_bytes, dtype=torch.float32):
+        """dtype=torch.float64: the same graph evaluated in double precision -- the anchor that tells an fp32 summation-order
+        difference (HIP MFMA order vs torch's CPU conv order) from an error: both fp32 evaluations are compared with it."""
+        self.dtype = dtype
         blob = path_or_bytes if isinstance(path_or_bytes, (bytes, bytearray)) else open(path_or_bytes, "rb").read()
         hdr = struct.unpack_from("<II7i8i", blob, 0)
         assert hdr[0] == 0x57434941 and hdr[1] == 1, "bad engine file"
@@ -44,8 +47,8 @@ class EngineOracle:
         payload = np.frombuffer(blob, "<f4", -1, off)
         self.weights = []
         for co, ci, kh, kw, wo, bo in tab:
-            w = torch.from_numpy(payload[wo:wo + co * ci * kh * kw].reshape(co, ci, kh, kw).copy())
-            b = torch.from_numpy(payload[bo:bo + co].copy())
+            w = torch.from_numpy(payload[wo:wo + co * ci * kh * kw].reshape(co, ci, kh, kw).copy()).to(dtype)
+            b = torch.from_numpy(payload[bo:bo + co].copy()).to(dtype)
             self.weights.append((w, b))
 
     # ------------------------------------------------------------------ graph
@@ -54,7 +57,8 @@ class EngineOracle:
         """x: fp32 [N,3,H,W]. Returns the list of buffers (NCHW, channels = buffer width)."""
         n = x_nchw.shape[0]
         bufs = [None] * len(self.buffers)
-        bufs[0] = torch.cat([x_nchw.float(), torch.zeros(n, self.buffers[0][2] - 3, self.in_h, self.in_w)], 1)
+        dt = self.dtype
+        bufs[0] = torch.cat([x_nchw.to(dt), torch.zeros(n, self.buffers[0][2] - 3, self.in_h, self.in_w, dtype=dt)], 1)
 
         def get(bi, coff, c):
             return bufs[bi][:, coff:coff + c]
@@ -62,7 +66,7 @@ class EngineOracle:
         def put(bi, coff, val):
             h, w, c, _ = self.buffers[bi]
             if bufs[bi] is None:
-                bufs[bi] = torch.zeros(n, c, h, w)
+                bufs[bi] = torch.zeros(n, c, h, w, dtype=dt)
             bufs[bi][:, coff:coff + val.shape[1]] = val
 
         for o in self.ops:
@@ -114,22 +118,22 @@ class EngineOracle:
             strides.append(np.full(h * w, s, np.float32))
         return np.concatenate(pts), np.concatenate(strides)
 
-    def decode(self, dfl_logits, cls_logits):
-        """numpy fp32: boxes [N,A,4] xyxy (letterbox px), max logit [N,A], label [N,A]."""
+    def decode(self, dfl_logits, cls_logits, ft=np.float32):
+        """numpy fp32 (ft=np.float64: the double-precision anchor): boxes [N,A,4] xyxy (letterbox px), max logit [N,A], label [N,A]."""
         nc, reg_max = self.meta[0], self.meta[1]
-        d = np.asarray(dfl_logits, np.float32)
+        d = np.asarray(dfl_logits, ft)
         n, a, _ = d.shape
         d = d.reshape(n, a, 4, reg_max)
-        e = np.exp(d - d.max(-1, keepdims=True)).astype(np.float32)
-        p = e / e.sum(-1, keepdims=True, dtype=np.float32)
-        dist = (p * np.arange(reg_max, dtype=np.float32)).sum(-1, dtype=np.float32)      # l t r b
+        e = np.exp(d - d.max(-1, keepdims=True)).astype(ft)
+        p = e / e.sum(-1, keepdims=True, dtype=ft)
+        dist = (p * np.arange(reg_max, dtype=ft)).sum(-1, dtype=ft)      # l t r b
         pts, st = self.anchors()
         x1 = (pts[:, 0] - dist[..., 0]) * st
         y1 = (pts[:, 1] - dist[..., 1]) * st
         x2 = (pts[:, 0] + dist[..., 2]) * st
         y2 = (pts[:, 1] + dist[..., 3]) * st
-        c = np.asarray(cls_logits, np.float32)
-        return np.stack([x1, y1, x2, y2], -1).astype(np.float32), c.max(-1), c.argmax(-1).astype(np.int32)
+        c = np.asarray(cls_logits, ft)
+        return np.stack([x1, y1, x2, y2], -1).astype(ft), c.max(-1), c.argmax(-1).astype(np.int32)
 
 
 def logit_threshold(conf: float) -> np.float32:

@@ -1,0 +1,379 @@
+"""GPU parity at the shapes BASELINE.json's configs name (through the C ABI, against the oracle chain):
+
+* configs[0]  960x540 stream                        -> test_configs0_pipeline_960x540
+* configs[1]  the bench's own kernel mix: ONE full 512-frame / 15 360-crop fp16 launch group
+                                                    -> test_bench_shaped_group_fp16
+* configs[2]  YOLOv8m, 1920x1080, 100 persons       -> test_yolov8m_head_decode_nms, test_configs2_pipeline_ids
+* fp16 with the detector's OWN boxes feeding the tracker for >= 300 frames, deviations + ID switches against the fp32
+  oracle chain                                      -> test_fp16_own_detections_vs_fp32_oracle_chain
+* more tracked detections per frame than max_persons / the ReID arena -> test_crowded_frames_nothing_dropped
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, pkg
+from oracle import deepsort_oracle as O
+from oracle import image_oracle as I
+from oracle import nets_oracle as N
+
+pytestmark = pytest.mark.gpu
+ef = pkg("engine_file")
+syn = pkg("synthetic")
+config = pkg("config")
+HipEngine = pkg("hip_engine").HipEngine
+
+
+@pytest.fixture(scope="module")
+def engines_m():
+    return ef.ensure_seeded_engines(ROOT, scale="m")
+
+
+def reid_oracle_embeddings(eo, frame, boxes):
+    crops, valid = I.crops_to_batch(frame, boxes)
+    emb = eo.run(torch.from_numpy(crops))[eo.outputs[0][0]][:, :, 0, 0].numpy()
+    return emb, valid
+
+
+def oracle_chain_planted(sc, eo_reid, frames, n_frames, **kw):
+    """inject mode: planted boxes -> crops -> fp32 ReID oracle -> DeepSORT oracle."""
+    trk = O.OracleTracker(**kw)
+    out, embs = [], []
+    for f in range(n_frames):
+        boxes, conf, cls, _ = sc.detections(f)
+        emb, valid = reid_oracle_embeddings(eo_reid, frames[f], boxes)
+        tlwh = np.stack([boxes[:, 0], boxes[:, 1], boxes[:, 2] - boxes[:, 0], boxes[:, 3] - boxes[:, 1]], 1).astype(np.float32)
+        trk.predict()
+        trk.update(list(tlwh), list(conf), ["person"] * len(boxes), [emb[i] if valid[i] else None for i in range(len(boxes))])
+        out.append(trk.output_tuples())
+        embs.append(emb)
+    return out, embs, trk
+
+
+def assert_same_tracks(tracks, ref, n_frames):
+    for f in range(n_frames):
+        got, exp = tracks[f], ref[f]
+        assert [t[4] for t in got] == [t[4] for t in exp], (f, got, exp)            # identical track ids, same order
+        assert [t[5] for t in got] == [t[5] for t in exp]
+        if exp:
+            assert np.abs(np.array([t[:4] for t in got]) - np.array([t[:4] for t in exp])).max() <= 1
+
+
+# ------------------------------------------------------------------------------------------- configs[0]
+@pytest.mark.parametrize("dtype", ["fp32", "fp16"])
+def test_configs0_pipeline_960x540(gpu, engines, dtype):
+    """configs[0]'s frame size (the reference's own clip is 960x540: r = 2/3, resized 640x360, pad 0/140): the whole
+    pipeline, detector included, against the oracle chain."""
+    n_frames, batch = 24, 8
+    sc = syn.Scene(seed=40, n_targets=10, width=960, height=540, w_range=(30.0, 60.0), h_range=(90.0, 150.0), y_range=(30.0, 350.0),
+                   gaps=[(1, 5, 9), (7, 11, 18)], births={4: 6})
+    frames = sc.render_batch(0, n_frames)
+    TP = pkg("pipeline").TrackingPipeline
+    pipe = TP(engines[0], engines[1], (540, 960), batch=batch, ring_frames=n_frames, max_persons=16, dtype=dtype, inject=True)
+    pipe.upload(0, frames)
+    pipe.inject(0, [sc.detections(f)[:3] for f in range(n_frames)])
+    tracks, dets = pipe.run(0, n_frames, want_dets=True)
+    torch.set_num_threads(8)
+    ref, embs, otrk = oracle_chain_planted(sc, N.EngineOracle(engines[1]), frames, n_frames)
+    assert_same_tracks(tracks, ref, n_frames)
+    assert any(len(t) for t in ref)
+    emb_err = np.abs(pipe.last_embeddings() - embs[-1]).max()
+    print(f"[{dtype}] 960x540 pipeline: embedding err vs oracle {emb_err:.2e}")
+    assert emb_err < (1e-3 if dtype == "fp32" else 1e-3)
+    a = pipe.tracker_core.export_arrays()
+    assert a["track_id"].tolist() == [t.track_id for t in otrk.tracks] and a["state"].tolist() == [t.state for t in otrk.tracks]
+    # the detector at this geometry (fp32: same kept set as the oracle chain away from near-ties)
+    if dtype == "fp32":
+        eo = N.EngineOracle(engines[0])
+        x, ratios, pad = I.preprocess_yolo_input(frames[3])
+        assert ratios == (640 / 960, 640 / 960) and pad == (0.0, 140.0)
+        dfl, cls = eo.yolo_head(torch.from_numpy(x))
+        rb, rml, rlab = eo.decode(dfl.numpy(), cls.numpy())
+        keep, margin = N.nms(rb[0], rml[0], rlab[0], 0.3, 0.5, 300, return_margin=True)
+        ref_boxes = I.scale_bboxes(rb[0][keep], frames[3].shape[:2], ratios, pad)
+        b, s, l = dets[3]
+        if margin > 5e-3:
+            assert len(b) == len(keep) and np.array_equal(l, rlab[0][keep])
+            assert np.abs(b - ref_boxes).max() < 1.5e-2                          # 1e-3-class letterbox px / ratio 2/3, see test_gpu_nets
+    pipe.close()
+
+
+# ------------------------------------------------------------------------------------------- configs[2]
+@pytest.fixture(scope="module")
+def scene_1080():
+    return syn.Scene(seed=2, n_targets=100, width=1920, height=1080, w_range=(30.0, 60.0), h_range=(90.0, 150.0), y_range=(50.0, 850.0))
+
+
+@pytest.mark.parametrize("dtype,tol_logit,tol_box", [("fp32", 1e-3, None), ("fp16", 0.12, 6.0)])
+def test_yolov8m_head_decode_nms(gpu, engines_m, scene_1080, dtype, tol_logit, tol_box):
+    """YOLOv8m (83 convs, Cout 48/96/192/384/576 tile dispatch) on a letterboxed 1920x1080 frame: raw head, decode and the
+    integer NMS outcome against the nets oracle; fp32 boxes anchored on the fp64 evaluation of the same engine file."""
+    frame = scene_1080.render(0)
+    x, ratios, pad = I.preprocess_yolo_input(frame)
+    assert abs(ratios[0] - 1 / 3) < 1e-7 and pad == (0.0, 140.0)
+    torch.set_num_threads(8)
+    eo = N.EngineOracle(engines_m[0])
+    dfl_ref, cls_ref = (t.numpy() for t in eo.yolo_head(torch.from_numpy(x)))
+    eng = HipEngine(engines_m[0], dtype=dtype, max_items=2, warm_up=False)
+    assert (eng.n_anchors, eng.out_dim, eng.n_convs) == (8400, 80, 83) and abs(eng.flops_per_item / 1e9 - 78.94) < 0.01
+    dfl, cls = eng.yolo_head_np(x)
+    e_d, e_c = np.abs(dfl - dfl_ref).max(), np.abs(cls - cls_ref).max()
+    boxes, ml, lab = eng.yolo_decode_np(x)
+    rb, rml, rlab = eo.decode(dfl_ref, cls_ref)
+    e_b = np.abs(boxes - rb).max()
+    print(f"[YOLOv8m {dtype}] max |dfl logit err| {e_d:.2e}  |cls logit err| {e_c:.2e}  |box err| {e_b:.2e} px")
+    assert e_d < tol_logit and e_c < tol_logit
+    if dtype == "fp32":
+        eo64 = N.EngineOracle(engines_m[0], dtype=torch.float64)
+        d64, c64 = (t.numpy() for t in eo64.yolo_head(torch.from_numpy(x)))
+        b64 = eo64.decode(d64, c64, ft=np.float64)[0]
+        e_hip, e_cpu = np.abs(boxes - b64).max(), np.abs(rb - b64).max()
+        print(f"[YOLOv8m fp32] box err vs fp64: HIP {e_hip:.2e} px, torch-CPU fp32 {e_cpu:.2e} px")
+        assert e_hip <= max(1e-3, 1.5 * e_cpu)
+    else:
+        assert e_b < tol_box
+    kb, kml, klab = eo.decode(dfl, cls)                      # decode kernel on its own head tensor: kernel-level parity
+    assert np.abs(boxes - kb).max() < 2e-3 and np.array_equal(ml, kml) and np.array_equal(lab, klab)
+    nd, ob, osc, ol = eng.yolo_infer_np(x, conf=0.3, iou=0.5, max_det=300)
+    keep, margin = N.nms(boxes[0], ml[0], lab[0], 0.3, 0.5, 300, return_margin=True)
+    n_cand = int((ml[0] >= N.logit_threshold(0.3)).sum())
+    print(f"[YOLOv8m {dtype}] NMS candidates {n_cand}, kept {len(keep)}")
+    assert nd[0] == len(keep) and np.array_equal(ob[0, :nd[0]], boxes[0][keep]) and np.array_equal(ol[0, :nd[0]], lab[0][keep])
+    assert n_cand > 200
+    eng.close()
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "fp16"])
+def test_configs2_pipeline_ids(gpu, engines_m, scene_1080, dtype):
+    """configs[2]-shaped run: YOLOv8m, 1920x1080, 100 planted persons (ReID groups of 400 crops, 100 x 100 association):
+    track ids, classes and boxes of every frame against the oracle chain."""
+    n_frames, batch = 12, 4
+    sc = scene_1080
+    frames = sc.render_batch(0, n_frames)
+    TP = pkg("pipeline").TrackingPipeline
+    pipe = TP(engines_m[0], engines_m[1], (1080, 1920), batch=batch, ring_frames=n_frames, max_persons=104, dtype=dtype, inject=True)
+    pipe.upload(0, frames)
+    pipe.inject(0, [sc.detections(f)[:3] for f in range(n_frames)])
+    tracks, nd = pipe.run(0, n_frames)
+    assert (nd > 0).all()
+    torch.set_num_threads(16)
+    ref, embs, otrk = oracle_chain_planted(sc, N.EngineOracle(engines_m[1]), frames, n_frames)
+    assert_same_tracks(tracks, ref, n_frames)
+    assert len(ref[-1]) >= 90
+    emb_err = np.abs(pipe.last_embeddings() - embs[-1]).max()
+    print(f"[{dtype}] configs[2] pipeline: {len(ref[-1])} confirmed tracks, embedding err vs oracle {emb_err:.2e}")
+    assert emb_err < 1e-3
+    a = pipe.tracker_core.export_arrays()
+    assert a["track_id"].tolist() == [t.track_id for t in otrk.tracks] and a["state"].tolist() == [t.state for t in otrk.tracks]
+    assert np.abs(a["mean"] - np.stack([t.mean for t in otrk.tracks])).max() < 1e-3 * (1 if dtype == "fp32" else 50)
+    pipe.close()
+
+
+# ------------------------------------------------------------------------------------------- configs[1], bench kernel mix
+def test_bench_shaped_group_fp16(gpu, engines):
+    """bench.py's launch shape: ONE full 512-frame group = 15 360 crops through the persistent / ping-pong / fused-block
+    conv kernels that only engage at that size (dispatch depends on M).  Oracle checks: ReID embeddings of the first,
+    middle and last frame against the fp32 nets oracle; the detector's NMS outcome on those frames against the oracle NMS
+    of the kernel's own decode; track ids of ALL 512 frames against the DeepSORT oracle fed the same embeddings."""
+    n_frames = 512
+    sc = syn.Scene(seed=0, n_targets=30)
+    frames = sc.render_batch(0, n_frames)
+    TP = pkg("pipeline").TrackingPipeline
+    pipe = TP(engines[0], engines[1], (720, 1280), batch=n_frames, ring_frames=n_frames, max_persons=32, dtype="fp16", inject=True)
+    pipe.option("taper", 0)                                     # one full group, as in the bench's steady state
+    pipe.upload(0, frames)
+    dets = [sc.detections(f) for f in range(n_frames)]
+    pipe.inject(0, [d[:3] for d in dets])
+    tracks, det_out = pipe.run(0, n_frames, want_dets=True)
+    emb, per = pipe.group_embeddings()
+    assert per.tolist() == [30] * n_frames and emb.shape == (15360, 512)
+    assert np.allclose(np.linalg.norm(emb, axis=1), 1, atol=1e-3)
+    torch.set_num_threads(16)
+    eo = N.EngineOracle(engines[1])
+    worst = 0.0
+    for f in (0, 255, 511):
+        ref, valid = reid_oracle_embeddings(eo, frames[f], dets[f][0])
+        assert valid.all()
+        worst = max(worst, float(np.abs(emb[30 * f:30 * f + 30] - ref).max()))
+    print(f"512-frame group: fp16 embedding err vs fp32 oracle on frames 0/255/511: {worst:.2e}")
+    assert worst < 1e-3
+    # association: DeepSORT oracle on the embeddings the group produced (integer outcome must be identical)
+    trk = O.OracleTracker()
+    for f in range(n_frames):
+        boxes, conf = dets[f][0], dets[f][1]
+        tlwh = np.stack([boxes[:, 0], boxes[:, 1], boxes[:, 2] - boxes[:, 0], boxes[:, 3] - boxes[:, 1]], 1).astype(np.float32)
+        trk.predict()
+        trk.update(list(tlwh), list(conf), ["person"] * 30, list(emb[30 * f:30 * f + 30]))
+        exp = trk.output_tuples()
+        assert [t[4] for t in tracks[f]] == [t[4] for t in exp], f
+        if exp:
+            assert np.abs(np.array([t[:4] for t in tracks[f]]) - np.array([t[:4] for t in exp])).max() <= 1
+    assert len(tracks[-1]) == 30
+    # the detector inside the same group (big-tile YOLO kernels): the four NMS tensors of frames 0 / 511 are those the
+    # small-batch engine gives for the same frame up to fp16 rounding of intermediate tensors
+    small = HipEngine(engines[0], dtype="fp16", max_items=2, warm_up=False)
+    for f in (0, 511):
+        nd1, b1, s1, l1 = small.detect_np(frames[f])
+        b0, s0, l0 = det_out[f]
+        iou = np.stack([N.box_iou_xyxy(g, b1[0, :nd1[0]]) for g in b0])
+        best = np.where(l0[:, None] == l1[0, None, :nd1[0]], iou, 0).max(1)
+        frac = (best[s0 > 0.35] > 0.9).mean()
+        print(f"frame {f}: 512-frame group {len(b0)} detections vs 1-frame engine {nd1[0]}; {frac:.4f} of the confident ones matched")
+        assert frac > 0.97 and abs(len(b0) - nd1[0]) <= 3
+    small.close()
+    pipe.close()
+
+
+# ------------------------------------------------------------------------------------------- fp16, own detections
+def match_outputs(a, b, thr=0.5):
+    """Greedy IoU matching of two frames' track tuples -> list of (index in a, index in b)."""
+    if not a or not b:
+        return []
+    ba, bb = np.array([t[:4] for t in a], np.float32), np.array([t[:4] for t in b], np.float32)
+    iou = np.stack([N.box_iou_xyxy(x, bb) for x in ba])
+    pairs = []
+    while iou.size and iou.max() > thr:
+        i, j = np.unravel_index(int(iou.argmax()), iou.shape)
+        pairs.append((int(i), int(j)))
+        iou[i, :] = 0
+        iou[:, j] = 0
+    return pairs
+
+
+def test_fp16_own_detections_vs_fp32_oracle_chain(gpu, engines):
+    """inject=0 in fp16 (the mode the bench runs): the detector's own boxes feed crop/ReID/association for 320 frames.
+    Against the fp32 ORACLE chain (letterbox -> torch fp32 YOLO -> NMS -> scale_bboxes -> filter -> crops -> torch fp32
+    ReID -> DeepSORT oracle) on the same frames: max box / score deviation of matched detections, the fraction of the
+    oracle's confirmed track outputs the fp16 chain reproduces, and the number of ID switches (a matched oracle track
+    changing its fp16 partner id).  Seeded heads fire on background texture, so near-threshold detections differ
+    between the two precisions; the bound is on what those differences do to the tracks."""
+    n_frames, batch = 320, 32
+    sc = syn.Scene(seed=12, n_targets=20)
+    frames = sc.render_batch(0, n_frames)
+    old = set(config.CLASSES_TO_TRACK)
+    config.CLASSES_TO_TRACK.clear()
+    config.CLASSES_TO_TRACK.update(config.CLASSES)         # seeded heads fire on arbitrary classes: track all of them
+    try:
+        torch.set_num_threads(16)
+        yo, ro = N.EngineOracle(engines[0]), N.EngineOracle(engines[1])
+
+        def oracle_detect(frame):
+            x, ratios, pad = I.preprocess_yolo_input(frame)
+            dfl, cls = yo.yolo_head(torch.from_numpy(x))
+            b, ml, lab = yo.decode(dfl.numpy(), cls.numpy())
+            keep = N.nms(b[0], ml[0], lab[0], 0.3, 0.5, 300)
+            return I.scale_bboxes(b[0][keep], frame.shape[:2], ratios, pad), N.sigmoid32(ml[0][keep]), lab[0][keep]
+
+        # tracker confidence floor: keeps ~12 detections of frame 0 (bounded CPU work for the oracle ReID), same value on both sides
+        s0 = np.sort(oracle_detect(frames[0])[1])[::-1]
+        min_conf = float((s0[11] + s0[12]) / 2)
+        TP = pkg("pipeline").TrackingPipeline
+        pipe = TP(engines[0], engines[1], (720, 1280), batch=batch, ring_frames=n_frames, max_persons=64, dtype="fp16", inject=False,
+                  min_confidence=min_conf, max_tracks=1024)
+        pipe.upload(0, frames)
+        tracks, dets = pipe.run(0, n_frames, want_dets=True)
+        trk = O.OracleTracker()
+        id_map, switches, n_ref, n_hit, n_hip = {}, 0, 0, 0, 0
+        box_dev, score_dev, det_frac = 0.0, 0.0, []
+        for f in range(n_frames):
+            ob, osc, ol = oracle_detect(frames[f])
+            keep = [i for i in range(len(ob)) if osc[i] >= min_conf]
+            b, c = ob[keep], osc[keep]
+            emb, valid = reid_oracle_embeddings(ro, frames[f], b) if len(b) else (np.zeros((0, 512), np.float32), np.zeros(0, bool))
+            tlwh = np.stack([b[:, 0], b[:, 1], b[:, 2] - b[:, 0], b[:, 3] - b[:, 1]], 1).astype(np.float32) if len(b) else np.zeros((0, 4), np.float32)
+            trk.predict()
+            trk.update(list(tlwh), list(c), [config.class_name(int(k)) for k in ol[keep]], [emb[i] if valid[i] else None for i in range(len(b))])
+            exp = trk.output_tuples()
+            # detections of the two chains on this frame (above the tracker floor)
+            hb, hs, hl = dets[f]
+            hk = hs >= min_conf
+            if len(b) and hk.any():
+                iou = np.stack([N.box_iou_xyxy(x, hb[hk]) for x in b])
+                j = iou.argmax(1)
+                ok = (iou.max(1) > 0.9) & (hl[hk][j] == ol[keep])
+                det_frac.append(ok.mean())
+                if ok.any():
+                    box_dev = max(box_dev, float(np.abs(b[ok] - hb[hk][j[ok]]).max()))
+                    score_dev = max(score_dev, float(np.abs(c[ok] - hs[hk][j[ok]]).max()))
+            # track outputs
+            n_ref += len(exp)
+            n_hip += len(tracks[f])
+            for i, j in match_outputs(exp, tracks[f]):
+                n_hit += 1
+                oid, hid = exp[i][4], tracks[f][j][4]
+                if oid in id_map and id_map[oid] != hid:
+                    switches += 1
+                id_map[oid] = hid
+        print(f"fp16 own-detections chain vs fp32 oracle chain, {n_frames} frames, tracker floor {min_conf:.3f}: "
+              f"{np.mean(det_frac):.4f} of the oracle's detections reproduced (IoU > 0.9, same class), "
+              f"max box dev {box_dev:.2f} px, max score dev {score_dev:.3f}; confirmed track outputs oracle {n_ref} / fp16 {n_hip}, "
+              f"{n_hit} matched ({n_hit / max(n_ref, 1):.4f}), ID switches {switches}")
+        assert n_ref > 300                                      # the chains confirm tracks (static background inside a 16-frame block)
+        assert np.mean(det_frac) > 0.9 and n_hit / n_ref > 0.85
+        assert switches <= max(3, int(0.02 * n_hit))
+        pipe.close()
+    finally:
+        config.CLASSES_TO_TRACK.clear()
+        config.CLASSES_TO_TRACK.update(old)
+
+
+# ------------------------------------------------------------------------------------------- crowded frames
+def test_crowded_frames_nothing_dropped(gpu, engines):
+    """More tracked detections per frame than max_persons and than the ReID arena (deepsort_tracker.py:88-101 passes every
+    detection that survives the filter): the pipeline (grown crop buffers, several ReID launch groups), the per-frame plugin
+    path (ReIDModel with max_batch far below the detection count) and the oracle chain must hold the same tracker state."""
+    n_frames = 4
+    sc = syn.Scene(seed=33, n_targets=8)
+    frames = sc.render_batch(0, n_frames)
+    old = set(config.CLASSES_TO_TRACK)
+    config.CLASSES_TO_TRACK.clear()
+    config.CLASSES_TO_TRACK.update(config.CLASSES)
+    try:
+        det = pkg("detector").YOLODetector(engines[0], dtype="fp32")
+        ds = pkg("deepsort_tracker").DeepSORT(engines[1], dtype="fp32", n_init=2, max_tracks=2048, reid_max_batch=64)
+        plug_state, n_det = [], []
+        for f in range(n_frames):
+            b, s, c, _ = det.detect(frames[f])
+            n_det.append(len(b))
+            out = ds.update(b, s, c, frames[f].copy())
+            plug_state.append((out, ds.tracker_core.export_arrays()))
+        assert min(n_det) > 128                                 # more than max_persons (16), the ReID arena (64) and its old default (128)
+        TP = pkg("pipeline").TrackingPipeline
+        reid = HipEngine(engines[1], dtype="fp32", max_items=100, warm_up=False)
+        pipe = TP(engines[0], reid, (720, 1280), batch=2, ring_frames=4, max_persons=16, dtype="fp32", inject=False, n_init=2, max_tracks=2048)
+        pipe.upload(0, frames)
+        nt, rows, nd = pipe.run_raw(0, n_frames)
+        a = pipe.tracker_core.export_arrays()
+        p = plug_state[-1][1]
+        assert nd.tolist() == n_det
+        assert a["track_id"].tolist() == p["track_id"].tolist() and a["state"].tolist() == p["state"].tolist()
+        assert a["hits"].tolist() == p["hits"].tolist() and np.allclose(a["mean"], p["mean"], atol=1e-4)
+        assert nt.tolist() == [len(s[0]) for s in plug_state] and nt.max() > 16        # true counts, beyond the 16 stored rows
+        cnt = pipe.counters()
+        assert cnt["grown_groups"] >= 1 and cnt["clipped_frames"] == int((nt > 16).sum())
+        for f in range(n_frames):
+            exp = plug_state[f][0][:16]
+            assert [tuple(r[:5]) for r in rows[f][:min(nt[f], 16)].tolist()] == [t[:5] for t in exp]
+        # oracle chain on the first two frames (300 crops each through the fp32 ReID oracle)
+        torch.set_num_threads(16)
+        yo, ro = N.EngineOracle(engines[0]), N.EngineOracle(engines[1])
+        trk = O.OracleTracker(n_init=2)
+        for f in range(2):
+            x, ratios, pad = I.preprocess_yolo_input(frames[f])
+            dfl, cls = yo.yolo_head(torch.from_numpy(x))
+            b, ml, lab = yo.decode(dfl.numpy(), cls.numpy())
+            keep, margin = N.nms(b[0], ml[0], lab[0], 0.3, 0.5, 300, return_margin=True)
+            ob = I.scale_bboxes(b[0][keep], frames[f].shape[:2], ratios, pad)
+            emb, valid = reid_oracle_embeddings(ro, frames[f], ob)
+            tlwh = np.stack([ob[:, 0], ob[:, 1], ob[:, 2] - ob[:, 0], ob[:, 3] - ob[:, 1]], 1).astype(np.float32)
+            trk.predict()
+            trk.update(list(tlwh), list(N.sigmoid32(ml[0][keep])), [config.class_name(int(k)) for k in lab[0][keep]],
+                       [emb[i] if valid[i] else None for i in range(len(ob))])
+            if margin > 5e-3 and len(keep) == n_det[f]:
+                assert [t[4] for t in trk.output_tuples()] == [t[4] for t in plug_state[f][0]], f
+        pipe.close()
+    finally:
+        config.CLASSES_TO_TRACK.clear()
+        config.CLASSES_TO_TRACK.update(old)

@@ -34,6 +34,14 @@ def yolo_ref(engines, frames):
     return eo, x, dfl.numpy(), cls.numpy()
 
 
+@pytest.fixture(scope="module")
+def yolo_ref64(engines, yolo_ref):
+    """The same engine file evaluated in fp64 (torch CPU double): the anchor for the fp32 box bound."""
+    eo64 = N.EngineOracle(engines[0], dtype=torch.float64)
+    d64, c64 = (t.numpy() for t in eo64.yolo_head(torch.from_numpy(yolo_ref[1])))
+    return d64, c64, eo64.decode(d64, c64, ft=np.float64)[0]
+
+
 def test_small_graph_every_op_fp32(gpu, tmp_path):
     """A small engine that exercises every op kind, tile variant and slice/residual mode."""
     g = ef.Graph(ef.KIND_REID, 24, 16)
@@ -69,10 +77,14 @@ def test_small_graph_every_op_fp32(gpu, tmp_path):
         eng.close()
 
 
-# fp32: logits agree to ~4e-5 (different fp32 summation order over K <= 2304); the DFL expectation times the
-# stride (<= 32) turns that into a few 1e-3 px on a 640 px canvas (3.6e-6 relative) -> 5e-3 px bound.
-@pytest.mark.parametrize("dtype,tol_logit,tol_box", [("fp32", 1e-3, 5e-3), ("fp16", 0.25, 8.0)])
-def test_yolo_head_and_decode(gpu, engines, yolo_ref, dtype, tol_logit, tol_box):
+# fp32 (north_star: box coords within 1e-3): two fp32 evaluations of a 63-conv net differ by their summation order (K <= 2304
+# per conv: MFMA 16x16x4 chains here, MKL-DNN blocking in torch); the DFL expectation times the stride (<= 32) amplifies a
+# ~4e-5 logit difference to a few 1e-3 px on the stride-32 level.  Neither side is "the" fp32 result, so both are measured
+# against the fp64 evaluation of the same engine file: the HIP boxes must be within 1e-3 px of it, or at least as close
+# to it as torch's own fp32 evaluation is (x1.25 slack for the max over 67 200 coordinates).  fp16 gates: ~2x the measured
+# deviation (logits 3e-2, boxes 2.3 px).
+@pytest.mark.parametrize("dtype,tol_logit,tol_box", [("fp32", 2e-4, None), ("fp16", 0.08, 5.0)])
+def test_yolo_head_and_decode(gpu, engines, yolo_ref, yolo_ref64, dtype, tol_logit, tol_box):
     eo, x, dfl_ref, cls_ref = yolo_ref
     eng = HipEngine(engines[0], dtype=dtype, max_items=2, warm_up=False)
     assert (eng.n_anchors, eng.out_dim, eng.n_convs) == (8400, 80, 63) and abs(eng.flops_per_item - 8.742912e9) < 1e3
@@ -84,7 +96,18 @@ def test_yolo_head_and_decode(gpu, engines, yolo_ref, dtype, tol_logit, tol_box)
     rb, rml, rlab = eo.decode(dfl_ref, cls_ref)
     e_b = np.abs(boxes - rb).max()
     print(f"[{dtype}] max |box err| {e_b:.2e} px")
-    assert e_b < tol_box and np.abs(ml - rml).max() < tol_logit
+    assert np.abs(ml - rml).max() < tol_logit
+    if dtype == "fp32":
+        d64, c64, b64 = yolo_ref64
+        e_hip, e_cpu = np.abs(boxes - b64).max(), np.abs(rb - b64).max()
+        l_hip, l_cpu = max(np.abs(dfl - d64).max(), np.abs(cls - c64).max()), max(np.abs(dfl_ref - d64).max(), np.abs(cls_ref - c64).max())
+        small = np.abs(boxes - b64)[:, eo.anchors()[1] <= 16].max()
+        print(f"[fp32] vs fp64 evaluation: box err HIP {e_hip:.2e} px / torch-CPU fp32 {e_cpu:.2e} px (strides 8+16 only: HIP {small:.2e}); "
+              f"logit err HIP {l_hip:.2e} / torch {l_cpu:.2e}")
+        assert e_hip <= max(1e-3, 1.25 * e_cpu)
+        assert l_hip <= max(5e-5, 1.25 * l_cpu)
+    else:
+        assert e_b < tol_box
     if dtype == "fp32":
         gap = np.sort(cls_ref, -1)[..., -1] - np.sort(cls_ref, -1)[..., -2]
         assert (lab == rlab)[gap > 1e-3].all()                 # labels identical away from arg-max near-ties
@@ -131,7 +154,8 @@ def test_detector_plugin_vs_oracle_fp32(gpu, engines, frames):
         if margin > 5e-3:     # away from threshold near-ties the two chains keep exactly the same anchors
             assert len(boxes) == len(keep)
             assert np.array_equal(cids, rlab[0][keep])
-            assert np.abs(boxes - ref_boxes).max() < 1e-2 / 0.5     # 1e-3-class error in letterbox px, /ratio
+            # two fp32 chains (see test_yolo_head_and_decode: each is within ~2e-3 letterbox px of the fp64 result), / ratio 0.5
+            assert np.abs(boxes - ref_boxes).max() < 5e-3 / 0.5
             assert np.allclose(scores, N.sigmoid32(rml[0][keep]), atol=1e-4)
         else:
             assert abs(len(boxes) - len(keep)) <= 3
@@ -162,7 +186,7 @@ def test_fp16_frames_path_fused_stem(gpu, engines, frames):
     eng.close()
 
 
-@pytest.mark.parametrize("dtype,tol", [("fp32", 1e-3), ("fp16", 3e-2)])
+@pytest.mark.parametrize("dtype,tol", [("fp32", 1e-5), ("fp16", 5e-4)])     # measured 1.4e-7 / 9.8e-5 (north_star: 1e-3)
 def test_reid_embeddings(gpu, engines, frames, dtype, tol):
     sc = syn.Scene(seed=0)
     boxes = sc.detections(0)[0]
@@ -186,7 +210,7 @@ def test_reid_embeddings(gpu, engines, frames, dtype, tol):
 
 
 @pytest.mark.parametrize("n_crops", [960, 950])
-@pytest.mark.parametrize("dtype,tol_split,tol", [("fp32", 2e-5, 1e-3), ("fp16", 3e-3, 3e-2)])
+@pytest.mark.parametrize("dtype,tol_split,tol", [("fp32", 2e-5, 1e-5), ("fp16", 1e-3, 5e-4)])
 def test_reid_large_batch_kernels(gpu, engines, dtype, tol_split, tol, n_crops):
     """The big-tile conv kernels only engage at production batch sizes (ping-pong 256x256 / 512x128 tiles, the
     patch forms, one block per CU, the persistent weights-resident kernel): 960 crops in ONE launch group must give

@@ -48,7 +48,7 @@ def test_pipeline_inject_matches_oracle(gpu, engines, dtype):
     assert (nd > 0).all()                                   # the detector ran on every frame
     emb_err = np.abs(pipe.last_embeddings() - embs[-1]).max()
     print(f"[{dtype}] pipeline embedding err vs oracle {emb_err:.2e}")
-    assert emb_err < (1e-3 if dtype == "fp32" else 3e-2)
+    assert emb_err < (1e-5 if dtype == "fp32" else 5e-4)          # measured 1.4e-7 / 1e-4 (north_star: 1e-3)
     # the pipeline's crop kernel takes its taps with 12-byte loads, the single-frame entry point with byte loads: same bytes,
     # so the embeddings of the last frame's detections must be IDENTICAL
     boxes, conf, cls = sc.detections(n_frames - 1)[:3]

@@ -20,7 +20,7 @@ def test_abi_exports_every_declared_symbol(lib):
     missing = [n for n in sorted(declared) if not hasattr(handle, n)]
     assert not missing, missing
     assert declared == set(lib.EXPORTS), declared ^ set(lib.EXPORTS)
-    assert handle.aic_abi_version() == 1
+    assert handle.aic_abi_version() == 2
 
 
 def test_no_cpu_fallback(lib):
@@ -96,6 +96,25 @@ def test_min_cost_matching_matches_reference_fixtures(lib, golden):
     mt, ut, ud = la.min_cost_matching(lambda *a: cost.copy(), 0.2, None, None, [0, 1, 2], [0, 1, 2])
     assert mt == [(0, 0), (1, 1)] and ut == [2] and ud == [2]
     assert la.min_cost_matching(lambda *a: cost, 0.2, None, None, [], [0, 1]) == ([], [], [0, 1])
+
+
+def test_match_cascade_matches_oracle(lib):
+    """aic_match_cascade (csrc/assoc_host.cpp) vs the oracle cascade on random frames with ties, gated entries, tentative /
+    confirmed / stale tracks and empty sides (linear_assignment.py:91-157, tracker_core.py:83-177)."""
+    from asan_driver import random_frame
+    rng = np.random.default_rng(3)
+    for it in range(300):
+        app, maha, iou, state, tsu = random_frame(rng, it)
+        t, n = app.shape
+        max_age = int(rng.integers(1, 7))
+        mt, md = np.zeros(max(min(t, n), 1), np.int32), np.zeros(max(min(t, n), 1), np.int32)
+        ut, ud = np.zeros(max(t, 1), np.int32), np.zeros(max(n, 1), np.int32)
+        nm, nut, nud = (np.zeros(1, np.int32) for _ in range(3))
+        lib.call("aic_match_cascade", lib.ptr(app), lib.ptr(maha), lib.ptr(iou), t, n, lib.ptr(state), lib.ptr(tsu), 0.2, 0.7, max_age,
+                 lib.ptr(mt), lib.ptr(md), lib.ptr(nm), lib.ptr(ut), lib.ptr(nut), lib.ptr(ud), lib.ptr(nud))
+        em, eut, eud = O.cascade_on_matrices(app, maha, iou, state.tolist(), tsu.tolist(), 0.2, 0.7, max_age)
+        assert list(zip(mt[:nm[0]].tolist(), md[:nm[0]].tolist())) == [(int(a), int(b)) for a, b in em], it
+        assert ut[:nut[0]].tolist() == [int(v) for v in eut] and ud[:nud[0]].tolist() == [int(v) for v in eud], it
 
 
 def test_engine_file_graphs():
