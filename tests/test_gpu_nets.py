@@ -80,10 +80,11 @@ def test_small_graph_every_op_fp32(gpu, tmp_path):
 # fp32 (north_star: box coords within 1e-3): two fp32 evaluations of a 63-conv net differ by their summation order (K <= 2304
 # per conv: MFMA 16x16x4 chains here, MKL-DNN blocking in torch); the DFL expectation times the stride (<= 32) amplifies a
 # ~4e-5 logit difference to a few 1e-3 px on the stride-32 level.  Neither side is "the" fp32 result, so both are measured
-# against the fp64 evaluation of the same engine file: the HIP boxes must be within 1e-3 px of it, or at least as close
-# to it as torch's own fp32 evaluation is (x1.25 slack for the max over 67 200 coordinates).  fp16 gates: ~2x the measured
-# deviation (logits 3e-2, boxes 2.3 px).
-@pytest.mark.parametrize("dtype,tol_logit,tol_box", [("fp32", 2e-4, None), ("fp16", 0.08, 5.0)])
+# against the fp64 evaluation of the same engine file: the HIP boxes must be within 1e-3 px of it (the fp32 MFMA path sums
+# each K-step of 16 products from zero and adds the partial sum to the accumulator -- two-level summation, conv_common.hpp --
+# which lands it at 6.7e-4 px, closer than torch's own fp32 evaluation at 1.5e-3 px).  fp16 gates: ~2x the measured
+# deviation (logits 2.5e-2, boxes 1.7 px).
+@pytest.mark.parametrize("dtype,tol_logit,tol_box", [("fp32", 2e-4, None), ("fp16", 0.06, 4.0)])
 def test_yolo_head_and_decode(gpu, engines, yolo_ref, yolo_ref64, dtype, tol_logit, tol_box):
     eo, x, dfl_ref, cls_ref = yolo_ref
     eng = HipEngine(engines[0], dtype=dtype, max_items=2, warm_up=False)
@@ -104,8 +105,8 @@ def test_yolo_head_and_decode(gpu, engines, yolo_ref, yolo_ref64, dtype, tol_log
         small = np.abs(boxes - b64)[:, eo.anchors()[1] <= 16].max()
         print(f"[fp32] vs fp64 evaluation: box err HIP {e_hip:.2e} px / torch-CPU fp32 {e_cpu:.2e} px (strides 8+16 only: HIP {small:.2e}); "
               f"logit err HIP {l_hip:.2e} / torch {l_cpu:.2e}")
-        assert e_hip <= max(1e-3, 1.25 * e_cpu)
-        assert l_hip <= max(5e-5, 1.25 * l_cpu)
+        assert e_hip <= 1e-3                        # north_star: box coords within 1e-3 (measured 6.7e-4 px; torch-CPU fp32: 1.5e-3)
+        assert l_hip <= max(5e-5, l_cpu)
     else:
         assert e_b < tol_box
     if dtype == "fp32":

@@ -68,37 +68,6 @@ def test_pipeline_inject_matches_oracle(gpu, engines, dtype):
     pipe.close()
 
 
-def test_plugin_path_and_pipeline_detections_fp32(gpu, engines):
-    """inject=0: the detector's own boxes feed ReID + association. Per-frame plugin classes and the
-    batched pipeline must agree with each other exactly, and with the oracle chain on the detections."""
-    n_frames = 6
-    sc = syn.Scene(seed=33, n_targets=8)
-    frames = sc.render_batch(0, n_frames)
-    old = set(config.CLASSES_TO_TRACK)
-    config.CLASSES_TO_TRACK.clear()
-    config.CLASSES_TO_TRACK.update(config.CLASSES)         # seeded heads fire on arbitrary classes: track all of them
-    try:
-        det = pkg("detector").YOLODetector(engines[0], dtype="fp32")
-        ds = pkg("deepsort_tracker").DeepSORT(engines[1], dtype="fp32", n_init=2)
-        plug = []
-        for f in range(n_frames):
-            b, s, c, _ = det.detect(frames[f])
-            b, s, c = b[:24], s[:24], c[:24]
-            plug.append((b, ds.update(b, s, c, frames[f].copy())))
-        TP = pkg("pipeline").TrackingPipeline
-        pipe = TP(engines[0], engines[1], (720, 1280), batch=4, ring_frames=8, max_persons=24, dtype="fp32", inject=False, n_init=2)
-        pipe.upload(0, frames)
-        tracks, dets = pipe.run(0, n_frames, want_dets=True)
-        for f in range(n_frames):
-            assert np.array_equal(dets[f][0][:24], plug[f][0])                       # same detections, same order
-            assert tracks[f] == plug[f][1], (f, tracks[f], plug[f][1])               # same track tuples
-        assert any(len(t) for t in tracks)                                            # something got confirmed
-        assert ds.frame_count == n_frames and ds.update(np.array([]), np.array([]), np.array([]), frames[0]) == []
-    finally:
-        config.CLASSES_TO_TRACK.clear()
-        config.CLASSES_TO_TRACK.update(old)
-
-
 def test_run_from_host_equals_resident_run(gpu, engines):
     """Frames streamed from host memory group by group (pageable, then page-locked) give the very same rows as the
     upload-then-run path (src/aicamera_tracker.py:170 hands over host frames)."""
