@@ -74,6 +74,8 @@ _SIGS = {
     "aic_lsap": (_I, [_P, _I, _I, _P, _P]),
     "aic_min_cost_matching": (_I, [_P, _I, _I, _D, _P, _P, _P]),
     "aic_match_cascade": (_I, [_P, _P, _P, _I, _I, _P, _P, _D, _D, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "aic_match_cascade_device": (_I, [_I, _P, _P, _P, _I, _I, _P, _P, _D, _D, _I, _I, _P]),
+    "aic_tracker_option": (_I, [_P, C.c_char_p, _I]),
     "aic_tracker_create": (_I, [_I, _P, _P]),
     "aic_tracker_destroy": (_I, [_P]),
     "aic_tracker_predict": (_I, [_P]),

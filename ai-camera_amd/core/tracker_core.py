@@ -48,6 +48,10 @@ class TrackerCore:
     def class_name_of(self, cid):
         return self._names[cid] if 0 <= cid < len(self._names) else "Unknown"
 
+    def option(self, key, value):
+        """aic_tracker_option: option("device_assoc", 1) runs cascade / LSAP / lifecycle on the device as well."""
+        L.call("aic_tracker_option", self._h, str(key).encode(), int(value))
+
     def close(self):
         if getattr(self, "_owned", False) and self._h:
             L.call("aic_tracker_destroy", self._h)

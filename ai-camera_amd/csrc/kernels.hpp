@@ -134,5 +134,15 @@ void launch_trk_step(float* mean, float* cov, const int* slots, const int* glen,
                      hipStream_t s);
 void launch_trk_commit(float* mean, float* cov, const int* lists, int M, int U, int A, const float* xyah, float* out_tlwh,
                        float* gal_raw, float* gal_n, int gmax, int dim, const float* feat, const float* feat_n, hipStream_t s);
+// association on the device, k frames per launch (kernels_trk_dev.hip, trk_dev.hpp)
+struct DevTrkHdr; struct DevTrack; struct TrkDevParams; struct EpochDets; struct EpochScratch; struct EpochOut;
+void launch_trk_epoch_prep(const DevTrkHdr* hdr, const DevTrack* trk, const float* gal_n, int gmax, int dim, int cap, const float* featn,
+                           int dn, int dn_pad, int k, float* sm, float* gram, hipStream_t s);
+void launch_trk_epoch(DevTrkHdr* hdr, DevTrack* trk, int* free_slots, float* mean, float* cov, float* gal_raw, float* gal_n,
+                      const TrkDevParams& prm, const EpochDets& dets, int f0, int k, int d_begin, int dn_pad, int nmax, int has_sm,
+                      const EpochScratch& scr, const EpochOut& out, hipStream_t s);
+void launch_trk_cascade_test(const TrkDevParams& prm, const EpochScratch& scr, int T, int n, const int* state, const int* tsu,
+                             int* out_mdet, int* out_err, int stage1_only, hipStream_t s);
+
 
 }  // namespace aic

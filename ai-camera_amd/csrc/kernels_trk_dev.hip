@@ -13,6 +13,8 @@
 #include "trk_dev.hpp"
 #include "trk_math.hpp"
 
+#include <algorithm>
+
 namespace aic {
 
 typedef float floatx4 __attribute__((ext_vector_type(4)));
@@ -144,7 +146,7 @@ namespace {
 
 struct Lds {                        // carved out of the dynamic LDS block by lds_carve()
     // track table (SoA), list order
-    int *id, *state, *hits, *age, *tsu, *cls, *slot, *glen, *ghead, *sm, *napp;
+    int *id, *state, *hits, *age, *tsu, *cls, *slot, *glen, *ghead, *sm, *napp, *glen0;
     float* conf;
     unsigned short* newrow;         // [TMAX][TRK_KMAX] epoch rows appended to the track in this epoch
     int *mdet;                      // [TMAX] matched detection of the frame or -1
@@ -168,7 +170,7 @@ __device__ __forceinline__ Lds lds_carve(char* base, int cap, int nmax, int tota
     char* p = base;
     auto take = [&](size_t bytes) { char* q = p; p += (bytes + 15) & ~(size_t)15; return q; };
     L.u = (double*)take(8 * BT); L.v = (double*)take(8 * BT); L.dist = (double*)take(8 * BT);
-    int** ti[] = {&L.id, &L.state, &L.hits, &L.age, &L.tsu, &L.cls, &L.slot, &L.glen, &L.ghead, &L.sm, &L.napp, &L.mdet, &L.rows,
+    int** ti[] = {&L.id, &L.state, &L.hits, &L.age, &L.tsu, &L.cls, &L.slot, &L.glen, &L.ghead, &L.sm, &L.napp, &L.glen0, &L.mdet, &L.rows,
                   &L.pred, &L.rowof, &L.colof, &L.todo, &L.pos, &L.asg};
     for (auto a : ti) *a = (int*)take(4 * BT);
     L.conf = (float*)take(4 * BT);
@@ -353,11 +355,13 @@ struct EpochArgs {
     int lds_bytes;
 };
 
+namespace {
+
 // min_cost_matching (linear_assignment.py:19-88) of rows[0..nr) x cols[0..nc) on the full matrices of the frame. Block-wide.
 //   stage 1: sub[r][c] = maha > chi2 ? INFTY : app (linear_assignment.py:187-210), threshold max_cos
 //   stage 2: sub[r][c] = iou, threshold max_iou
-// Matched pairs are entered into mdet / mtrk. Returns false on an LSAP failure.
-__device__ bool match_block(const Lds& L, const EpochArgs& a, int nr, int nc, int n, bool stage2, int* err) {
+// Matched pairs are entered into mdet / mtrk. *err != 0 on an LSAP failure.
+__device__ void match_block(const Lds& L, const EpochArgs& a, const int* cols, int nr, int nc, int n, bool stage2, int* err) {
     const float* app = a.scr.cost;
     const float* maha = app + (size_t)TRK_DEV_TMAX * TRK_DEV_NMAX;
     const float* iou = maha + (size_t)TRK_DEV_TMAX * TRK_DEV_NMAX;
@@ -366,33 +370,48 @@ __device__ bool match_block(const Lds& L, const EpochArgs& a, int nr, int nc, in
     float* sub = in_lds ? L.arena : a.scr.sub;
     for (int e = threadIdx.x; e < nr * nc; e += BT) {
         const int r = e / nc, c = e - r * nc;
-        const size_t kk = (size_t)L.rows[r] * n + L.cols[c];
+        const size_t kk = (size_t)L.rows[r] * n + cols[c];
         float x = stage2 ? iou[kk] : (maha[kk] > kChi2_4 ? kInfty : app[kk]);
         if (x > maxd) x = clamp;                                  // linear_assignment.py:58
         sub[e] = x;
     }
-    if (!in_lds) __threadfence_block();
+    __threadfence_block();
     __syncthreads();
     if (threadIdx.x < 64) {
         const bool ok = lsap_wave(sub, nr, nc, L, threadIdx.x);
         if (!ok && threadIdx.x == 0) *err = 2;
     }
     __syncthreads();
-    if (*err) return false;
+    if (*err) return;
     for (int r = threadIdx.x; r < nr; r += BT) {
         const int c = L.asg[r];
         if (c >= 0 && sub[(size_t)r * nc + c] <= maxd) {          // linear_assignment.py:76
-            L.mdet[L.rows[r]] = L.cols[c];
-            L.mtrk[L.cols[c]] = L.rows[r];
+            L.mdet[L.rows[r]] = cols[c];
+            L.mtrk[cols[c]] = L.rows[r];
         }
     }
     __syncthreads();
-    return true;
 }
+
+// track.py:70-74 as a ring: returns the ring position the new row goes to and advances (glen, ghead)
+__device__ __forceinline__ int ring_push(int& glen, int& ghead, int gmax) {
+    int pos;
+    if (glen < gmax) {
+        pos = ghead + glen;
+        if (pos >= gmax) pos -= gmax;
+        glen += 1;
+    } else {
+        pos = ghead;
+        ghead = ghead + 1 == gmax ? 0 : ghead + 1;
+    }
+    return pos;
+}
+
+}  // namespace
 
 __global__ __launch_bounds__(TRK_DEV_TMAX) void trk_epoch_kernel(EpochArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    __shared__ int s_T, s_next_id, s_nfree, s_err, s_nund, s_napp_total;
+    __shared__ int s_err, s_napp_total;
     const Lds L = lds_carve(smem, a.prm.cap, a.nmax, a.lds_bytes);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int gmax = a.prm.gmax, dim = a.prm.dim;
@@ -400,29 +419,27 @@ __global__ __launch_bounds__(TRK_DEV_TMAX) void trk_epoch_kernel(EpochArgs a) {
     float* c_maha = c_app + (size_t)TRK_DEV_TMAX * TRK_DEV_NMAX;
     float* c_iou = c_maha + (size_t)TRK_DEV_TMAX * TRK_DEV_NMAX;
 
-    // ---- load the track table
-    if (tid == 0) { s_T = a.hdr->n_tracks; s_next_id = a.hdr->next_id; s_nfree = a.hdr->n_free; s_err = 0; s_napp_total = 0; }
-    __syncthreads();
-    {
-        const int T = s_T;
-        if (tid < T) {
-            const DevTrack t = a.trk[tid];
-            L.id[tid] = t.id, L.state[tid] = t.state, L.hits[tid] = t.hits, L.age[tid] = t.age, L.tsu[tid] = t.tsu, L.cls[tid] = t.cls;
-            L.conf[tid] = t.conf, L.slot[tid] = t.slot, L.glen[tid] = t.glen, L.ghead[tid] = t.ghead;
-            L.sm[tid] = a.has_sm ? tid : -1;                      // row of the epoch's suffix-minimum table
-            L.napp[tid] = 0;
-        }
-        for (int i = tid; i < s_nfree; i += BT) L.free_slots[i] = a.free_slots[i];
+    // ---- load the track table (uniform copies of the scalars in registers)
+    int T = a.hdr->n_tracks, next_id = a.hdr->next_id, nfree = a.hdr->n_free;
+    if (tid == 0) { s_err = 0; s_napp_total = 0; if (a.out.dbg_match) a.out.dbg_match[0] = 0; }
+    if (tid < T) {
+        const DevTrack t = a.trk[tid];
+        L.id[tid] = t.id, L.state[tid] = t.state, L.hits[tid] = t.hits, L.age[tid] = t.age, L.tsu[tid] = t.tsu, L.cls[tid] = t.cls;
+        L.conf[tid] = t.conf, L.slot[tid] = t.slot, L.glen[tid] = t.glen, L.ghead[tid] = t.ghead, L.glen0[tid] = t.glen;
+        L.sm[tid] = a.has_sm ? tid : -1;                          // row of the epoch's suffix-minimum table
+        L.napp[tid] = 0;
     }
+    for (int i = tid; i < nfree; i += BT) L.free_slots[i] = a.free_slots[i];
     __syncthreads();
 
-    int fi = 0;
+    int fi = 0, err_frame = -1;
     for (; fi < a.k; ++fi) {
         const int f = a.f0 + fi;
         const int n = a.dets.frame_n[f], d0 = a.dets.frame_d0[f];
         const int erow0 = d0 - a.d_begin;                        // first epoch row of this frame
-        const int T = s_T;
-        if (n > a.nmax || n > TRK_DEV_NMAX) { if (tid == 0) s_err = 3; }
+        if (n > a.nmax || n > TRK_DEV_NMAX || erow0 + n > a.dn_pad) { if (tid == 0) s_err = 3; }
+        __syncthreads();
+        if (s_err) { err_frame = f; break; }
         // ---- detections of the frame -> LDS (detection.py:36-47 for xyah); Kalman predict of every track (tracker_core.py:44-49)
         if (tid < n) {
             const floatx4 b = *reinterpret_cast<const floatx4*>(a.dets.tlwh + (size_t)(d0 + tid) * 4);
@@ -444,10 +461,9 @@ __global__ __launch_bounds__(TRK_DEV_TMAX) void trk_epoch_kernel(EpochArgs a) {
         }
         __threadfence_block();
         __syncthreads();
-        if (s_err) break;
 
         // ---- cost rows of every track: squared Mahalanobis (kalman_filter.py:206-249), 1 - IoU (matching.py:13-106),
-        //      min-over-gallery cosine distance (matching.py:144-217) from the epoch's SM / GRAM tables
+        //      min-over-gallery cosine distance (matching.py:144-217) out of the epoch's SM / GRAM tables
         if (T > 0 && n > 0) {
             for (int t = wv; t < T; t += NW) {
                 const int slot = L.slot[t];
@@ -461,9 +477,12 @@ __global__ __launch_bounds__(TRK_DEV_TMAX) void trk_epoch_kernel(EpochArgs a) {
                 if (bh > 0.f) bw = m2 * bh; else bh = fmaxf(0.f, bh);
                 const float bx = m0 - bw / 2.0f, by = m1 - bh / 2.0f;
                 const float brx = bx + bw, bry = by + bh;
-                // gallery state of the track inside the epoch
-                const int glen = L.glen[t], napp = L.napp[t], smr = L.sm[t];
-                const int glen0 = glen - napp + 0;                 // rows before the epoch ... (evictions restore below)
+                // gallery of the track inside the epoch: rows older than the epoch that survived `ev` evictions (suffix minimum
+                // SM[ev]) + the rows the epoch appended (never evicted inside it: k <= gmax)
+                const int glen = L.glen[t], napp = L.napp[t], smr = L.sm[t], g0 = L.glen0[t];
+                const int ev = max(0, g0 + napp - gmax);
+                const float* smrow = (smr >= 0 && ev < g0) ? a.scr.sm + ((size_t)smr * (TRK_KMAX + 1) + ev) * a.dn_pad : nullptr;
+                const unsigned short* nr_ = L.newrow + t * TRK_KMAX;
                 for (int j = lane; j < n; j += 64) {
                     const float* z = L.xyah + j * 4;
                     float d[4], y[4];
@@ -484,28 +503,274 @@ __global__ __launch_bounds__(TRK_DEV_TMAX) void trk_epoch_kernel(EpochArgs a) {
                     c_iou[o] = 1.0f - inter / fmaxf(uni, 1e-7f);
                     float v = kInfty;                              // empty gallery / featureless detection (matching.py:148,175)
                     if (glen > 0 && L.dhas[j]) {
-                        float mn = kBig;
                         const int erow = erow0 + j;
-                        if (smr >= 0) {                            // rows older than the epoch, after L.tsu-independent evictions
-                            const int ev = L.ghead[t];             // (placeholder, replaced below)
-                            (void)ev;
-                        }
-                        // old rows: evictions so far in this epoch = rows appended beyond the budget
-                        if (smr >= 0) {
-                            const int g0 = glen0 < 0 ? 0 : glen0;
-                            (void)g0;
-                        }
-                        mn = fminf(mn, kBig);
+                        float mn = smrow ? smrow[erow] : kBig;
+                        for (int q = 0; q < napp; ++q) mn = fminf(mn, a.scr.gram[(size_t)nr_[q] * a.dn_pad + erow]);
                         v = mn;
-                        (void)erow;
                     }
                     c_app[o] = v;
                 }
             }
         }
+        __threadfence_block();
         __syncthreads();
-        break;   // placeholder: replaced by the complete frame loop below
+
+        // ---- matching cascade over time_since_update = 1 .. max_age (linear_assignment.py:91-157)
+        int nund = n;
+        if (T > 0 && n > 0) {
+            int cur = 0;
+            for (;;) {
+                if (nund == 0) break;
+                const bool conf_t = tid < T && L.state[tid] == 2;
+                const int tv = (conf_t && L.tsu[tid] > cur && L.tsu[tid] <= a.prm.max_age) ? L.tsu[tid] : 0x7fffffff;
+                const int lv = block_min_int(tv, L.wcnt);
+                if (lv == 0x7fffffff) break;
+                cur = lv;
+                const int nr = block_compact(conf_t && L.tsu[tid] == lv, tid, L.rows, L.wcnt);
+                match_block(L, a, L.und, nr, nund, n, false, &s_err);
+                if (s_err) break;
+                const int dj = tid < nund ? L.und[tid] : -1;
+                nund = block_compact(dj >= 0 && L.mtrk[dj] < 0, dj, L.und, L.wcnt);
+            }
+            // ---- IoU stage: tentative tracks, then confirmed tracks that missed exactly this frame (tracker_core.py:138-166)
+            if (!s_err) {
+                const int n1 = block_compact(tid < T && L.state[tid] == 1, tid, L.rows, L.wcnt);
+                const int n2 = block_compact(tid < T && L.state[tid] == 2 && L.mdet[tid] < 0 && L.tsu[tid] == 1, tid, L.rows + n1, L.wcnt);
+                if (n1 + n2 > 0 && nund > 0) match_block(L, a, L.und, n1 + n2, nund, n, true, &s_err);
+            }
+        }
+        __syncthreads();
+        if (s_err) { err_frame = f; break; }
+
+        // ---- lifecycle (tracker_core.py:63-81): unmatched detections in ascending order become new tracks
+        const int U = block_compact(tid < n && L.mtrk[tid] < 0, tid, L.cols, L.wcnt);
+        if (nfree < U || T + U > BT) { if (tid == 0) s_err = 1; }
+        __syncthreads();
+        if (s_err) { err_frame = f; break; }
+        if (tid < T) {
+            const int det = L.mdet[tid];
+            if (det >= 0) {                                        // Track.update, track.py:82-104
+                if (L.dhas[det]) {
+                    int gl = L.glen[tid], gh = L.ghead[tid];
+                    const int pos = ring_push(gl, gh, gmax);
+                    L.glen[tid] = gl, L.ghead[tid] = gh;
+                    const int na = L.napp[tid];
+                    L.newrow[tid * TRK_KMAX + na] = (unsigned short)(erow0 + det);
+                    L.napp[tid] = na + 1;
+                    const int ai = atomicAdd(&s_napp_total, 1);
+                    a.scr.appends[ai * 3] = L.slot[tid], a.scr.appends[ai * 3 + 1] = pos, a.scr.appends[ai * 3 + 2] = erow0 + det;
+                }
+                L.hits[tid] += 1;
+                L.tsu[tid] = 0;
+                L.conf[tid] = L.dconf[det];
+                L.cls[tid] = L.dcls[det];
+                if (L.state[tid] == 1 && L.hits[tid] >= a.prm.n_init) L.state[tid] = 2;
+                if (a.out.dbg_match && fi == a.k - 1) {
+                    const int mi = atomicAdd(&a.out.dbg_match[0], 1);
+                    a.out.dbg_match[1 + 2 * mi] = L.id[tid], a.out.dbg_match[2 + 2 * mi] = det;
+                }
+            } else {                                               // Track.mark_missed, track.py:106-119
+                if (L.state[tid] == 1) L.state[tid] = 3;
+                else if (L.state[tid] == 2 && L.tsu[tid] > a.prm.max_age) L.state[tid] = 3;
+            }
+        }
+        for (int t = wv; t < T; t += NW) {                         // Kalman update of the matched tracks + their new tlwh (track.py:133-151)
+            const int det = L.mdet[t];
+            if (det < 0) continue;
+            const int slot = L.slot[t];
+            const float mi = kf_update_wave(a.cov + (size_t)slot * 64, a.mean + (size_t)slot * 8, L.xyah + det * 4, lane);
+            const float cx = __shfl(mi, 0), cy = __shfl(mi, 8), ar = __shfl(mi, 16), hh = __shfl(mi, 24);
+            if (lane == 0) {
+                float w = 0.f, h2 = hh;
+                if (hh > 0.f) w = ar * hh; else h2 = fmaxf(0.f, hh);
+                float* o = L.tbox + t * 4;
+                o[0] = cx - w / 2.0f; o[1] = cy - h2 / 2.0f; o[2] = w; o[3] = h2;
+            }
+        }
+        for (int r = wv; r < U; r += NW) {                         // _initiate_track, tracker_core.py:180-194
+            const int det = L.cols[r];
+            const int slot = L.free_slots[nfree - 1 - r];
+            kf_initiate_wave(a.cov + (size_t)slot * 64, a.mean + (size_t)slot * 8, L.xyah + det * 4, lane);
+            if (lane == 0) {
+                const int ti = T + r;
+                L.id[ti] = next_id + r, L.state[ti] = 1, L.hits[ti] = 1, L.age[ti] = 1, L.tsu[ti] = 0;
+                L.cls[ti] = L.dcls[det], L.conf[ti] = L.dconf[det], L.slot[ti] = slot;
+                L.sm[ti] = -1, L.glen0[ti] = 0, L.mdet[ti] = -1;
+                int gl = 0, gh = 0, na = 0;
+                if (L.dhas[det]) {
+                    const int pos = ring_push(gl, gh, gmax);
+                    L.newrow[ti * TRK_KMAX] = (unsigned short)(erow0 + det);
+                    na = 1;
+                    const int ai = atomicAdd(&s_napp_total, 1);
+                    a.scr.appends[ai * 3] = slot, a.scr.appends[ai * 3 + 1] = pos, a.scr.appends[ai * 3 + 2] = erow0 + det;
+                }
+                L.glen[ti] = gl, L.ghead[ti] = gh, L.napp[ti] = na;
+            }
+        }
+        nfree -= U;
+        next_id += U;
+        if (a.out.dbg_tn && fi == a.k - 1 && tid == 0) { a.out.dbg_tn[0] = T; a.out.dbg_tn[1] = n; }
+        __threadfence_block();
+        __syncthreads();
+
+        // ---- outputs: confirmed tracks updated in this frame, list order (deepsort_tracker.py:126-141)
+        {
+            const int cnt = block_compact(tid < T && L.state[tid] == 2 && L.mdet[tid] >= 0, tid, L.rows, L.wcnt);
+            if (tid == 0) a.out.n_tracks[f] = cnt;
+            if (tid < cnt && tid < a.out.max_rows) {
+                const int t = L.rows[tid];
+                const float* b = L.tbox + t * 4;
+                const float x1 = b[0], y1 = b[1];
+                const float w = b[2] > 0.f ? b[2] : 0.f, h = b[3] > 0.f ? b[3] : 0.f;
+                int* r = a.out.rows + ((size_t)f * a.out.max_rows + tid) * 6;
+                r[0] = (int)rintf(x1), r[1] = (int)rintf(y1), r[2] = (int)rintf(x1 + w), r[3] = (int)rintf(y1 + h);   // round half to even
+                r[4] = L.id[t], r[5] = L.cls[t];
+                a.out.conf[(size_t)f * a.out.max_rows + tid] = L.conf[t];
+            }
+        }
+        // ---- prune deleted tracks (tracker_core.py:75): their slots go back in list order, the table closes up
+        {
+            const int Tn = T + U;
+            const bool dead = tid < Tn && L.state[tid] == 3;
+            const int nd = block_compact(dead, tid < Tn ? L.slot[tid] : 0, L.free_slots + nfree, L.wcnt);
+            nfree += nd;
+            const int Tk = block_compact(tid < Tn && !dead, tid, L.rows, L.wcnt);
+            int e_id = 0, e_state = 0, e_hits = 0, e_age = 0, e_tsu = 0, e_cls = 0, e_slot = 0, e_glen = 0, e_ghead = 0, e_sm = 0, e_napp = 0, e_g0 = 0;
+            float e_conf = 0.f;
+            unsigned short e_new[TRK_KMAX];
+            if (tid < Tk) {
+                const int s = L.rows[tid];
+                e_id = L.id[s], e_state = L.state[s], e_hits = L.hits[s], e_age = L.age[s], e_tsu = L.tsu[s], e_cls = L.cls[s];
+                e_slot = L.slot[s], e_glen = L.glen[s], e_ghead = L.ghead[s], e_sm = L.sm[s], e_napp = L.napp[s], e_g0 = L.glen0[s];
+                e_conf = L.conf[s];
+#pragma unroll
+                for (int q = 0; q < TRK_KMAX; ++q) e_new[q] = L.newrow[s * TRK_KMAX + q];
+            }
+            __syncthreads();
+            if (tid < Tk) {
+                L.id[tid] = e_id, L.state[tid] = e_state, L.hits[tid] = e_hits, L.age[tid] = e_age, L.tsu[tid] = e_tsu, L.cls[tid] = e_cls;
+                L.slot[tid] = e_slot, L.glen[tid] = e_glen, L.ghead[tid] = e_ghead, L.sm[tid] = e_sm, L.napp[tid] = e_napp, L.glen0[tid] = e_g0;
+                L.conf[tid] = e_conf;
+#pragma unroll
+                for (int q = 0; q < TRK_KMAX; ++q) L.newrow[tid * TRK_KMAX + q] = e_new[q];
+            }
+            T = Tk;
+            __syncthreads();
+        }
     }
+
+    // ---- gallery rows appended in this epoch: raw row (export) + unit row (cost kernels), one ring position each
+    __syncthreads();
+    {
+        const int na = s_napp_total;
+        const float* fr = a.dets.feat + (size_t)a.d_begin * dim;
+        const float* fn = a.dets.feat_n + (size_t)a.d_begin * dim;
+        for (int i = wv; i < na; i += NW) {
+            const int slot = a.scr.appends[i * 3], pos = a.scr.appends[i * 3 + 1], er = a.scr.appends[i * 3 + 2];
+            const size_t dst = ((size_t)slot * gmax + pos) * dim, src = (size_t)er * dim;
+            for (int c = lane; c < dim; c += 64) {
+                a.gal_raw[dst + c] = fr[src + c];
+                a.gal_n[dst + c] = fn[src + c];
+            }
+        }
+    }
+    // ---- write the table back
+    if (tid < T) {
+        DevTrack t;
+        t.id = L.id[tid], t.state = L.state[tid], t.hits = L.hits[tid], t.age = L.age[tid], t.tsu = L.tsu[tid], t.cls = L.cls[tid];
+        t.conf = L.conf[tid], t.slot = L.slot[tid], t.glen = L.glen[tid], t.ghead = L.ghead[tid], t.pad[0] = 0, t.pad[1] = 0;
+        a.trk[tid] = t;
+    }
+    for (int i = tid; i < nfree; i += BT) a.free_slots[i] = L.free_slots[i];
+    if (tid == 0) {
+        a.hdr->n_tracks = T, a.hdr->next_id = next_id, a.hdr->n_free = nfree;
+        a.hdr->err = s_err, a.hdr->err_frame = err_frame, a.hdr->frames_done = fi;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ test entry: cascade on given matrices
+// aic_match_cascade_device: the device cascade + LSAP on caller-provided cost matrices of ONE frame (parity tests against
+// csrc/assoc_host.cpp, SciPy and tests/golden/assign.npz).  One block; matrices in global memory at scr.cost.
+__global__ __launch_bounds__(TRK_DEV_TMAX) void trk_cascade_test_kernel(EpochArgs a, int T, int n, const int* state, const int* tsu,
+                                                                        int* out_mdet, int* out_err, int lds_bytes, int stage1_only) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ int s_err;
+    const Lds L = lds_carve(smem, a.prm.cap, a.nmax, lds_bytes);
+    const int tid = threadIdx.x;
+    if (tid == 0) s_err = 0;
+    if (tid < T) { L.state[tid] = state[tid]; L.tsu[tid] = tsu[tid]; L.mdet[tid] = -1; }
+    if (tid < n) { L.mtrk[tid] = -1; L.und[tid] = tid; }
+    __syncthreads();
+    int nund = n;
+    if (T > 0 && n > 0) {
+        int cur = 0;
+        for (;;) {
+            if (nund == 0) break;
+            const bool conf_t = tid < T && L.state[tid] == 2;
+            const int tv = (conf_t && L.tsu[tid] > cur && L.tsu[tid] <= a.prm.max_age) ? L.tsu[tid] : 0x7fffffff;
+            const int lv = block_min_int(tv, L.wcnt);
+            if (lv == 0x7fffffff) break;
+            cur = lv;
+            const int nr = block_compact(conf_t && L.tsu[tid] == lv, tid, L.rows, L.wcnt);
+            match_block(L, a, L.und, nr, nund, n, false, &s_err);
+            if (s_err) break;
+            const int dj = tid < nund ? L.und[tid] : -1;
+            nund = block_compact(dj >= 0 && L.mtrk[dj] < 0, dj, L.und, L.wcnt);
+        }
+        if (!s_err && !stage1_only) {
+            const int n1 = block_compact(tid < T && L.state[tid] == 1, tid, L.rows, L.wcnt);
+            const int n2 = block_compact(tid < T && L.state[tid] == 2 && L.mdet[tid] < 0 && L.tsu[tid] == 1, tid, L.rows + n1, L.wcnt);
+            if (n1 + n2 > 0 && nund > 0) match_block(L, a, L.und, n1 + n2, nund, n, true, &s_err);
+        }
+    }
+    __syncthreads();
+    if (tid < T) out_mdet[tid] = L.mdet[tid];
+    if (tid == 0) *out_err = s_err;
+}
+
+// ------------------------------------------------------------------------------------------------ launchers
+static int epoch_lds_bytes() { return 152 * 1024; }
+
+void launch_trk_epoch_prep(const DevTrkHdr* hdr, const DevTrack* trk, const float* gal_n, int gmax, int dim, int cap, const float* featn,
+                           int dn, int dn_pad, int k, float* sm, float* gram, hipStream_t s) {
+    if (dn <= 0) return;
+    const long tasks = ((long)cap + dn_pad / 16) * (dn_pad / 32);
+    const int grid = (int)std::min<long>(512, (tasks + 3) / 4);
+    hipLaunchKernelGGL(trk_epoch_prep_kernel, dim3(grid), dim3(256), 0, s, hdr, trk, gal_n, gmax, dim, featn, dn, dn_pad, k, sm, gram);
+    KCHECK();
+}
+
+static void epoch_attr() {
+    static bool done = false;
+    if (!done) {
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(trk_epoch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, epoch_lds_bytes()));
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(trk_cascade_test_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, epoch_lds_bytes()));
+        done = true;
+    }
+}
+
+void launch_trk_epoch(DevTrkHdr* hdr, DevTrack* trk, int* free_slots, float* mean, float* cov, float* gal_raw, float* gal_n,
+                      const TrkDevParams& prm, const EpochDets& dets, int f0, int k, int d_begin, int dn_pad, int nmax, int has_sm,
+                      const EpochScratch& scr, const EpochOut& out, hipStream_t s) {
+    AIC_REQUIRE(prm.cap <= TRK_DEV_TMAX && nmax <= TRK_DEV_NMAX && k >= 1 && k <= TRK_KMAX, AIC_ERR_CAPACITY, "device association: shape beyond the epoch kernel");
+    epoch_attr();
+    EpochArgs a;
+    a.hdr = hdr, a.trk = trk, a.free_slots = free_slots, a.mean = mean, a.cov = cov, a.gal_raw = gal_raw, a.gal_n = gal_n;
+    a.prm = prm, a.dets = dets, a.f0 = f0, a.k = k, a.d_begin = d_begin, a.dn_pad = dn_pad, a.nmax = std::max(nmax, 1), a.has_sm = has_sm;
+    a.scr = scr, a.out = out, a.lds_bytes = epoch_lds_bytes();
+    hipLaunchKernelGGL(trk_epoch_kernel, dim3(1), dim3(TRK_DEV_TMAX), (size_t)epoch_lds_bytes(), s, a);
+    KCHECK();
+}
+
+void launch_trk_cascade_test(const TrkDevParams& prm, const EpochScratch& scr, int T, int n, const int* state, const int* tsu,
+                             int* out_mdet, int* out_err, int stage1_only, hipStream_t s) {
+    AIC_REQUIRE(T <= TRK_DEV_TMAX && n <= TRK_DEV_NMAX, AIC_ERR_CAPACITY, "device cascade: at most 512 tracks x 512 detections");
+    epoch_attr();
+    EpochArgs a{};
+    a.prm = prm, a.scr = scr, a.nmax = std::max(n, 1), a.lds_bytes = epoch_lds_bytes();
+    hipLaunchKernelGGL(trk_cascade_test_kernel, dim3(1), dim3(TRK_DEV_TMAX), (size_t)epoch_lds_bytes(), s, a, T, n, state, tsu, out_mdet, out_err,
+                       epoch_lds_bytes(), stage1_only);
+    KCHECK();
 }
 
 }  // namespace aic

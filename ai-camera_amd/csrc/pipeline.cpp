@@ -37,6 +37,10 @@ struct Chunk {
     PinBuf<int> h_frame_of, h_valid;
     DevBuf<float> d_boxes, d_emb, d_emb_n;
     DevBuf<int> d_frame_of, d_valid;
+    // association on the device: per-crop detection arrays + per-frame counts of the group, and the group's output rows
+    PinBuf<char> h_meta, h_out;
+    DevBuf<char> d_meta, d_out;
+    size_t m_n = 0, m_d0 = 0, m_tlwh = 0, m_conf = 0, m_cls = 0, m_bytes = 0;   // offsets into h_meta / d_meta
     PinBuf<int> h_numdets, h_labels;
     PinBuf<float> h_detboxes, h_scores;
     std::vector<FrameDets> dets;
@@ -64,6 +68,7 @@ struct Pipeline {
     // host-side wall time (seconds): issuing launch groups, waiting for a group, walking frames through the tracker
     double t_issue = 0, t_wait = 0, t_track = 0;
     long n_frames_done = 0;
+    bool dev_assoc = getenv("AICAM_TRK_HOST") == nullptr;   // association on the device, k frames per launch (aic_pipeline_option("device_assoc"))
     bool taper = getenv("AICAM_NO_TAPER") == nullptr;   // aic_pipeline_option("taper")
     int last_chunk = -1;             // chunk context of the most recently finished launch group (aic_pipeline_group_embeddings)
     long n_grow = 0;                 // launch groups whose crop count outgrew the buffers sized from max_persons
@@ -199,6 +204,26 @@ struct Pipeline {
                 c.h_frame_of.p[fd.crop0 + i] = f;
             }
         }
+        const bool dev_mode = dev_assoc && trk.dev_capable();
+        if (dev_mode) {   // what the epoch kernels read: frame_n[frames] | frame_d0[frames] | tlwh[nc,4] | conf[nc] | cls[nc]
+            c.m_n = 0, c.m_d0 = (size_t)frames * 4, c.m_tlwh = (((size_t)frames * 8 + 15) / 16) * 16;
+            c.m_conf = c.m_tlwh + (size_t)nc * 16, c.m_cls = c.m_conf + (size_t)nc * 4, c.m_bytes = c.m_cls + (size_t)nc * 4 + 16;
+            if (c.m_bytes > c.h_meta.n) { HIP_CHECK(hipStreamSynchronize(s)); c.h_meta.alloc(c.m_bytes + c.m_bytes / 4), c.d_meta.alloc(c.m_bytes + c.m_bytes / 4); }
+            int* hn = reinterpret_cast<int*>(c.h_meta.p + c.m_n);
+            int* hd = reinterpret_cast<int*>(c.h_meta.p + c.m_d0);
+            float* ht = reinterpret_cast<float*>(c.h_meta.p + c.m_tlwh);
+            float* hc = reinterpret_cast<float*>(c.h_meta.p + c.m_conf);
+            int* hk = reinterpret_cast<int*>(c.h_meta.p + c.m_cls);
+            for (int f = 0; f < frames; ++f) {
+                const FrameDets& fd = c.dets[f];
+                hn[f] = fd.n, hd[f] = fd.crop0;
+                if (fd.n) {
+                    std::copy(fd.tlwh.begin(), fd.tlwh.end(), ht + (size_t)fd.crop0 * 4);
+                    std::copy(fd.conf.begin(), fd.conf.end(), hc + fd.crop0);
+                    std::copy(fd.cls.begin(), fd.cls.end(), hk + fd.crop0);
+                }
+            }
+        }
         // crop + ReID on their own stream: in inject mode they do not depend on the detector, and their CU-filling
         // launches backfill the CUs that YOLO's thin layers (50-400 blocks per launch) leave idle
         hipStream_t sr = split_streams ? dev->s_reid : s;
@@ -222,6 +247,7 @@ struct Pipeline {
             }
             HIP_CHECK(hipMemcpyAsync(c.h_valid.p, c.d_valid.p, (size_t)nc * 4, hipMemcpyDeviceToHost, sr));
         }
+        if (dev_mode) HIP_CHECK(hipMemcpyAsync(c.d_meta.p, c.h_meta.p, c.m_bytes, hipMemcpyHostToDevice, sr));
         if (split_streams) {
             HIP_CHECK(hipEventRecord(c.ev_reid, sr));
             HIP_CHECK(hipStreamWaitEvent(s, c.ev_reid, 0));
@@ -304,6 +330,56 @@ struct Pipeline {
         n_frames_done += c.frames;
     }
 
+    // Stage B with the association on the device: the frames of the group go through the tracker in epochs of k frames, two
+    // launches per epoch on the tracker stream and NO host round trip; the host picks up the group's output rows at the end.
+    void stage_b_device(Chunk& c, int out_base, int32_t* n_tracks, int32_t* tracks6, float* track_conf, int32_t* n_dets,
+                        float* det_boxes, float* det_scores, int32_t* det_labels) {
+        const double t0 = now();
+        hipStream_t s = dev->s_trk;
+        const int mp = prm.max_persons;
+        const size_t o_rows = (((size_t)c.frames * 4 + 15) / 16) * 16, o_conf = o_rows + (size_t)c.frames * mp * 24;
+        const size_t obytes = o_conf + (size_t)c.frames * mp * 4;
+        if (obytes > c.h_out.n) { c.h_out.alloc(obytes), c.d_out.alloc(obytes); }
+        trk.ensure_dim(dim);
+        HIP_CHECK(hipStreamWaitEvent(s, c.done, 0));           // the group's embeddings, crop validity and detection arrays are in HBM
+        EpochDets dets{reinterpret_cast<const int*>(c.d_meta.p + c.m_n), reinterpret_cast<const int*>(c.d_meta.p + c.m_d0),
+                       reinterpret_cast<const float*>(c.d_meta.p + c.m_tlwh), reinterpret_cast<const float*>(c.d_meta.p + c.m_conf),
+                       reinterpret_cast<const int*>(c.d_meta.p + c.m_cls), c.d_valid.p, c.d_emb.p, c.d_emb_n.p};
+        EpochOut out{reinterpret_cast<int*>(c.d_out.p), reinterpret_cast<int*>(c.d_out.p + o_rows), reinterpret_cast<float*>(c.d_out.p + o_conf),
+                     mp, nullptr, nullptr};
+        trk.run_epochs(dets, reinterpret_cast<const int*>(c.h_meta.p + c.m_n), reinterpret_cast<const int*>(c.h_meta.p + c.m_d0), c.frames, out, s);
+        HIP_CHECK(hipMemcpyAsync(c.h_out.p, c.d_out.p, obytes, hipMemcpyDeviceToHost, s));
+        const double t1 = now();
+        t_track += t1 - t0;                                    // host time of the association: planning + launches
+        HIP_CHECK(hipStreamSynchronize(s));
+        trk.check_epochs();
+        const double t2 = now();
+        t_wait += t2 - t1;
+        const int* on = reinterpret_cast<const int*>(c.h_out.p);
+        const int* orow = reinterpret_cast<const int*>(c.h_out.p + o_rows);
+        const float* oc = reinterpret_cast<const float*>(c.h_out.p + o_conf);
+        const size_t md = prm.max_det;
+        for (int f = 0; f < c.frames; ++f) {
+            const int o = out_base + f;
+            const int k = std::min(on[f], mp);
+            if (n_tracks) n_tracks[o] = on[f];                 // the true count: rows beyond max_persons are not stored
+            if (on[f] > mp) n_rows_clipped += 1;
+            if (tracks6) std::copy(orow + (size_t)f * mp * 6, orow + ((size_t)f * mp + k) * 6, tracks6 + (size_t)o * mp * 6);
+            if (track_conf) std::copy(oc + (size_t)f * mp, oc + (size_t)f * mp + k, track_conf + (size_t)o * mp);
+            if (n_dets) n_dets[o] = c.h_numdets.p[f];
+            if (det_boxes) std::copy(c.h_detboxes.p + f * md * 4, c.h_detboxes.p + (f + 1) * md * 4, det_boxes + (size_t)o * md * 4);
+            if (det_scores) std::copy(c.h_scores.p + f * md, c.h_scores.p + (f + 1) * md, det_scores + (size_t)o * md);
+            if (det_labels) std::copy(c.h_labels.p + f * md, c.h_labels.p + (f + 1) * md, det_labels + (size_t)o * md);
+        }
+        const FrameDets& fl = c.dets[c.frames - 1];
+        last_emb_n = fl.n;
+        last_emb.resize((size_t)fl.n * dim);
+        if (fl.n) HIP_CHECK(hipMemcpy(last_emb.data(), c.d_emb.p + (size_t)fl.crop0 * dim, last_emb.size() * 4, hipMemcpyDeviceToHost));
+        last_chunk = (int)(&c - &ck[0]);
+        t_track += now() - t2;
+        n_frames_done += c.frames;
+    }
+
     // passes > 1: the same ring range is walked `passes` times back to back as ONE continuous stream (outputs of a
     // later pass overwrite the rows of the earlier one): only the very last group of the call has an un-overlapped tail.
     void run(int slot, int count, int32_t* n_tracks, int32_t* tracks6, float* track_conf, int32_t* n_dets, float* det_boxes,
@@ -367,7 +443,13 @@ struct Pipeline {
                     cv.wait(lk, [&] { return issued > k; });
                     if (perr) break;
                 }
-                stage_b(ck[k % NCK], goff[k], n_tracks, tracks6, track_conf, n_dets, det_boxes, det_scores, det_labels);
+                if (dev_assoc && trk.dev_capable()) {
+                    trk.dev_assoc = true;
+                    stage_b_device(ck[k % NCK], goff[k], n_tracks, tracks6, track_conf, n_dets, det_boxes, det_scores, det_labels);
+                } else {
+                    trk.dev_assoc = false;
+                    stage_b(ck[k % NCK], goff[k], n_tracks, tracks6, track_conf, n_dets, det_boxes, det_scores, det_labels);
+                }
                 {
                     std::lock_guard<std::mutex> lk(mu);
                     consumed = k + 1;
@@ -507,6 +589,7 @@ int aic_pipeline_option(aic_pipeline* p, const char* key, int value) {
         AIC_REQUIRE(p && key, AIC_ERR_INVALID, "NULL argument");
         const std::string k(key);
         if (k == "taper") p->p.taper = value != 0;
+        else if (k == "device_assoc") p->p.dev_assoc = value != 0;
         else AIC_REQUIRE(false, AIC_ERR_INVALID, "unknown pipeline option: " + k);
     });
 }

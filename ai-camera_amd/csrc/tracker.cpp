@@ -62,6 +62,8 @@ void Tracker::grow_galleries() {
 }
 
 void Tracker::predict() {   // tracker_core.py:44-49 -> track.py:76-80
+    if (use_device()) { dev_predicts += 1; return; }     // device path: the epoch kernel predicts at the start of the frame
+    to_host();
     if (pre_predicted) {                       // the device side of this predict already ran inside the previous frame's launch
         pre_predicted = false;
         for (auto& t : tracks) { t.age += 1; t.tsu += 1; }
@@ -134,6 +136,25 @@ struct TrkTimes {
 void Tracker::update(const float* det_tlwh, const float* conf, const int32_t* cls, const float* feat, int feat_mem,
                      const uint8_t* has_feat, int n, int dim_in, const float* feat_n, const NextDets* nx) {
     dev->use();
+    if (use_device() && nx == nullptr) {
+        if (feat != nullptr && n > 0) ensure_dim(dim_in);
+        if (dev_predicts == 1 && dev_capable()) {          // the reference's protocol: one predict(), one update()
+            dev_predicts = 0;
+            update_device(det_tlwh, conf, cls, feat, feat_mem, has_feat, n, dim_in);
+            return;
+        }
+        const int replay = dev_predicts;                    // unusual call sequence: replay it on the host path
+        dev_predicts = 0;
+        const bool keep = dev_assoc;
+        dev_assoc = false;
+        try {
+            for (int i = 0; i < replay; ++i) predict();
+            update(det_tlwh, conf, cls, feat, feat_mem, has_feat, n, dim_in, feat_n, nx);
+        } catch (...) { dev_assoc = keep; throw; }
+        dev_assoc = keep;
+        return;
+    }
+    to_host();
     const double tt0 = g_trk_times.on ? TrkTimes::now() : 0.0;
     double tt1 = tt0, tt2 = tt0, tt3 = tt0;
     hipStream_t s = dev->s_trk;
@@ -436,6 +457,189 @@ void Tracker::update(const float* det_tlwh, const float* conf, const int32_t* cl
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------ association on the device
+void Tracker::to_device() {
+    if (on_device) return;
+    AIC_REQUIRE(dev_capable(), AIC_ERR_INVALID, "device association needs nn_budget > 0, max_tracks <= 512 and a feature dimension divisible by 4");
+    AIC_REQUIRE(!pre_rows && !pend.active, AIC_ERR_RUNTIME, "device association: a pipelined host step is still open");
+    dev->use();
+    flush_predict();
+    hipStream_t s = dev->s_trk;
+    d_tbl.ensure(tbl_bytes());
+    h_tbl.ensure(tbl_bytes());
+    HIP_CHECK(hipStreamSynchronize(s));                    // h_tbl may still be the target of the previous header copy
+    DevTrkHdr* hh = reinterpret_cast<DevTrkHdr*>(h_tbl.p);
+    DevTrack* ht = reinterpret_cast<DevTrack*>(h_tbl.p + sizeof(DevTrkHdr));
+    int* hf = reinterpret_cast<int*>(h_tbl.p + sizeof(DevTrkHdr) + sizeof(DevTrack) * (size_t)cap);
+    std::memset(hh, 0, sizeof(DevTrkHdr));
+    hh->n_tracks = (int)tracks.size(), hh->next_id = next_id, hh->n_free = (int)free_slots.size();
+    for (size_t i = 0; i < tracks.size(); ++i) {
+        const TrackRec& r = tracks[i];
+        DevTrack& t = ht[i];
+        t.id = r.id, t.state = r.state, t.hits = r.hits, t.age = r.age, t.tsu = r.tsu, t.cls = r.cls, t.conf = r.conf;
+        t.slot = r.slot, t.glen = r.glen, t.ghead = r.ghead, t.pad[0] = t.pad[1] = 0;
+    }
+    std::copy(free_slots.begin(), free_slots.end(), hf);
+    HIP_CHECK(hipMemcpyAsync(d_tbl.p, h_tbl.p, tbl_bytes(), hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    on_device = true;
+}
+
+void Tracker::to_host() {
+    if (!on_device) return;
+    dev->use();
+    hipStream_t s = dev->s_trk;
+    HIP_CHECK(hipMemcpyAsync(h_tbl.p, d_tbl.p, tbl_bytes(), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    const DevTrkHdr* hh = reinterpret_cast<const DevTrkHdr*>(h_tbl.p);
+    const DevTrack* ht = reinterpret_cast<const DevTrack*>(h_tbl.p + sizeof(DevTrkHdr));
+    const int* hf = reinterpret_cast<const int*>(h_tbl.p + sizeof(DevTrkHdr) + sizeof(DevTrack) * (size_t)cap);
+    tracks.clear();
+    for (int i = 0; i < hh->n_tracks; ++i) {
+        TrackRec r{};
+        r.id = ht[i].id, r.state = ht[i].state, r.hits = ht[i].hits, r.age = ht[i].age, r.tsu = ht[i].tsu, r.cls = ht[i].cls;
+        r.conf = ht[i].conf, r.slot = ht[i].slot, r.glen = ht[i].glen, r.ghead = ht[i].ghead;
+        tracks.push_back(r);
+    }
+    free_slots.assign(hf, hf + hh->n_free);
+    next_id = hh->next_id;
+    on_device = false;
+    for (int i = 0; i < dev_predicts; ++i)                // predicts announced but not yet consumed by an epoch
+        for (auto& t : tracks) { t.age += 1; t.tsu += 1; }
+    if (dev_predicts > 0 && !tracks.empty()) {
+        for (int i = 0; i + 1 < dev_predicts; ++i) { pending_predict = true; flush_predict(); }
+        pending_predict = true;
+    }
+    dev_predicts = 0;
+}
+
+void Tracker::run_epochs(const EpochDets& dets, const int* h_n, const int* h_d0, int frames, const EpochOut& out, hipStream_t s, bool debug) {
+    to_device();
+    const bool feats = dets.feat_n != nullptr && dim > 0;
+    TrkDevParams prm;
+    prm.max_cos = (float)this->prm.max_cosine_distance, prm.clamp_cos = (float)(this->prm.max_cosine_distance + 1e-5);   // lsap.cpp:133-134
+    prm.max_iou = (float)this->prm.max_iou_distance, prm.clamp_iou = (float)(this->prm.max_iou_distance + 1e-5);
+    prm.max_age = this->prm.max_age, prm.n_init = this->prm.n_init, prm.gmax = gmax, prm.dim = dim, prm.cap = cap;
+    d_costs.ensure((size_t)3 * TRK_DEV_TMAX * TRK_DEV_NMAX);
+    d_sub.ensure((size_t)TRK_DEV_TMAX * TRK_DEV_NMAX);
+    d_appends.ensure((size_t)3 * TRK_DEV_DNMAX);
+    d_dbg.ensure(16 + 2 * TRK_DEV_TMAX);
+    const int kmax = std::max(1, std::min(TRK_KMAX, gmax));
+    int f = 0;
+    while (f < frames) {
+        int k = 0, dn = 0, nmax = 0;
+        while (f + k < frames && k < kmax && dn + h_n[f + k] <= TRK_DEV_DNMAX) {
+            dn += h_n[f + k];
+            nmax = std::max(nmax, h_n[f + k]);
+            ++k;
+        }
+        AIC_REQUIRE(k > 0 && nmax <= TRK_DEV_NMAX, AIC_ERR_CAPACITY, "device association: more than 512 detections in one frame");
+        const int dn_pad = std::max(32, (dn + 31) / 32 * 32);
+        const int d_begin = h_d0[f];
+        const bool has_sm = feats && dn > 0;
+        EpochScratch scr{nullptr, nullptr, d_costs.p, d_sub.p, d_appends.p};
+        if (has_sm) {
+            d_sm.ensure((size_t)cap * (TRK_KMAX + 1) * dn_pad);
+            d_gram.ensure((size_t)dn_pad * dn_pad);
+            scr.sm = d_sm.p, scr.gram = d_gram.p;
+            Prof pr(*dev, PROF_TRK, s, 2.0 * ((double)cap * gmax + dn) * dn * dim, 0);
+            launch_trk_epoch_prep(tbl_hdr(), tbl_trk(), d_gal_n.p, gmax, dim, cap, dets.feat_n + (size_t)d_begin * dim, dn, dn_pad, k, d_sm.p, d_gram.p, s);
+        }
+        EpochOut o = out;
+        const bool last = f + k >= frames;
+        if (!(debug && last)) o.dbg_match = nullptr, o.dbg_tn = nullptr;
+        {
+            Prof pr(*dev, PROF_TRK, s, 0, 0);
+            launch_trk_epoch(tbl_hdr(), tbl_trk(), tbl_free(), d_mean.p, d_cov.p, d_gal_raw.p, d_gal_n.p, prm, dets, f, k, d_begin, dn_pad, nmax,
+                             has_sm ? 1 : 0, scr, o, s);
+        }
+        f += k;
+    }
+    HIP_CHECK(hipMemcpyAsync(h_tbl.p, d_tbl.p, sizeof(DevTrkHdr), hipMemcpyDeviceToHost, s));
+}
+
+void Tracker::check_epochs() {
+    const DevTrkHdr* hh = reinterpret_cast<const DevTrkHdr*>(h_tbl.p);
+    if (hh->err == 0) return;
+    const std::string at = " (frame " + std::to_string(hh->err_frame) + " of the launch group; the tracker state is the frame before it)";
+    AIC_REQUIRE(hh->err != 1, AIC_ERR_CAPACITY, "track capacity exhausted (raise max_tracks)" + at);
+    AIC_REQUIRE(hh->err != 3, AIC_ERR_CAPACITY, "device association: frame beyond the epoch kernel's capacity" + at);
+    AIC_REQUIRE(false, AIC_ERR_RUNTIME, "device association: the assignment problem has no finite solution" + at);
+}
+
+// aic_tracker_update through the device path: one frame = one epoch of length 1.
+void Tracker::update_device(const float* det_tlwh, const float* conf, const int32_t* cls, const float* feat, int feat_mem,
+                            const uint8_t* has_feat, int n, int dim_in) {
+    AIC_REQUIRE(n >= 0 && n <= TRK_DEV_NMAX, AIC_ERR_CAPACITY, "device association: more than 512 detections in one frame");
+    hipStream_t s = dev->s_trk;
+    const bool any_feat = feat != nullptr && n > 0;
+    const int max_rows = TRK_DEV_TMAX;
+    // staging layout (host == device): n | d0 | tlwh[n*4] | conf[n] | cls[n] | valid[n] || out: n_tracks | rows[max_rows*6] | conf[max_rows]
+    const size_t o_tlwh = 16, o_conf = o_tlwh + (size_t)n * 16, o_cls = o_conf + (size_t)n * 4, o_valid = o_cls + (size_t)n * 4;
+    const size_t o_out = ((o_valid + (size_t)n * 4 + 15) / 16) * 16, o_rows = o_out + 16, o_oconf = o_rows + (size_t)max_rows * 24;
+    const size_t bytes = o_oconf + (size_t)max_rows * 4;
+    HIP_CHECK(hipStreamSynchronize(s));
+    h_api.ensure(bytes);
+    d_api.ensure(bytes);
+    int* hi = reinterpret_cast<int*>(h_api.p);
+    hi[0] = n, hi[1] = 0;
+    if (n) {
+        std::memcpy(h_api.p + o_tlwh, det_tlwh, (size_t)n * 16);
+        std::memcpy(h_api.p + o_conf, conf, (size_t)n * 4);
+        std::memcpy(h_api.p + o_cls, cls, (size_t)n * 4);
+        int* hv = reinterpret_cast<int*>(h_api.p + o_valid);
+        for (int j = 0; j < n; ++j) hv[j] = (any_feat && (!has_feat || has_feat[j])) ? 1 : 0;
+    }
+    HIP_CHECK(hipMemcpyAsync(d_api.p, h_api.p, o_out, hipMemcpyHostToDevice, s));
+    const float* d_featp = nullptr;
+    const float* d_featn = nullptr;
+    if (any_feat) {
+        if (feat_mem == AIC_DEVICE) d_featp = feat;
+        else {
+            d_feat.ensure((size_t)n * dim);
+            HIP_CHECK(hipMemcpyAsync(d_feat.p, feat, (size_t)n * dim * 4, hipMemcpyHostToDevice, s));
+            d_featp = d_feat.p;
+        }
+        d_detn.ensure((size_t)n * dim);
+        launch_normalize_rows(d_featp, d_detn.p, n, dim, s);
+        d_featn = d_detn.p;
+    }
+    EpochDets dets{reinterpret_cast<const int*>(d_api.p), reinterpret_cast<const int*>(d_api.p + 4),
+                   reinterpret_cast<const float*>(d_api.p + o_tlwh), reinterpret_cast<const float*>(d_api.p + o_conf),
+                   reinterpret_cast<const int*>(d_api.p + o_cls), reinterpret_cast<const int*>(d_api.p + o_valid), d_featp, d_featn};
+    d_dbg.ensure(16 + 2 * TRK_DEV_TMAX);
+    EpochOut out{reinterpret_cast<int*>(d_api.p + o_out), reinterpret_cast<int*>(d_api.p + o_rows), reinterpret_cast<float*>(d_api.p + o_oconf),
+                 max_rows, d_dbg.p + 8, d_dbg.p};
+    const int zero = 0;
+    run_epochs(dets, &n, &zero, 1, out, s, true);
+    HIP_CHECK(hipMemcpyAsync(h_api.p + o_out, d_api.p + o_out, bytes - o_out, hipMemcpyDeviceToHost, s));
+    std::vector<int> dbg(16 + 2 * TRK_DEV_TMAX);
+    HIP_CHECK(hipMemcpyAsync(dbg.data(), d_dbg.p, dbg.size() * 4, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    check_epochs();
+    const int no = *reinterpret_cast<const int*>(h_api.p + o_out);
+    const int* rows = reinterpret_cast<const int*>(h_api.p + o_rows);
+    const float* oc = reinterpret_cast<const float*>(h_api.p + o_oconf);
+    outputs.clear();
+    for (int k2 = 0; k2 < no && k2 < max_rows; ++k2) {
+        const int* r = rows + (size_t)k2 * 6;
+        outputs.push_back(TrackOut{r[0], r[1], r[2], r[3], r[4], r[5], oc[k2]});
+    }
+    last_t = dbg[0], last_n = dbg[1];
+    last_matches.clear();
+    for (int m = 0; m < dbg[8]; ++m) last_matches.emplace_back(dbg[9 + 2 * m], dbg[10 + 2 * m]);
+    const size_t tn = (size_t)last_t * last_n;
+    last_app.assign(tn, kInfty), last_maha.assign(tn, 0.f), last_iou.assign(tn, kInfty);
+    if (tn) {
+        const size_t stride = (size_t)TRK_DEV_TMAX * TRK_DEV_NMAX;
+        HIP_CHECK(hipMemcpyAsync(last_app.data(), d_costs.p, tn * 4, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipMemcpyAsync(last_maha.data(), d_costs.p + stride, tn * 4, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipMemcpyAsync(last_iou.data(), d_costs.p + 2 * stride, tn * 4, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+    }
+}
+
 }  // namespace aic
 
 // =================================================================================================
@@ -601,6 +805,53 @@ int aic_tracker_destroy(aic_tracker* t) {
     return guarded([&] { delete t; });
 }
 
+int aic_tracker_option(aic_tracker* t, const char* key, int value) {
+    return guarded([&] {
+        AIC_REQUIRE(t && key, AIC_ERR_INVALID, "NULL argument");
+        const std::string k(key);
+        if (k == "device_assoc") {
+            AIC_REQUIRE(!value || t->t.dev_capable(), AIC_ERR_INVALID,
+                        "device association needs nn_budget > 0, max_tracks <= 512 and a feature dimension divisible by 4");
+            if (!value) t->t.to_host();
+            t->t.dev_assoc = value != 0;
+        } else AIC_REQUIRE(false, AIC_ERR_INVALID, "unknown tracker option: " + k);
+    });
+}
+
+// The device cascade + LSAP of kernels_trk_dev.hip on caller-provided matrices of one frame (parity tests).
+int aic_match_cascade_device(int device_id, const float* app, const float* maha, const float* iou, int t, int n, const int32_t* state,
+                             const int32_t* tsu, double max_cosine_distance, double max_iou_distance, int max_age, int stage1_only,
+                             int32_t* match_det_of_track) {
+    return guarded([&] {
+        AIC_REQUIRE(t >= 0 && n >= 0 && t <= TRK_DEV_TMAX && n <= TRK_DEV_NMAX, AIC_ERR_CAPACITY, "at most 512 tracks x 512 detections");
+        if (t == 0) return;
+        AIC_REQUIRE(state && tsu && match_det_of_track && (n == 0 || (app && maha && iou)), AIC_ERR_INVALID, "NULL argument");
+        Device& d = device(device_id);
+        hipStream_t s = d.s_trk;
+        const size_t stride = (size_t)TRK_DEV_TMAX * TRK_DEV_NMAX, tn = (size_t)t * n;
+        DevBuf<float> costs(3 * stride), sub(stride);
+        DevBuf<int> st(t), ts(t), md(t + 1);
+        if (tn) {
+            HIP_CHECK(hipMemcpyAsync(costs.p, app, tn * 4, hipMemcpyHostToDevice, s));
+            HIP_CHECK(hipMemcpyAsync(costs.p + stride, maha, tn * 4, hipMemcpyHostToDevice, s));
+            HIP_CHECK(hipMemcpyAsync(costs.p + 2 * stride, iou, tn * 4, hipMemcpyHostToDevice, s));
+        }
+        HIP_CHECK(hipMemcpyAsync(st.p, state, (size_t)t * 4, hipMemcpyHostToDevice, s));
+        HIP_CHECK(hipMemcpyAsync(ts.p, tsu, (size_t)t * 4, hipMemcpyHostToDevice, s));
+        TrkDevParams prm{};
+        prm.max_cos = (float)max_cosine_distance, prm.clamp_cos = (float)(max_cosine_distance + 1e-5);
+        prm.max_iou = (float)max_iou_distance, prm.clamp_iou = (float)(max_iou_distance + 1e-5);
+        prm.max_age = max_age, prm.n_init = 3, prm.gmax = 1, prm.dim = 0, prm.cap = TRK_DEV_TMAX;
+        EpochScratch scr{nullptr, nullptr, costs.p, sub.p, nullptr};
+        launch_trk_cascade_test(prm, scr, t, n, st.p, ts.p, md.p, md.p + t, stage1_only, s);
+        std::vector<int> out(t + 1);
+        HIP_CHECK(hipMemcpyAsync(out.data(), md.p, (size_t)(t + 1) * 4, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        AIC_REQUIRE(out[t] == 0, AIC_ERR_INVALID, "cost matrix contains NaN/-inf or is infeasible");
+        std::copy(out.begin(), out.begin() + t, match_det_of_track);
+    });
+}
+
 int aic_tracker_predict(aic_tracker* t) {
     return guarded([&] {
         AIC_REQUIRE(t, AIC_ERR_INVALID, "NULL tracker");
@@ -634,6 +885,7 @@ int aic_tracker_outputs(aic_tracker* t, int32_t* out6, float* conf, int cap, int
 int aic_tracker_num_tracks(const aic_tracker* t, int32_t* n) {
     return guarded([&] {
         AIC_REQUIRE(t && n, AIC_ERR_INVALID, "NULL argument");
+        const_cast<aic_tracker*>(t)->t.to_host();
         *n = (int32_t)t->t.tracks.size();
     });
 }
@@ -643,6 +895,7 @@ int aic_tracker_export(aic_tracker* t, int cap, int32_t* track_id, int32_t* stat
     return guarded([&] {
         AIC_REQUIRE(t, AIC_ERR_INVALID, "NULL tracker");
         Tracker& k = t->t;
+        k.to_host();
         const int T = (int)k.tracks.size();
         AIC_REQUIRE(T <= cap, AIC_ERR_CAPACITY, "export capacity too small");
         std::vector<float> hm, hc;
@@ -675,6 +928,7 @@ int aic_tracker_export_gallery(aic_tracker* t, int index, float* out, int cap_ro
     return guarded([&] {
         AIC_REQUIRE(t && out, AIC_ERR_INVALID, "NULL argument");
         Tracker& k = t->t;
+        k.to_host();
         AIC_REQUIRE(index >= 0 && index < (int)k.tracks.size(), AIC_ERR_INVALID, "track index out of range");
         const TrackRec& r = k.tracks[index];
         AIC_REQUIRE(r.glen <= cap_rows, AIC_ERR_CAPACITY, "gallery capacity too small");

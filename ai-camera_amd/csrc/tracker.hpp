@@ -1,6 +1,7 @@
 // tracker.hpp -- DeepSORT core with Kalman state and galleries in HBM, lifecycle + cascade on host.
 #pragma once
 #include "kernels.hpp"
+#include "trk_dev.hpp"
 
 namespace aic {
 
@@ -54,6 +55,31 @@ struct Tracker {
     int last_t = 0, last_n = 0;
     std::vector<std::pair<int, int>> last_matches;   // (track id, det)
     std::vector<TrackOut> outputs;
+
+    // ---- association on the device, k frames per launch (kernels_trk_dev.hip): the track table lives in HBM between launches
+    bool dev_assoc = false;            // aic_tracker_option("device_assoc"); the pipeline turns it on when dev_capable()
+    bool on_device = false;            // the HBM table is the current one; `tracks` / `free_slots` / `next_id` are stale
+    int dev_predicts = 0;              // predict() calls not yet consumed by an update (device path: the epoch kernel predicts)
+    DevBuf<char> d_tbl;                // DevTrkHdr | DevTrack[cap] | int free_slots[cap]
+    PinBuf<char> h_tbl;
+    DevBuf<float> d_sm, d_gram, d_costs, d_sub;
+    DevBuf<int> d_appends, d_dbg;
+    PinBuf<char> h_api;                // single-frame API staging (aic_tracker_update through the device path)
+    DevBuf<char> d_api;
+    bool dev_capable() const { return !unlimited && cap <= TRK_DEV_TMAX && (dim == 0 || dim % 4 == 0); }
+    bool use_device() const { return dev_assoc && dev_capable(); }
+    DevTrkHdr* tbl_hdr() { return reinterpret_cast<DevTrkHdr*>(d_tbl.p); }
+    DevTrack* tbl_trk() { return reinterpret_cast<DevTrack*>(d_tbl.p + sizeof(DevTrkHdr)); }
+    int* tbl_free() { return reinterpret_cast<int*>(d_tbl.p + sizeof(DevTrkHdr) + sizeof(DevTrack) * (size_t)cap); }
+    size_t tbl_bytes() const { return sizeof(DevTrkHdr) + (sizeof(DevTrack) + 4) * (size_t)cap; }
+    void to_device();
+    void to_host();
+    // frames [0, frames) of one launch group (h_n / h_d0: host copies of dets.frame_n / frame_d0), all launches on stream s,
+    // no host synchronisation; the header copy lands in h_tbl behind them (check_epochs() after the caller's sync)
+    void run_epochs(const EpochDets& dets, const int* h_n, const int* h_d0, int frames, const EpochOut& out, hipStream_t s, bool debug = false);
+    void check_epochs();
+    void update_device(const float* det_tlwh, const float* conf, const int32_t* cls, const float* feat, int feat_mem,
+                       const uint8_t* has_feat, int n, int dim_in);
 
     Tracker(Device& d, const aic_tracker_params& p);
     void ensure_dim(int d);

@@ -156,6 +156,13 @@ int aic_match_cascade(const float* app, const float* maha, const float* iou, int
                       int32_t* unmatched_tracks, int32_t* n_unmatched_tracks, int32_t* unmatched_dets,
                       int32_t* n_unmatched_dets);
 
+/* The same cascade (stage1_only = 0) or its appearance stage alone (1) run by the DEVICE association kernels
+ * (csrc/kernels_trk_dev.hip: wave-parallel restatement of the same SciPy LSAP) on one frame's matrices; at most 512 x 512.
+ * match_det_of_track[T]: the detection each track got, or -1.  Parity-test entry point of SURVEY.md §8(f)-4. */
+int aic_match_cascade_device(int device, const float* app, const float* maha, const float* iou, int t, int n,
+                             const int32_t* state, const int32_t* time_since_update, double max_cosine_distance,
+                             double max_iou_distance, int max_age, int stage1_only, int32_t* match_det_of_track);
+
 /* ------------------------------------------------------------------ tracker
  * TrackerCore (src/tracker/core/tracker_core.py:11-198) + Track lifecycle
  * (src/tracker/core/track.py:16-171).  Kalman state and feature galleries live in HBM;
@@ -173,6 +180,10 @@ typedef struct aic_tracker_params {
 
 int aic_tracker_create(int device, const aic_tracker_params* p, aic_tracker** out);
 int aic_tracker_destroy(aic_tracker* t);
+/* "device_assoc" = 1: predict/update run the whole frame (gating, cascade, LSAP, lifecycle, Kalman update) on the device,
+ * the track table stays in HBM between calls (what the pipeline does k frames per launch); 0 (default for this entry
+ * point): cost matrices on the device, cascade/LSAP/lifecycle in host C++.  Same results either way. */
+int aic_tracker_option(aic_tracker* t, const char* key, int value);
 /* TrackerCore.predict (tracker_core.py:44-49). */
 int aic_tracker_predict(aic_tracker* t);
 /* TrackerCore.update (tracker_core.py:51-81) on N detections: tlwh[N,4], conf[N], class id[N],

@@ -1,0 +1,137 @@
+"""Association ON THE DEVICE (csrc/kernels_trk_dev.hip): the wave-parallel restatement of SciPy's rectangular
+LSAP, the thresholded matching and the matching cascade against SciPy itself, the reference fixtures (tests/golden/assign.npz)
+and the oracle cascade; the complete device tracker (epochs of k frames, track table in HBM) against the reference
+trajectories (tests/golden/traj*.npz) -- identical ids, states, counters and matches on every frame."""
+import numpy as np
+import pytest
+from scipy.optimize import linear_sum_assignment as scipy_lsa
+
+from asan_driver import random_cost, random_frame
+from conftest import pkg
+from oracle import deepsort_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def device_cascade(lib, app, maha, iou, state, tsu, max_cos, max_iou, max_age, stage1_only=0):
+    t, n = app.shape
+    out = np.full(max(t, 1), -2, np.int32)
+    lib.call("aic_match_cascade_device", 0, lib.ptr(np.ascontiguousarray(app, np.float32)), lib.ptr(np.ascontiguousarray(maha, np.float32)),
+             lib.ptr(np.ascontiguousarray(iou, np.float32)), t, n, lib.ptr(np.ascontiguousarray(state, np.int32)),
+             lib.ptr(np.ascontiguousarray(tsu, np.int32)), float(max_cos), float(max_iou), int(max_age), int(stage1_only), lib.ptr(out))
+    return out[:t]
+
+
+def test_device_lsap_matches_scipy(gpu, lib):
+    """Pure assignment (threshold above every entry): the device LSAP must return SciPy's optimum AND SciPy's choice among
+    equal optima (random, tied, quantised, constant, partly infeasible matrices; wide, square and tall)."""
+    rng = np.random.default_rng(7)
+    for it in range(1200):
+        r, c = (int(v) for v in rng.integers(1, 48, 2))
+        if it % 97 == 0:
+            r, c = int(rng.integers(60, 200)), int(rng.integers(60, 200))       # several columns per lane, larger than one wave
+        m = random_cost(rng, it, r, c).astype(np.float32)
+        got = device_cascade(lib, m, np.zeros_like(m), np.zeros_like(m), np.full(r, 2), np.ones(r), 1e30, 1e30, 1, stage1_only=1)
+        sr, sc = scipy_lsa(m.astype(np.float64))
+        exp = np.full(r, -1, np.int32)
+        exp[sr] = sc
+        assert np.array_equal(got, exp), (it, m.shape)
+
+
+def test_device_min_cost_matching_reference_fixtures(gpu, lib, golden):
+    g = golden("assign")
+    for k in range(int(g["n_cases"])):
+        m = np.ascontiguousarray(g[f"c{k}_cost"], np.float32)
+        nr, nc = m.shape
+        for name, thr in (("cos", 0.2), ("iou", 0.7)):
+            got = device_cascade(lib, m, np.zeros_like(m), np.zeros_like(m), np.full(nr, 2), np.ones(nr), thr, thr, 1, stage1_only=1)
+            exp = np.full(nr, -1, np.int32)
+            em = g[f"c{k}_{name}_m"]                       # (row id, col id) with rows 0,2,4.. and cols 100..
+            for a, b in em.reshape(-1, 2):
+                exp[a // 2] = b - 100
+            assert np.array_equal(got, exp), (k, name)
+
+
+def test_device_cascade_matches_oracle(gpu, lib):
+    rng = np.random.default_rng(3)
+    for it in range(400):
+        app, maha, iou, state, tsu = random_frame(rng, it)
+        t, n = app.shape
+        if t == 0:
+            continue
+        max_age = int(rng.integers(1, 7))
+        got = device_cascade(lib, app, maha, iou, state, tsu, 0.2, 0.7, max_age)
+        em, _, _ = O.cascade_on_matrices(app, maha, iou, state.tolist(), tsu.tolist(), 0.2, 0.7, max_age)
+        exp = np.full(t, -1, np.int32)
+        for a, b in em:
+            exp[a] = b
+        assert np.array_equal(got, exp), it
+
+
+@pytest.mark.parametrize("name", ["traj8", "traj30", "traj100"])
+def test_device_tracker_trajectories_identical_to_reference(gpu, golden, name):
+    """The reference trajectories through the device path (aic_tracker_option device_assoc = 1): every frame one epoch."""
+    from golden.traj_config import TRAJ, scene_inputs
+    TC = pkg("core.tracker_core").TrackerCore
+    g = golden(name)
+    _, tk, frames, dim, _ = TRAJ[name]
+    trk = TC(**tk)
+    trk.option("device_assoc", 1)
+    worst_mean = 0.0
+    for f in range(frames):
+        tlwh, conf, ids, feats, has = scene_inputs(name, f)
+        trk.predict()
+        trk.update_arrays(tlwh, conf, np.zeros(len(ids), np.int32), feats, has.astype(np.uint8))
+        k = int((g["match_tid"][f] >= 0).sum())
+        assert sorted(trk.last_matches()) == sorted(zip(g["match_tid"][f, :k].tolist(), g["match_det"][f, :k].tolist())), f
+        rows, _ = trk.outputs()
+        no = int(g["n_out"][f])
+        assert len(rows) == no, f
+        if no:
+            assert np.array_equal(rows[:, 4], g["out"][f, :no, 4])
+            assert np.abs(rows[:, :4] - g["out"][f, :no, :4]).max() <= 1
+        if f % 7 == 0 or f == frames - 1:                 # the table comes back from HBM for the check, then goes up again
+            a = trk.export_arrays()
+            nt = int(g["n_tracks"][f])
+            assert a["track_id"].tolist() == g["tid"][f, :nt].tolist(), f
+            assert a["state"].tolist() == g["state"][f, :nt].tolist(), f
+            assert a["hits"].tolist() == g["hits"][f, :nt].tolist() and a["age"].tolist() == g["age"][f, :nt].tolist()
+            assert a["time_since_update"].tolist() == g["tsu"][f, :nt].tolist()
+            assert a["gallery_len"].tolist() == g["glen"][f, :nt].tolist()
+            if nt:
+                worst_mean = max(worst_mean, float(np.abs(a["mean"] - g["mean"][f, :nt]).max()))
+    assert worst_mean < 1e-3, worst_mean
+    v = trk.tracks[0]
+    assert len(v.features) == a["gallery_len"][0] and v.features[0].shape == (dim,)
+
+
+def test_device_and_host_association_same_costs(gpu):
+    """One tracker per path on the same inputs: identical cost matrices (bit for bit: same MFMA contraction order), matches
+    and outputs, including a gallery that wraps (budget 5) and featureless detections."""
+    syn = pkg("synthetic")
+    TC = pkg("core.tracker_core").TrackerCore
+    sc = syn.Scene(seed=8, n_targets=14, gaps=[(2, 4, 9), (5, 10, 14)], births={9: 5}, jitter=1.5)
+    a, b = TC(nn_budget=5, max_age=6), TC(nn_budget=5, max_age=6)
+    b.option("device_assoc", 1)
+    for f in range(40):
+        boxes, conf, cls, ids = sc.detections(f)
+        feats = syn.identity_features(ids, f, dim=128, noise=0.03)
+        has = np.ones(len(ids), np.uint8)
+        if f % 5 == 3 and len(has):
+            has[0] = 0
+        tlwh = np.stack([boxes[:, 0], boxes[:, 1], boxes[:, 2] - boxes[:, 0], boxes[:, 3] - boxes[:, 1]], 1).astype(np.float32)
+        for t in (a, b):
+            t.predict()
+            t.update_arrays(tlwh, conf, cls, feats, has)
+        ca, cb = a.last_costs(), b.last_costs()
+        for x, y in zip(ca, cb):
+            assert x.shape == y.shape and np.array_equal(x, y), f
+        assert sorted(a.last_matches()) == sorted(b.last_matches()), f
+        ra, rb = a.outputs(), b.outputs()
+        assert np.array_equal(ra[0], rb[0]) and np.array_equal(ra[1], rb[1]), f
+    ea, eb = a.export_arrays(), b.export_arrays()
+    for key in ("track_id", "state", "hits", "age", "time_since_update", "gallery_len"):
+        assert ea[key].tolist() == eb[key].tolist(), key
+    assert np.array_equal(ea["mean"], eb["mean"]) and np.array_equal(ea["cov"], eb["cov"])
+    for ta, tb in zip(a.tracks, b.tracks):
+        assert np.array_equal(np.stack(ta.features), np.stack(tb.features))

@@ -33,13 +33,15 @@ def oracle_tracks(sc, reid_eo, frames, n_frames, **trk_kw):
     return out, embs, trk
 
 
+@pytest.mark.parametrize("assoc", ["device", "host"])
 @pytest.mark.parametrize("dtype", ["fp32", "fp16"])
-def test_pipeline_inject_matches_oracle(gpu, engines, dtype):
+def test_pipeline_inject_matches_oracle(gpu, engines, dtype, assoc):
     n_frames, batch = 24, 8
     sc = syn.Scene(seed=21, n_targets=12, gaps=[(2, 6, 9), (5, 12, 20)], births={11: 5})
     frames = sc.render_batch(0, n_frames)
     TP = pkg("pipeline").TrackingPipeline
     pipe = TP(engines[0], engines[1], (720, 1280), batch=batch, ring_frames=n_frames, max_persons=16, dtype=dtype, inject=True)
+    pipe.option("device_assoc", int(assoc == "device"))     # association on the device (k frames per launch) / cascade + LSAP in host C++
     pipe.upload(0, frames)
     pipe.inject(0, [sc.detections(f)[:3] for f in range(n_frames)])
     tracks, nd = pipe.run(0, n_frames)
@@ -120,7 +122,8 @@ def test_run_passes_equals_consecutive_calls(gpu, engines):
     b.close()
 
 
-def test_pipeline_small_gallery_budget(gpu, engines):
+@pytest.mark.parametrize("assoc", ["device", "host"])
+def test_pipeline_small_gallery_budget(gpu, engines, assoc):
     """nn_budget 3, max_age 4: the gallery ring evicts on almost every frame and tracks die and are re-born inside one
     launch group -- the pipelined tracker step (commit of frame f inside the association launch of f+1) must keep the
     oracle's ids, states and Kalman means."""
@@ -130,6 +133,7 @@ def test_pipeline_small_gallery_budget(gpu, engines):
     TP = pkg("pipeline").TrackingPipeline
     pipe = TP(engines[0], engines[1], (720, 1280), batch=batch, ring_frames=n_frames, max_persons=16, dtype="fp32", inject=True,
               nn_budget=3, max_age=4)
+    pipe.option("device_assoc", int(assoc == "device"))     # device: epochs are capped at the gallery budget (3 frames per launch)
     pipe.upload(0, frames)
     pipe.inject(0, [sc.detections(f)[:3] for f in range(n_frames)])
     tracks, nd = pipe.run(0, n_frames)
