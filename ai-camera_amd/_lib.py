@@ -93,6 +93,12 @@ _SIGS = {
     "aic_pipeline_run": (_I, [_P, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "aic_pipeline_run_passes": (_I, [_P, _I, _I, _I, _P, _P, _P, _P]),
     "aic_pipeline_run_from_host": (_I, [_P, _P, _I, _I, _P, _P, _P, _P]),
+    "aic_pipeline_run_from_host_passes": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P]),
+    "aic_pipeline_group_times": (_I, [_P, _P, _P, _P, _I, _P]),
+    "aic_pipeline_exchange_enable": (_I, [_P, _P, _P, _I, _I]),
+    "aic_pipeline_exchange_stream": (_I, [_P, _P]),
+    "aic_pipeline_exchange_wait": (_I, [_P, C.c_int64, _I, _P, _P]),
+    "aic_pipeline_exchange_done": (_I, [_P, C.c_int64]),
     "aic_host_register": (_I, [_P, C.c_size_t]),
     "aic_host_unregister": (_I, [_P]),
     "aic_pipeline_tracker": (_I, [_P, _P]),

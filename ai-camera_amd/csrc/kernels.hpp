@@ -141,6 +141,7 @@ void launch_trk_epoch_prep(const DevTrkHdr* hdr, const DevTrack* trk, const floa
 void launch_trk_epoch(DevTrkHdr* hdr, DevTrack* trk, int* free_slots, float* mean, float* cov, float* gal_raw, float* gal_n,
                       const TrkDevParams& prm, const EpochDets& dets, int f0, int k, int d_begin, int dn_pad, int nmax, int has_sm,
                       const EpochScratch& scr, const EpochOut& out, hipStream_t s);
+void launch_gallery_shard(const DevTrkHdr* hdr, const DevTrack* trk, const float* gal_n, int gmax, int dim, float* out, int t_max, hipStream_t s);
 void launch_trk_cascade_test(const TrkDevParams& prm, const EpochScratch& scr, int T, int n, const int* state, const int* tsu,
                              int* out_mdet, int* out_err, int stage1_only, hipStream_t s);
 

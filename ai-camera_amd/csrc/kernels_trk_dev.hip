@@ -14,6 +14,8 @@
 #include "trk_math.hpp"
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 
 namespace aic {
 
@@ -161,22 +163,28 @@ struct Lds {                        // carved out of the dynamic LDS block by ld
     int *pred, *rowof, *colof, *todo, *pos, *asg;
     // scalars / scratch
     int* wcnt;                      // [NW + 8]
-    float* arena;                   // assignment sub-matrix
+    float* kf;                      // [KF_SLOTS][72] Kalman state of the low slots for the whole epoch: cov[64] | mean[8]
+    float* arena;                   // cost matrices of the frame (when they fit) + assignment sub-matrix
     int arena_floats;
 };
+
+constexpr int KF_SLOTS = 96;        // slots are handed out lowest first, so live tracks sit here unless > 96 are alive
 
 __device__ __forceinline__ Lds lds_carve(char* base, int cap, int nmax, int total_bytes) {
     Lds L;
     char* p = base;
     auto take = [&](size_t bytes) { char* q = p; p += (bytes + 15) & ~(size_t)15; return q; };
-    L.u = (double*)take(8 * BT); L.v = (double*)take(8 * BT); L.dist = (double*)take(8 * BT);
-    int** ti[] = {&L.id, &L.state, &L.hits, &L.age, &L.tsu, &L.cls, &L.slot, &L.glen, &L.ghead, &L.sm, &L.napp, &L.glen0, &L.mdet, &L.rows,
-                  &L.pred, &L.rowof, &L.colof, &L.todo, &L.pos, &L.asg};
-    for (auto a : ti) *a = (int*)take(4 * BT);
-    L.conf = (float*)take(4 * BT);
-    L.tbox = (float*)take(16 * BT);
-    L.newrow = (unsigned short*)take(2 * BT * TRK_KMAX);
-    L.free_slots = (int*)take(4 * (size_t)cap);
+    const size_t tc = (size_t)cap, mx = (size_t)max(cap, nmax);     // table rows; side of the largest assignment problem
+    L.u = (double*)take(8 * mx); L.v = (double*)take(8 * mx); L.dist = (double*)take(8 * mx);
+    int** ti[] = {&L.id, &L.state, &L.hits, &L.age, &L.tsu, &L.cls, &L.slot, &L.glen, &L.ghead, &L.sm, &L.napp, &L.glen0, &L.mdet, &L.rows};
+    for (auto a : ti) *a = (int*)take(4 * tc);
+    int** li[] = {&L.pred, &L.rowof, &L.colof, &L.todo, &L.pos, &L.asg};
+    for (auto a : li) *a = (int*)take(4 * mx);
+    L.conf = (float*)take(4 * tc);
+    L.tbox = (float*)take(16 * tc);
+    L.newrow = (unsigned short*)take(2 * tc * TRK_KMAX);
+    L.free_slots = (int*)take(4 * tc);
+    L.kf = (float*)take(4 * 72 * (size_t)KF_SLOTS);
     L.tlwh = (float*)take(16 * (size_t)nmax); L.xyah = (float*)take(16 * (size_t)nmax); L.dconf = (float*)take(4 * (size_t)nmax);
     int** di[] = {&L.dcls, &L.dhas, &L.mtrk, &L.und, &L.cols};
     for (auto a : di) *a = (int*)take(4 * (size_t)nmax);
@@ -341,6 +349,89 @@ __device__ bool lsap_wave(const float* cm, int nr, int nc, const Lds& L, int lan
     return true;
 }
 
+__device__ __forceinline__ double readlane_f64(double x, int l) {
+    const long long b = __double_as_longlong(x);
+    const int lo = __builtin_amdgcn_readlane((int)b, l), hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+
+// The same algorithm with max(nr, nc) <= 64: lane j IS column j (dist, v, pred, row_of_col, list position in registers), lane i
+// IS row i (u, col_of_row); the list of unscanned columns is only its inverse pos[] (the lane whose pos == p sits at list
+// position p).  LDS is touched for the cost entries alone.
+__device__ bool lsap_wave64(const float* cm, int nr, int nc, const Lds& L, int lane) {
+    const bool tall = nr > nc;
+    const int R = tall ? nc : nr, C = tall ? nr : nc;
+    const double inf = __longlong_as_double(0x7ff0000000000000ll);
+    double v = 0.0, u = 0.0, dist = inf;
+    int rowof = -1, colof = -1, pred = -1;
+    for (int root = 0; root < R; ++root) {
+        dist = inf;
+        int pos = lane < C ? C - 1 - lane : -1;
+        bool seen = false;
+        double base = 0.0;
+        int live = C, i = root, sink = -1;
+        while (sink < 0) {
+            const double ui = readlane_f64(u, i);
+            if (pos >= 0) {
+                const float cij = tall ? cm[lane * nc + i] : cm[i * nc + lane];
+                const double red = ((base + (double)cij) - ui) - v;
+                if (red < dist) { dist = red; pred = i; }
+            }
+            const double m = wave_min_f64(pos >= 0 ? dist : inf);
+            if (!(m < inf)) return false;
+            const bool cand = pos >= 0 && dist == m;
+            const bool cand_u = cand && rowof < 0;
+            const unsigned long long bu = __ballot(cand_u);
+            int jp;
+            if (bu) {                                              // the LAST visited unassigned minimum
+                if (__popcll(bu) == 1) jp = __ffsll((long long)bu) - 1;
+                else {
+                    const unsigned pp = wave_umax32(cand_u ? (unsigned)pos + 1u : 0u) - 1u;
+                    jp = __ffsll((long long)__ballot(cand_u && (unsigned)pos == pp)) - 1;
+                }
+            } else {                                               // the FIRST visited minimum
+                const unsigned long long bc = __ballot(cand);
+                if (__popcll(bc) == 1) jp = __ffsll((long long)bc) - 1;
+                else {
+                    const unsigned pp = wave_umin32(cand ? (unsigned)pos : 0xffffffffu);
+                    jp = __ffsll((long long)__ballot(cand && (unsigned)pos == pp)) - 1;
+                }
+            }
+            jp = __builtin_amdgcn_readfirstlane(jp);
+            base = m;
+            const int pick = __builtin_amdgcn_readlane(pos, jp);
+            const int rj = __builtin_amdgcn_readlane(rowof, jp);
+            if (rj < 0) sink = jp; else i = rj;
+            const int jl = __ffsll((long long)__ballot(pos == live - 1)) - 1;   // the list's last entry moves into the freed place
+            if (lane == jl) pos = pick;
+            if (lane == jp) { pos = -1; seen = true; }
+            --live;
+        }
+        // dual update (lsap.cpp:83-87): a seen row is the partner of a scanned assigned column
+        const double dlt = base - dist;
+        {
+            const int src = colof >= 0 ? colof : 0;
+            const double dl = __shfl(dlt, src);
+            const int sn = __shfl((int)seen, src);
+            if (lane < R && colof >= 0 && sn) u = u + dl;
+        }
+        if (seen) v = v - dlt;
+        if (lane == root) u = u + base;
+        int j = sink;
+        for (;;) {                                                 // flip the path back to the root
+            const int i2 = __builtin_amdgcn_readlane(pred, j);
+            if (lane == j) rowof = i2;
+            const int t = __builtin_amdgcn_readlane(colof, i2);
+            if (lane == i2) colof = j;
+            j = t;
+            if (i2 == root) break;
+        }
+    }
+    if (lane < nr) L.asg[lane] = tall ? rowof : colof;
+    wave_lds_sync();
+    return true;
+}
+
 }  // namespace
 
 struct EpochArgs {
@@ -353,6 +444,7 @@ struct EpochArgs {
     EpochScratch scr;
     EpochOut out;
     int lds_bytes;
+    long long* prof;                       // AICAM_TRK_PHASES: shader-clock cycles per phase, accumulated by thread 0 (NULL: off)
 };
 
 namespace {
@@ -361,13 +453,14 @@ namespace {
 //   stage 1: sub[r][c] = maha > chi2 ? INFTY : app (linear_assignment.py:187-210), threshold max_cos
 //   stage 2: sub[r][c] = iou, threshold max_iou
 // Matched pairs are entered into mdet / mtrk. *err != 0 on an LSAP failure.
-__device__ void match_block(const Lds& L, const EpochArgs& a, const int* cols, int nr, int nc, int n, bool stage2, int* err) {
-    const float* app = a.scr.cost;
-    const float* maha = app + (size_t)TRK_DEV_TMAX * TRK_DEV_NMAX;
-    const float* iou = maha + (size_t)TRK_DEV_TMAX * TRK_DEV_NMAX;
+struct FrameCosts { const float* app; const float* maha; const float* iou; float* sub_lds; int sub_floats; };
+
+__device__ void match_block(const Lds& L, const EpochArgs& a, const FrameCosts& fc, const int* cols, int nr, int nc, int n, bool stage2, int* err) {
+    const float* app = fc.app;
+    const float* maha = fc.maha;
+    const float* iou = fc.iou;
     const float maxd = stage2 ? a.prm.max_iou : a.prm.max_cos, clamp = stage2 ? a.prm.clamp_iou : a.prm.clamp_cos;
-    const bool in_lds = nr * nc <= L.arena_floats;
-    float* sub = in_lds ? L.arena : a.scr.sub;
+    float* sub = nr * nc <= fc.sub_floats ? fc.sub_lds : a.scr.sub;
     for (int e = threadIdx.x; e < nr * nc; e += BT) {
         const int r = e / nc, c = e - r * nc;
         const size_t kk = (size_t)L.rows[r] * n + cols[c];
@@ -378,7 +471,7 @@ __device__ void match_block(const Lds& L, const EpochArgs& a, const int* cols, i
     __threadfence_block();
     __syncthreads();
     if (threadIdx.x < 64) {
-        const bool ok = lsap_wave(sub, nr, nc, L, threadIdx.x);
+        const bool ok = (nr <= 64 && nc <= 64) ? lsap_wave64(sub, nr, nc, L, threadIdx.x) : lsap_wave(sub, nr, nc, L, threadIdx.x);
         if (!ok && threadIdx.x == 0) *err = 2;
     }
     __syncthreads();
@@ -409,15 +502,23 @@ __device__ __forceinline__ int ring_push(int& glen, int& ghead, int gmax) {
 
 }  // namespace
 
+#define PHASE(i) do { if (a.prof && threadIdx.x == 0) { const long long _t = clock64(); atomicAdd((unsigned long long*)&a.prof[i], (unsigned long long)(_t - t_ph)); t_ph = _t; } } while (0)
+
 __global__ __launch_bounds__(TRK_DEV_TMAX) void trk_epoch_kernel(EpochArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ int s_err, s_napp_total;
+    long long t_ph = a.prof ? clock64() : 0;
     const Lds L = lds_carve(smem, a.prm.cap, a.nmax, a.lds_bytes);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int gmax = a.prm.gmax, dim = a.prm.dim;
-    float* c_app = a.scr.cost;
-    float* c_maha = c_app + (size_t)TRK_DEV_TMAX * TRK_DEV_NMAX;
-    float* c_iou = c_maha + (size_t)TRK_DEV_TMAX * TRK_DEV_NMAX;
+    // Kalman state: the low slots live in LDS for the whole epoch, the rest stays in HBM
+    auto kP = [&](int slot) -> float* { return slot < KF_SLOTS ? L.kf + slot * 72 : a.cov + (size_t)slot * 64; };
+    auto kM = [&](int slot) -> float* { return slot < KF_SLOTS ? L.kf + slot * 72 + 64 : a.mean + (size_t)slot * 8; };
+    {
+        const int ns = min(KF_SLOTS, a.prm.cap);
+        for (int e = tid; e < ns * 64; e += BT) L.kf[(e >> 6) * 72 + (e & 63)] = a.cov[e];
+        for (int e = tid; e < ns * 8; e += BT) L.kf[(e >> 3) * 72 + 64 + (e & 7)] = a.mean[e];
+    }
 
     // ---- load the track table (uniform copies of the scalars in registers)
     int T = a.hdr->n_tracks, next_id = a.hdr->next_id, nfree = a.hdr->n_free;
@@ -431,6 +532,7 @@ __global__ __launch_bounds__(TRK_DEV_TMAX) void trk_epoch_kernel(EpochArgs a) {
     }
     for (int i = tid; i < nfree; i += BT) L.free_slots[i] = a.free_slots[i];
     __syncthreads();
+    PHASE(0);
 
     int fi = 0, err_frame = -1;
     for (; fi < a.k; ++fi) {
@@ -457,18 +559,47 @@ __global__ __launch_bounds__(TRK_DEV_TMAX) void trk_epoch_kernel(EpochArgs a) {
         if (tid < T) { L.age[tid] += 1; L.tsu[tid] += 1; L.mdet[tid] = -1; }
         for (int t = wv; t < T; t += NW) {
             const int slot = L.slot[t];
-            kf_predict_wave(a.cov + (size_t)slot * 64, a.mean + (size_t)slot * 8, lane);
+            kf_predict_wave(kP(slot), kM(slot), lane);
         }
         __threadfence_block();
         __syncthreads();
+        PHASE(1);
 
         // ---- cost rows of every track: squared Mahalanobis (kalman_filter.py:206-249), 1 - IoU (matching.py:13-106),
-        //      min-over-gallery cosine distance (matching.py:144-217) out of the epoch's SM / GRAM tables
+        //      min-over-gallery cosine distance (matching.py:144-217) out of the epoch's SM / GRAM tables.
+        //      The three [T, n] matrices sit in LDS when they fit beside the assignment sub-matrix, else in HBM scratch.
+        const int tn = T * n;
+        const bool cost_lds = !a.out.dbg_tn && 4 * tn <= L.arena_floats;
+        float* c_app = cost_lds ? L.arena : a.scr.cost;
+        float* c_maha = cost_lds ? L.arena + tn : a.scr.cost + (size_t)TRK_DEV_TMAX * TRK_DEV_NMAX;
+        float* c_iou = cost_lds ? L.arena + 2 * tn : a.scr.cost + 2 * (size_t)TRK_DEV_TMAX * TRK_DEV_NMAX;
+        const FrameCosts fc{c_app, c_maha, c_iou, cost_lds ? L.arena + 3 * tn : L.arena, cost_lds ? L.arena_floats - 3 * tn : L.arena_floats};
         if (T > 0 && n > 0) {
-            for (int t = wv; t < T; t += NW) {
+            for (int e = tid; e < tn; e += BT) {                   // appearance: one (track, detection) pair per thread, all loads of a pair in flight together
+                const int t = e / n, j = e - t * n;
+                float v = kInfty;                                  // empty gallery / featureless detection (matching.py:148,175)
+                if (L.glen[t] > 0 && L.dhas[j]) {
+                    // gallery of the track inside the epoch: rows older than the epoch that survived `ev` evictions (suffix minimum
+                    // SM[ev]) + the rows the epoch appended (never evicted inside it: k <= gmax)
+                    const int napp = L.napp[t], smr = L.sm[t], g0 = L.glen0[t];
+                    const int ev = max(0, g0 + napp - gmax);
+                    const int erow = erow0 + j;
+                    float x[TRK_KMAX + 1];
+                    x[TRK_KMAX] = (smr >= 0 && ev < g0) ? a.scr.sm[((size_t)smr * (TRK_KMAX + 1) + ev) * a.dn_pad + erow] : kBig;
+                    const unsigned short* nr_ = L.newrow + t * TRK_KMAX;
+#pragma unroll
+                    for (int q = 0; q < TRK_KMAX; ++q) x[q] = q < napp ? a.scr.gram[(size_t)nr_[q] * a.dn_pad + erow] : kBig;
+                    float mn = x[TRK_KMAX];
+#pragma unroll
+                    for (int q = 0; q < TRK_KMAX; ++q) mn = fminf(mn, x[q]);
+                    v = mn;
+                }
+                c_app[e] = v;
+            }
+            for (int t = wv; t < T; t += NW) {                     // gating distance + IoU: one wave per track, lanes over the detections
                 const int slot = L.slot[t];
-                const float* P = a.cov + (size_t)slot * 64;
-                const float* m = a.mean + (size_t)slot * 8;
+                const float* P = kP(slot);
+                const float* m = kM(slot);
                 float S[4][4], Lc[4][4];
                 innovation_cov(P, m[3], S);
                 const bool ok = cholesky<4>(S, Lc);
@@ -477,12 +608,6 @@ __global__ __launch_bounds__(TRK_DEV_TMAX) void trk_epoch_kernel(EpochArgs a) {
                 if (bh > 0.f) bw = m2 * bh; else bh = fmaxf(0.f, bh);
                 const float bx = m0 - bw / 2.0f, by = m1 - bh / 2.0f;
                 const float brx = bx + bw, bry = by + bh;
-                // gallery of the track inside the epoch: rows older than the epoch that survived `ev` evictions (suffix minimum
-                // SM[ev]) + the rows the epoch appended (never evicted inside it: k <= gmax)
-                const int glen = L.glen[t], napp = L.napp[t], smr = L.sm[t], g0 = L.glen0[t];
-                const int ev = max(0, g0 + napp - gmax);
-                const float* smrow = (smr >= 0 && ev < g0) ? a.scr.sm + ((size_t)smr * (TRK_KMAX + 1) + ev) * a.dn_pad : nullptr;
-                const unsigned short* nr_ = L.newrow + t * TRK_KMAX;
                 for (int j = lane; j < n; j += 64) {
                     const float* z = L.xyah + j * 4;
                     float d[4], y[4];
@@ -501,19 +626,12 @@ __global__ __launch_bounds__(TRK_DEV_TMAX) void trk_epoch_kernel(EpochArgs a) {
                     const float inter = iw * ih;
                     const float uni = bw * bh + c[2] * c[3] - inter;
                     c_iou[o] = 1.0f - inter / fmaxf(uni, 1e-7f);
-                    float v = kInfty;                              // empty gallery / featureless detection (matching.py:148,175)
-                    if (glen > 0 && L.dhas[j]) {
-                        const int erow = erow0 + j;
-                        float mn = smrow ? smrow[erow] : kBig;
-                        for (int q = 0; q < napp; ++q) mn = fminf(mn, a.scr.gram[(size_t)nr_[q] * a.dn_pad + erow]);
-                        v = mn;
-                    }
-                    c_app[o] = v;
                 }
             }
         }
         __threadfence_block();
         __syncthreads();
+        PHASE(2);
 
         // ---- matching cascade over time_since_update = 1 .. max_age (linear_assignment.py:91-157)
         int nund = n;
@@ -527,20 +645,22 @@ __global__ __launch_bounds__(TRK_DEV_TMAX) void trk_epoch_kernel(EpochArgs a) {
                 if (lv == 0x7fffffff) break;
                 cur = lv;
                 const int nr = block_compact(conf_t && L.tsu[tid] == lv, tid, L.rows, L.wcnt);
-                match_block(L, a, L.und, nr, nund, n, false, &s_err);
+                match_block(L, a, fc, L.und, nr, nund, n, false, &s_err);
                 if (s_err) break;
                 const int dj = tid < nund ? L.und[tid] : -1;
                 nund = block_compact(dj >= 0 && L.mtrk[dj] < 0, dj, L.und, L.wcnt);
             }
+            PHASE(3);
             // ---- IoU stage: tentative tracks, then confirmed tracks that missed exactly this frame (tracker_core.py:138-166)
             if (!s_err) {
                 const int n1 = block_compact(tid < T && L.state[tid] == 1, tid, L.rows, L.wcnt);
                 const int n2 = block_compact(tid < T && L.state[tid] == 2 && L.mdet[tid] < 0 && L.tsu[tid] == 1, tid, L.rows + n1, L.wcnt);
-                if (n1 + n2 > 0 && nund > 0) match_block(L, a, L.und, n1 + n2, nund, n, true, &s_err);
+                if (n1 + n2 > 0 && nund > 0) match_block(L, a, fc, L.und, n1 + n2, nund, n, true, &s_err);
             }
         }
         __syncthreads();
         if (s_err) { err_frame = f; break; }
+        PHASE(4);
 
         // ---- lifecycle (tracker_core.py:63-81): unmatched detections in ascending order become new tracks
         const int U = block_compact(tid < n && L.mtrk[tid] < 0, tid, L.cols, L.wcnt);
@@ -578,7 +698,7 @@ __global__ __launch_bounds__(TRK_DEV_TMAX) void trk_epoch_kernel(EpochArgs a) {
             const int det = L.mdet[t];
             if (det < 0) continue;
             const int slot = L.slot[t];
-            const float mi = kf_update_wave(a.cov + (size_t)slot * 64, a.mean + (size_t)slot * 8, L.xyah + det * 4, lane);
+            const float mi = kf_update_wave(kP(slot), kM(slot), L.xyah + det * 4, lane);
             const float cx = __shfl(mi, 0), cy = __shfl(mi, 8), ar = __shfl(mi, 16), hh = __shfl(mi, 24);
             if (lane == 0) {
                 float w = 0.f, h2 = hh;
@@ -590,7 +710,7 @@ __global__ __launch_bounds__(TRK_DEV_TMAX) void trk_epoch_kernel(EpochArgs a) {
         for (int r = wv; r < U; r += NW) {                         // _initiate_track, tracker_core.py:180-194
             const int det = L.cols[r];
             const int slot = L.free_slots[nfree - 1 - r];
-            kf_initiate_wave(a.cov + (size_t)slot * 64, a.mean + (size_t)slot * 8, L.xyah + det * 4, lane);
+            kf_initiate_wave(kP(slot), kM(slot), L.xyah + det * 4, lane);
             if (lane == 0) {
                 const int ti = T + r;
                 L.id[ti] = next_id + r, L.state[ti] = 1, L.hits[ti] = 1, L.age[ti] = 1, L.tsu[ti] = 0;
@@ -612,6 +732,7 @@ __global__ __launch_bounds__(TRK_DEV_TMAX) void trk_epoch_kernel(EpochArgs a) {
         if (a.out.dbg_tn && fi == a.k - 1 && tid == 0) { a.out.dbg_tn[0] = T; a.out.dbg_tn[1] = n; }
         __threadfence_block();
         __syncthreads();
+        PHASE(5);
 
         // ---- outputs: confirmed tracks updated in this frame, list order (deepsort_tracker.py:126-141)
         {
@@ -657,22 +778,40 @@ __global__ __launch_bounds__(TRK_DEV_TMAX) void trk_epoch_kernel(EpochArgs a) {
             T = Tk;
             __syncthreads();
         }
+        PHASE(6);
     }
 
-    // ---- gallery rows appended in this epoch: raw row (export) + unit row (cost kernels), one ring position each
+    // ---- gallery rows appended in this epoch: raw row (export) + unit row (cost kernels), one ring position each.
+    //      16-byte copies, four rows per wave in flight (dim % 4 == 0 on this path)
     __syncthreads();
     {
         const int na = s_napp_total;
-        const float* fr = a.dets.feat + (size_t)a.d_begin * dim;
-        const float* fn = a.dets.feat_n + (size_t)a.d_begin * dim;
-        for (int i = wv; i < na; i += NW) {
-            const int slot = a.scr.appends[i * 3], pos = a.scr.appends[i * 3 + 1], er = a.scr.appends[i * 3 + 2];
-            const size_t dst = ((size_t)slot * gmax + pos) * dim, src = (size_t)er * dim;
-            for (int c = lane; c < dim; c += 64) {
-                a.gal_raw[dst + c] = fr[src + c];
-                a.gal_n[dst + c] = fn[src + c];
+        const floatx4* fr = reinterpret_cast<const floatx4*>(a.dets.feat + (size_t)a.d_begin * dim);
+        const floatx4* fn = reinterpret_cast<const floatx4*>(a.dets.feat_n + (size_t)a.d_begin * dim);
+        floatx4* graw = reinterpret_cast<floatx4*>(a.gal_raw);
+        floatx4* gn = reinterpret_cast<floatx4*>(a.gal_n);
+        const int d4 = dim >> 2;
+        for (int i0 = wv * 4; i0 < na; i0 += NW * 4) {
+            for (int c = lane; c < d4; c += 64) {
+                floatx4 xr[4], xn[4];
+                size_t dst[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = min(i0 + u, na - 1);
+                    const int slot = a.scr.appends[i * 3], pos = a.scr.appends[i * 3 + 1], er = a.scr.appends[i * 3 + 2];
+                    dst[u] = ((size_t)slot * gmax + pos) * d4 + c;
+                    xr[u] = fr[(size_t)er * d4 + c];
+                    xn[u] = fn[(size_t)er * d4 + c];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (i0 + u < na) { graw[dst[u]] = xr[u]; gn[dst[u]] = xn[u]; }
+                }
             }
         }
+        const int ns = min(KF_SLOTS, a.prm.cap);                  // Kalman state of the cached slots back to HBM
+        for (int e = tid; e < ns * 64; e += BT) a.cov[e] = L.kf[(e >> 6) * 72 + (e & 63)];
+        for (int e = tid; e < ns * 8; e += BT) a.mean[e] = L.kf[(e >> 3) * 72 + 64 + (e & 7)];
     }
     // ---- write the table back
     if (tid < T) {
@@ -682,6 +821,7 @@ __global__ __launch_bounds__(TRK_DEV_TMAX) void trk_epoch_kernel(EpochArgs a) {
         a.trk[tid] = t;
     }
     for (int i = tid; i < nfree; i += BT) a.free_slots[i] = L.free_slots[i];
+    PHASE(7);
     if (tid == 0) {
         a.hdr->n_tracks = T, a.hdr->next_id = next_id, a.hdr->n_free = nfree;
         a.hdr->err = s_err, a.hdr->err_frame = err_frame, a.hdr->frames_done = fi;
@@ -698,6 +838,8 @@ __global__ __launch_bounds__(TRK_DEV_TMAX) void trk_cascade_test_kernel(EpochArg
     const Lds L = lds_carve(smem, a.prm.cap, a.nmax, lds_bytes);
     const int tid = threadIdx.x;
     if (tid == 0) s_err = 0;
+    const size_t stride = (size_t)TRK_DEV_TMAX * TRK_DEV_NMAX;
+    const FrameCosts fc{a.scr.cost, a.scr.cost + stride, a.scr.cost + 2 * stride, L.arena, L.arena_floats};
     if (tid < T) { L.state[tid] = state[tid]; L.tsu[tid] = tsu[tid]; L.mdet[tid] = -1; }
     if (tid < n) { L.mtrk[tid] = -1; L.und[tid] = tid; }
     __syncthreads();
@@ -712,7 +854,7 @@ __global__ __launch_bounds__(TRK_DEV_TMAX) void trk_cascade_test_kernel(EpochArg
             if (lv == 0x7fffffff) break;
             cur = lv;
             const int nr = block_compact(conf_t && L.tsu[tid] == lv, tid, L.rows, L.wcnt);
-            match_block(L, a, L.und, nr, nund, n, false, &s_err);
+            match_block(L, a, fc, L.und, nr, nund, n, false, &s_err);
             if (s_err) break;
             const int dj = tid < nund ? L.und[tid] : -1;
             nund = block_compact(dj >= 0 && L.mtrk[dj] < 0, dj, L.und, L.wcnt);
@@ -720,12 +862,43 @@ __global__ __launch_bounds__(TRK_DEV_TMAX) void trk_cascade_test_kernel(EpochArg
         if (!s_err && !stage1_only) {
             const int n1 = block_compact(tid < T && L.state[tid] == 1, tid, L.rows, L.wcnt);
             const int n2 = block_compact(tid < T && L.state[tid] == 2 && L.mdet[tid] < 0 && L.tsu[tid] == 1, tid, L.rows + n1, L.wcnt);
-            if (n1 + n2 > 0 && nund > 0) match_block(L, a, L.und, n1 + n2, nund, n, true, &s_err);
+            if (n1 + n2 > 0 && nund > 0) match_block(L, a, fc, L.und, n1 + n2, nund, n, true, &s_err);
         }
     }
     __syncthreads();
     if (tid < T) out_mdet[tid] = L.mdet[tid];
     if (tid == 0) *out_err = s_err;
+}
+
+// ------------------------------------------------------------------------------------------------ cross-camera gallery shard
+// configs[4]: fp32 [t_max, 2 + dim] = (valid, track id, unit embedding of the newest gallery row) of the first
+// t_max confirmed tracks in list order, straight from the HBM-resident table. One block; rows are copied 16 bytes per lane.
+__global__ __launch_bounds__(TRK_DEV_TMAX) void gallery_shard_kernel(const DevTrkHdr* __restrict__ hdr, const DevTrack* __restrict__ trk,
+                                                                    const float* __restrict__ gal_n, int gmax, int dim, float* __restrict__ out, int t_max) {
+    __shared__ int wcnt[NW + 8];
+    __shared__ int sel[TRK_DEV_TMAX];
+    const int tid = threadIdx.x, T = hdr->n_tracks;
+    const bool ok = tid < T && trk[tid].state == 2 && trk[tid].glen > 0;
+    const int cnt = min(block_compact(ok, tid, sel, wcnt), t_max);
+    const int w = 2 + dim;
+    for (int r = tid >> 6; r < t_max; r += NW) {
+        float* o = out + (size_t)r * w;
+        if (r < cnt) {
+            const DevTrack t = trk[sel[r]];
+            int pos = t.ghead + t.glen - 1;
+            if (pos >= gmax) pos -= gmax;
+            const float* g = gal_n + ((size_t)t.slot * gmax + pos) * dim;
+            for (int c = tid & 63; c < dim; c += 64) o[2 + c] = g[c];
+            if ((tid & 63) == 0) { o[0] = 1.0f; o[1] = (float)t.id; }
+        } else if ((tid & 63) == 0) {
+            o[0] = 0.0f; o[1] = 0.0f;
+        }
+    }
+}
+
+void launch_gallery_shard(const DevTrkHdr* hdr, const DevTrack* trk, const float* gal_n, int gmax, int dim, float* out, int t_max, hipStream_t s) {
+    hipLaunchKernelGGL(gallery_shard_kernel, dim3(1), dim3(TRK_DEV_TMAX), 0, s, hdr, trk, gal_n, gmax, dim, out, t_max);
+    KCHECK();
 }
 
 // ------------------------------------------------------------------------------------------------ launchers
@@ -749,6 +922,28 @@ static void epoch_attr() {
     }
 }
 
+// AICAM_TRK_PHASES=1: per-phase shader-clock totals of the epoch kernel, printed at process exit
+namespace {
+struct PhaseProf {
+    long long* d = nullptr;
+    long launches = 0, frames = 0;
+    PhaseProf() {
+        if (getenv("AICAM_TRK_PHASES")) { (void)hipMalloc((void**)&d, 16 * 8); (void)hipMemset(d, 0, 16 * 8); }
+    }
+    ~PhaseProf() {
+        if (!d) return;
+        long long h[16];
+        (void)hipDeviceSynchronize();
+        if (hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess || !frames) return;
+        static const char* nm[8] = {"load table", "dets+predict", "cost rows", "cascade", "IoU stage", "lifecycle+KF update", "outputs+prune", "epoch tail"};
+        fprintf(stderr, "[trk_phases] %ld epoch launches, %ld frames; shader cycles per frame:", launches, frames);
+        for (int i = 0; i < 8; ++i) fprintf(stderr, " %s %.0f |", nm[i], (double)h[i] / frames);
+        fprintf(stderr, "\n");
+    }
+};
+PhaseProf g_phase;
+}  // namespace
+
 void launch_trk_epoch(DevTrkHdr* hdr, DevTrack* trk, int* free_slots, float* mean, float* cov, float* gal_raw, float* gal_n,
                       const TrkDevParams& prm, const EpochDets& dets, int f0, int k, int d_begin, int dn_pad, int nmax, int has_sm,
                       const EpochScratch& scr, const EpochOut& out, hipStream_t s) {
@@ -758,6 +953,8 @@ void launch_trk_epoch(DevTrkHdr* hdr, DevTrack* trk, int* free_slots, float* mea
     a.hdr = hdr, a.trk = trk, a.free_slots = free_slots, a.mean = mean, a.cov = cov, a.gal_raw = gal_raw, a.gal_n = gal_n;
     a.prm = prm, a.dets = dets, a.f0 = f0, a.k = k, a.d_begin = d_begin, a.dn_pad = dn_pad, a.nmax = std::max(nmax, 1), a.has_sm = has_sm;
     a.scr = scr, a.out = out, a.lds_bytes = epoch_lds_bytes();
+    a.prof = g_phase.d;
+    g_phase.launches += 1, g_phase.frames += k;
     hipLaunchKernelGGL(trk_epoch_kernel, dim3(1), dim3(TRK_DEV_TMAX), (size_t)epoch_lds_bytes(), s, a);
     KCHECK();
 }

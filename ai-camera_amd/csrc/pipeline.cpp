@@ -70,6 +70,20 @@ struct Pipeline {
     long n_frames_done = 0;
     bool dev_assoc = getenv("AICAM_TRK_HOST") == nullptr;   // association on the device, k frames per launch (aic_pipeline_option("device_assoc"))
     bool taper = getenv("AICAM_NO_TAPER") == nullptr;   // aic_pipeline_option("taper")
+    // configs[4]: cross-camera gallery exchange. The pipeline packs a shard of the stream's confirmed tracks on
+    // the tracker stream every x_every launch groups; a consumer thread (ai-camera_amd/distributed.py) all-gathers it over
+    // RCCL on the exchange stream. Double-buffered: the pipeline only ever waits if the consumer is two exchanges behind.
+    float* x_shard[2] = {nullptr, nullptr};
+    int x_tmax = 0, x_every = 1;
+    long x_groups = 0, x_packed = 0, x_done = 0;
+    hipStream_t s_xchg = nullptr;
+    hipEvent_t ev_shard[2] = {nullptr, nullptr};
+    std::mutex x_mu;
+    std::condition_variable x_cv;
+    int group_frames = 0;            // frames per launch group (aic_pipeline_option("group_frames")); 0 = prm.batch
+    struct GroupTime { int frames; double submit, done; };
+    std::vector<GroupTime> group_times;   // per launch group of the last call: stage A start -> track tuples on the host
+    std::vector<double> submit_t;
     int last_chunk = -1;             // chunk context of the most recently finished launch group (aic_pipeline_group_embeddings)
     long n_grow = 0;                 // launch groups whose crop count outgrew the buffers sized from max_persons
     long n_rows_clipped = 0;         // frames with more confirmed tracks than the caller's max_persons output rows
@@ -349,6 +363,16 @@ struct Pipeline {
                      mp, nullptr, nullptr};
         trk.run_epochs(dets, reinterpret_cast<const int*>(c.h_meta.p + c.m_n), reinterpret_cast<const int*>(c.h_meta.p + c.m_d0), c.frames, out, s);
         HIP_CHECK(hipMemcpyAsync(c.h_out.p, c.d_out.p, obytes, hipMemcpyDeviceToHost, s));
+        if (x_shard[0] && (x_groups++ % x_every) == 0) {       // gallery shard of this stream, ordered behind the group's epochs
+            std::unique_lock<std::mutex> lk(x_mu);
+            x_cv.wait(lk, [&] { return x_done >= x_packed - 1; });   // the buffer's previous exchange has been consumed
+            const int b = (int)(x_packed & 1);
+            launch_gallery_shard(trk.tbl_hdr(), trk.tbl_trk(), trk.d_gal_n.p, trk.gmax, trk.dim, x_shard[b], x_tmax, s);
+            HIP_CHECK(hipEventRecord(ev_shard[b], s));
+            x_packed += 1;
+            lk.unlock();
+            x_cv.notify_all();
+        }
         const double t1 = now();
         t_track += t1 - t0;                                    // host time of the association: planning + launches
         HIP_CHECK(hipStreamSynchronize(s));
@@ -392,10 +416,11 @@ struct Pipeline {
         // final group cannot overlap any GPU work, so a short final group shortens the un-overlapped tail of the call.
         std::vector<int> goff, glen;
         {
+            const int gf = group_frames > 0 ? std::min(group_frames, prm.batch) : prm.batch;
             for (int pass = 0; pass < passes; ++pass) {
                 const bool last = pass == passes - 1;
                 int done = 0;
-                while (count - done > prm.batch) { goff.push_back(done); glen.push_back(prm.batch); done += prm.batch; }
+                while (count - done > gf) { goff.push_back(done); glen.push_back(gf); done += gf; }
                 int rem = count - done;
                 while (taper && last && rem > 16) {
                     const int g = std::max(16, rem / 2);
@@ -406,6 +431,8 @@ struct Pipeline {
             }
         }
         const int nchunks = (int)goff.size();
+        group_times.clear();
+        submit_t.assign(nchunks, 0.0);
         // Two host threads: the producer issues the detection/ReID launch groups (stage A, ~100 launches
         // per group), this thread walks the frames of each finished group through the tracker (stage B:
         // small launches + syncs). A chunk context is reissued only after stage B released it.
@@ -421,6 +448,7 @@ struct Pipeline {
                         std::unique_lock<std::mutex> lk(mu);
                         cv.wait(lk, [&] { return k < consumed + NCK; });
                     }
+                    submit_t[k] = now();
                     stage_a(ck[k % NCK], slot + goff[k], glen[k]);
                     {
                         std::lock_guard<std::mutex> lk(mu);
@@ -450,6 +478,7 @@ struct Pipeline {
                     trk.dev_assoc = false;
                     stage_b(ck[k % NCK], goff[k], n_tracks, tracks6, track_conf, n_dets, det_boxes, det_scores, det_labels);
                 }
+                group_times.push_back(GroupTime{glen[k], submit_t[k], now()});
                 {
                     std::lock_guard<std::mutex> lk(mu);
                     consumed = k + 1;
@@ -537,13 +566,32 @@ int aic_pipeline_run_passes(aic_pipeline* p, int slot, int count, int passes, in
 
 int aic_pipeline_run_from_host(aic_pipeline* p, const uint8_t* frames_bgr, int slot, int count, int32_t* n_tracks,
                                int32_t* tracks6, float* track_conf, int32_t* n_dets) {
+    return aic_pipeline_run_from_host_passes(p, frames_bgr, slot, count, 1, n_tracks, tracks6, track_conf, n_dets);
+}
+
+int aic_pipeline_group_times(aic_pipeline* p, int32_t* frames, double* submit_s, double* done_s, int cap, int32_t* n) {
+    return guarded([&] {
+        AIC_REQUIRE(p && n, AIC_ERR_INVALID, "NULL argument");
+        const auto& g = p->p.group_times;
+        *n = (int32_t)g.size();
+        AIC_REQUIRE((int)g.size() <= cap || (!frames && !submit_s && !done_s), AIC_ERR_CAPACITY, "group capacity too small");
+        for (size_t i = 0; i < g.size(); ++i) {
+            if (frames) frames[i] = g[i].frames;
+            if (submit_s) submit_s[i] = g[i].submit;
+            if (done_s) done_s[i] = g[i].done;
+        }
+    });
+}
+
+int aic_pipeline_run_from_host_passes(aic_pipeline* p, const uint8_t* frames_bgr, int slot, int count, int passes, int32_t* n_tracks,
+                                      int32_t* tracks6, float* track_conf, int32_t* n_dets) {
     return guarded([&] {
         AIC_REQUIRE(p && frames_bgr, AIC_ERR_INVALID, "NULL argument");
         Pipeline& q = p->p;
         q.host_frames = frames_bgr;
         q.host_slot0 = slot;
         try {
-            q.run(slot, count, n_tracks, tracks6, track_conf, n_dets, nullptr, nullptr, nullptr);
+            q.run(slot, count, n_tracks, tracks6, track_conf, n_dets, nullptr, nullptr, nullptr, passes);
         } catch (...) {
             q.host_frames = nullptr;
             throw;
@@ -584,12 +632,65 @@ int aic_pipeline_stats(aic_pipeline* p, double* issue_s, double* wait_s, double*
     });
 }
 
+int aic_pipeline_exchange_enable(aic_pipeline* p, float* shard0_dev, float* shard1_dev, int t_max, int every_groups) {
+    return guarded([&] {
+        AIC_REQUIRE(p, AIC_ERR_INVALID, "NULL pipeline");
+        Pipeline& q = p->p;
+        q.dev->use();
+        std::lock_guard<std::mutex> lk(q.x_mu);
+        if (!shard0_dev) { q.x_shard[0] = q.x_shard[1] = nullptr; return; }
+        AIC_REQUIRE(shard1_dev && t_max > 0 && t_max <= TRK_DEV_TMAX && every_groups >= 1, AIC_ERR_INVALID, "bad exchange arguments");
+        AIC_REQUIRE(q.dev_assoc && q.trk.dev_capable(), AIC_ERR_INVALID, "the gallery exchange reads the HBM-resident track table (device association)");
+        if (!q.s_xchg) {
+            HIP_CHECK(hipStreamCreateWithFlags(&q.s_xchg, hipStreamNonBlocking));
+            for (auto& e : q.ev_shard) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        }
+        q.x_shard[0] = shard0_dev, q.x_shard[1] = shard1_dev, q.x_tmax = t_max, q.x_every = every_groups;
+        q.x_groups = q.x_packed = q.x_done = 0;
+    });
+}
+
+int aic_pipeline_exchange_stream(aic_pipeline* p, void** stream) {
+    return guarded([&] {
+        AIC_REQUIRE(p && stream && p->p.s_xchg, AIC_ERR_INVALID, "exchange not enabled");
+        *stream = (void*)p->p.s_xchg;
+    });
+}
+
+int aic_pipeline_exchange_wait(aic_pipeline* p, int64_t seq, int timeout_ms, int32_t* buffer, int32_t* ready) {
+    return guarded([&] {
+        AIC_REQUIRE(p && buffer && ready, AIC_ERR_INVALID, "NULL argument");
+        Pipeline& q = p->p;
+        std::unique_lock<std::mutex> lk(q.x_mu);
+        *ready = q.x_cv.wait_for(lk, std::chrono::milliseconds(timeout_ms), [&] { return q.x_packed > seq; }) ? 1 : 0;
+        if (!*ready) return;
+        *buffer = (int32_t)(seq & 1);
+        q.dev->use();
+        HIP_CHECK(hipStreamWaitEvent(q.s_xchg, q.ev_shard[seq & 1], 0));   // the collective reads the shard behind the pack kernel
+    });
+}
+
+int aic_pipeline_exchange_done(aic_pipeline* p, int64_t seq) {
+    return guarded([&] {
+        AIC_REQUIRE(p, AIC_ERR_INVALID, "NULL pipeline");
+        {
+            std::lock_guard<std::mutex> lk(p->p.x_mu);
+            p->p.x_done = std::max<long>(p->p.x_done, (long)seq + 1);
+        }
+        p->p.x_cv.notify_all();
+    });
+}
+
 int aic_pipeline_option(aic_pipeline* p, const char* key, int value) {
     return guarded([&] {
         AIC_REQUIRE(p && key, AIC_ERR_INVALID, "NULL argument");
         const std::string k(key);
         if (k == "taper") p->p.taper = value != 0;
         else if (k == "device_assoc") p->p.dev_assoc = value != 0;
+        else if (k == "group_frames") {
+            AIC_REQUIRE(value >= 0 && value <= p->p.prm.batch, AIC_ERR_INVALID, "group_frames must be in 0..batch");
+            p->p.group_frames = value;
+        }
         else AIC_REQUIRE(false, AIC_ERR_INVALID, "unknown pipeline option: " + k);
     });
 }

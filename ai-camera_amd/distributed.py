@@ -5,7 +5,11 @@ work): every K frames each rank contributes a fixed-shape shard of its confirmed
 latest embeddings; RCCL (backend "nccl") over xGMI on GPUs, gloo on CPU for the tests.
 
 The message is tiny (T_max x D fp32 = 256 KiB per rank) and therefore latency-bound: one
-all_gather_into_tensor of the packed shard per exchange -- never per track, never per frame."""
+all_gather_into_tensor of the packed shard per exchange -- never per track, never per frame.
+
+Host placement (8 ranks on one node): `bind_rank_to_gpu_numa` pins a rank's threads to the cores of
+the NUMA node its GPU hangs off BEFORE the first GPU call, so the page-locked buffers the library
+allocates afterwards (and the clip the bench registers) are node-local and ranks do not share cores."""
 from __future__ import annotations
 
 import os
@@ -35,6 +39,66 @@ def init_process_group(backend=None):
     if not dist.is_initialized():
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return dist
+
+
+def _cpulist(text):
+    out = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        out.extend(range(int(a), int(b or a) + 1))
+    return out
+
+
+def gpu_numa_nodes():
+    """NUMA node of every AMD GPU function on the PCI bus, in bus-address order (the order HIP enumerates devices in),
+    read from sysfs only: no GPU call, no driver context."""
+    nodes = []
+    base = "/sys/bus/pci/devices"
+    try:
+        for dev in sorted(os.listdir(base)):
+            d = os.path.join(base, dev)
+            try:
+                if open(os.path.join(d, "vendor")).read().strip() != "0x1002":
+                    continue
+                cls = open(os.path.join(d, "class")).read().strip()
+                if not (cls.startswith("0x0302") or cls.startswith("0x0380") or cls.startswith("0x1200")):
+                    continue          # 3D controller / display / processing accelerator
+                nodes.append(int(open(os.path.join(d, "numa_node")).read().strip()))
+            except OSError:
+                continue
+    except OSError:
+        pass
+    return nodes
+
+
+def bind_rank_to_gpu_numa(local_rank: int, world: int):
+    """os.sched_setaffinity for this process (and every thread it starts later): the allowed cores of the GPU's NUMA node,
+    split among the ranks that share the node; without NUMA information an even slice of the allowed cores.  Call before the
+    first GPU call.  Returns a description for the bench line; never raises (a rehearsal on a laptop must still run)."""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        return {"bound": False, "reason": "no sched_getaffinity"}
+    if world <= 1 and os.environ.get("AICAM_BIND_SINGLE") is None:
+        return {"bound": False, "cores": len(allowed), "reason": "single rank: the cores the box grants are all ours"}
+    try:
+        nodes = gpu_numa_nodes()
+        node = nodes[local_rank] if local_rank < len(nodes) else -1
+        mine, sharers, my_pos = allowed, world, local_rank
+        if node >= 0:
+            cl = set(_cpulist(open(f"/sys/devices/system/node/node{node}/cpulist").read()))
+            local = [c for c in allowed if c in cl]
+            if local:
+                same = [r for r in range(world) if r < len(nodes) and nodes[r] == node]
+                mine, sharers, my_pos = local, max(len(same), 1), same.index(local_rank) if local_rank in same else 0
+        per = max(1, len(mine) // sharers)
+        cores = mine[my_pos * per:(my_pos + 1) * per] or mine
+        os.sched_setaffinity(0, cores)
+        return {"bound": True, "numa_node": node, "cores": len(cores), "first_core": cores[0], "last_core": cores[-1]}
+    except Exception as e:            # noqa: BLE001 -- placement is an optimisation, never a failure
+        return {"bound": False, "reason": str(e)}
 
 
 def stream_seed(base_seed: int, rank: int) -> int:
@@ -126,3 +190,124 @@ def reduce_sum(value: float) -> float:
         t = t.cuda()
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
+
+
+class _Handle:
+    """Pending exchange: wait_numpy() -> [world, t_max, 2 + dim] on the host (tests); wait() -> the device/CPU tensor."""
+
+    def __init__(self, work, out, world):
+        self.work, self.out, self.world = work, out, world
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+        return self.out.view(self.world, -1, self.out.shape[-1])
+
+    def wait_numpy(self):
+        return self.wait().cpu().numpy()
+
+
+class GalleryExchange:
+    """configs[4]: cross-camera ReID gallery all-gather, SURVEY.md §8(e) form.
+
+    * fixed shard fp32 [T_max = 128, 2 + dim] per rank (valid flag, track id, unit embedding of the track's newest gallery
+      row), packed ON THE DEVICE from the HBM-resident track table by the library (aic_pipeline_exchange_*): no host NumPy hop;
+    * one `all_gather_into_tensor` per exchange on a DEDICATED stream (torch.cuda.ExternalStream over the library's exchange
+      stream), asynchronous to the detection/ReID and tracker streams: the per-stream association never waits for it;
+    * consumed read-only by an annotation pass (closest track of another camera within the cosine threshold): per-stream
+      results are identical to configs[3].
+    Cadence: the batched pipeline advances a stream's tracker once per launch group (the frames of a group are associated
+    back to back after the group's ReID), so the shard can change once per group; `every_frames` is rounded up to whole
+    launch groups (with 8-frame launch groups it is every 8 frames).  Every rank performs the same number of exchanges
+    (frames / cadence), so the collectives pair up whatever the ranks' relative speed.
+    device=None: CPU tensors over gloo (tests, rehearsals); the same packing and collective, no pipeline."""
+
+    def __init__(self, dim, device=None, t_max=GALLERY_T_MAX):
+        import torch
+        import torch.distributed as dist
+        self.dim, self.t_max, self.device = int(dim), int(t_max), device
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.rank = dist.get_rank() if self.world > 1 else 0
+        self._thread = None
+        self.count = 0
+        self.last_annotation = None
+        dev = torch.device("cpu") if device is None else torch.device("cuda", device)
+        self._shards = [torch.zeros((self.t_max, 2 + self.dim), dtype=torch.float32, device=dev) for _ in range(2)]
+        self._gathered = torch.zeros((self.world * self.t_max, 2 + self.dim), dtype=torch.float32, device=dev)
+
+    def pack(self, track_ids, embeddings, rank=None):
+        import torch
+        return torch.from_numpy(pack_gallery_shard(track_ids, embeddings, self.dim, self.t_max))
+
+    def all_gather(self, shard, async_op=True):
+        import torch.distributed as dist
+        if self.world == 1:
+            self._gathered.copy_(shard)
+            return _Handle(None, self._gathered, 1)
+        work = dist.all_gather_into_tensor(self._gathered, shard.to(self._gathered.device), async_op=async_op)
+        return _Handle(work if async_op else None, self._gathered, self.world)
+
+    # ---- device path: driven by the pipeline's per-launch-group hook, on its own thread and stream
+    def start(self, pipe, every_frames=8):
+        import ctypes as C
+        import threading
+        import torch
+        from . import _lib as L
+        groups = max(1, -(-int(every_frames) // pipe.batch))       # ceil: whole launch groups
+        L.call("aic_pipeline_exchange_enable", pipe._h, C.c_void_p(self._shards[0].data_ptr()), C.c_void_p(self._shards[1].data_ptr()),
+               self.t_max, groups)
+        sp = C.c_void_p()
+        L.call("aic_pipeline_exchange_stream", pipe._h, C.byref(sp))
+        stream = torch.cuda.ExternalStream(sp.value, device=torch.device("cuda", self.device))
+        self._stop = False
+
+        def loop():
+            seq = 0
+            while True:
+                buf, got = C.c_int32(), C.c_int32()
+                L.call("aic_pipeline_exchange_wait", pipe._h, seq, 200, C.byref(buf), C.byref(got))   # the shard of exchange `seq` is packed (stream-ordered)
+                if not got.value:
+                    if self._stop:
+                        break
+                    continue
+                with torch.cuda.stream(stream):
+                    h = self.all_gather(self._shards[buf.value])
+                    g = h.wait()
+                    self.last_annotation = annotate_device(g, self.rank, self.world)
+                    stream.synchronize()
+                L.call("aic_pipeline_exchange_done", pipe._h, seq)
+                seq += 1
+                self.count = seq
+
+        self._thread = threading.Thread(target=loop, daemon=True)
+        self._thread.start()
+        self._pipe = pipe
+
+    def stop(self):
+        from . import _lib as L
+        if self._thread is None:
+            return self.count
+        self._stop = True
+        self._thread.join()
+        L.call("aic_pipeline_exchange_enable", self._pipe._h, None, None, 0, 0)
+        self._thread = None
+        return self.count
+
+
+def annotate_device(gathered, my_rank, world, max_cosine_distance=0.2):
+    """Annotation pass on the gathered shards (device tensors): for each valid local row the closest valid row of any OTHER
+    rank within the threshold -> fp32 [t_max, 3] (rank, track id, distance; rank = -1: none).  Plain tensor algebra on the
+    exchange stream: 128 x 896 x 512 MACs, off every critical path; per-stream association does not read it."""
+    import torch
+    mine = gathered[my_rank]
+    out = torch.full((mine.shape[0], 3), -1.0, dtype=torch.float32, device=gathered.device)
+    if world == 1:
+        return out
+    others = torch.cat([gathered[r] for r in range(world) if r != my_rank])
+    ranks = torch.cat([torch.full((gathered.shape[1],), float(r), device=gathered.device) for r in range(world) if r != my_rank])
+    d = (1.0 - mine[:, 2:] @ others[:, 2:].T).clamp_min(0.0)
+    d = torch.where((mine[:, :1] > 0.5) & (others[:, 0] > 0.5)[None, :], d, torch.full_like(d, 1e5))
+    best, j = d.min(1)
+    ok = best <= max_cosine_distance
+    out[ok, 0], out[ok, 1], out[ok, 2] = ranks[j[ok]], others[j[ok], 1], best[ok]
+    return out

@@ -125,6 +125,23 @@ class TrackingPipeline:
         L.call("aic_pipeline_run_from_host", self._h, L.ptr(f), int(slot), count, L.ptr(nt), L.ptr(rows), L.ptr(tconf), L.ptr(nd))
         return nt[:count], rows[:count], nd[:count]
 
+    def run_raw_from_host_passes(self, frames_bgr, passes, slot=0):
+        """The host clip looped `passes` times as ONE continuous stream (bench.py's timed region)."""
+        f = frames_bgr
+        assert f.dtype == np.uint8 and f.flags["C_CONTIGUOUS"] and f.shape[1:] == (self.frame_h, self.frame_w, 3)
+        count = len(f)
+        nt, rows, tconf, nd = self._raw_bufs()
+        L.call("aic_pipeline_run_from_host_passes", self._h, L.ptr(f), int(slot), count, int(passes), L.ptr(nt), L.ptr(rows), L.ptr(tconf), L.ptr(nd))
+        return nt[:count], rows[:count], nd[:count]
+
+    def group_times(self):
+        """Launch groups of the last call: (frames [G], latency seconds [G]) -- handed to the pipeline -> tuples on the host."""
+        n = C.c_int32()
+        L.call("aic_pipeline_group_times", self._h, None, None, None, 0, C.byref(n))
+        fr, a, b = np.zeros(n.value, np.int32), np.zeros(n.value, np.float64), np.zeros(n.value, np.float64)
+        L.call("aic_pipeline_group_times", self._h, L.ptr(fr), L.ptr(a), L.ptr(b), max(n.value, 1), C.byref(n))
+        return fr, b - a
+
     @staticmethod
     def pin(array):
         """Page-lock a NumPy buffer (hipHostRegister) so H2D runs at PCIe rate and truly asynchronously."""

@@ -10,19 +10,23 @@ scripts/export_trt_engines.sh:37), seeded weights, conf 0.3 / NMS IoU 0.5 / max_
 parameters of src/config.py:23-29.  The detector runs in full on every frame; crop/ReID/association
 consume the planted boxes (inject switch) because seeded weights cannot see them.
 
-A STEP = one pass of the hot path over one batch: the 2R frames resident in HBM (R rendered frames
-played forward then backward, so the planted persons move continuously and the tracker stays in
-steady state; defaults R = 1024, launch groups of 512 frames: 288 GB of HBM are there to be used -- 8.5 / 8.7 / 9.0 k
-frames/s at groups of 128 / 256 / 512).  The K timed steps are issued as ONE pipeline call
-(`aic_pipeline_run_passes`: the clip looped K times, streamed continuously -- the tracker tail of a call's last
-group cannot overlap GPU work, so per-step calls cost 4-5 %; `--per-step-calls` restores them).
-Timed span = the reference's own FPS span (detect + track,
-src/aicamera_tracker.py:175,201-207): frames already in HBM -> track tuples on the host.
+A STEP = one pass of the hot path over one batch: the 2R frames of the clip (R rendered frames played
+forward then backward, so the planted persons move continuously and the tracker stays in steady state;
+defaults R = 1024, launch groups of 512 frames).  The K timed steps are ONE pipeline call (the clip looped
+K times, streamed continuously).
 
-One JSON line on rank 0.  `roofline`: the dominant kernel conv_igemm (MFMA implicit GEMM), achieved =
+TIMED SPAN = the reference's own FPS span (src/aicamera_tracker.py:175,201-207 with the `.to(device)` of
+yolo_detector.py:91 inside): frame bytes in (page-locked) HOST memory -> track tuples on the host.  Every
+launch group's frames cross PCIe on a copy stream under the previous group's compute
+(aic_pipeline_run_from_host_passes).  The rate with the clip already resident in HBM is reported beside it
+(`config.hbm_resident_fps`), as are per-frame latency (handed to the pipeline -> tuples on the host, p50 / p99)
+and throughput for launch groups of 16 / 64 / 128 / 256 / 512 frames.
+
+One JSON line on rank 0.  `roofline`: the dominant kernel class conv_igemm (MFMA implicit GEMM), achieved =
 algorithmic conv FLOPs / its summed launch durations, HIP events on the launch stream, recorded over
 the timed region.  `cpu_baseline`: the oracle chain (torch-CPU fp32 nets + NumPy/SciPy DeepSORT) timed
-on this box's host cores on a bounded sample of the same workload (rank 0, N=1 only).
+on this box's host cores on a bounded sample of the same workload (rank 0, N=1 only): >= 200 frames on all
+cores with a per-stage split, plus a 1-thread leg.
 """
 import os
 
@@ -44,7 +48,7 @@ PEAK_F16_TFLOPS = 2500.0   # dense fp16 MFMA, MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3
 
 
-def parse():
+def parse(argv=None):
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=4)
@@ -58,12 +62,13 @@ def parse():
     p.add_argument("--dtype", type=str, default="fp16", choices=("fp16", "fp32"))
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--no-prof", action="store_true", help="do not record HIP events in the timed region")
-    p.add_argument("--cpu-frames", type=int, default=-1, help="frames of the CPU baseline sample (-1 auto, 0 skip)")
-    p.add_argument("--per-step-calls", action="store_true", help="one pipeline call per step (each call pays its own un-overlapped tracker tail) instead of one continuous call for the K timed steps")
-    p.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive (host-streamed) measurement")
+    p.add_argument("--cpu-frames", type=int, default=-1, help="frames of the all-cores CPU baseline leg (-1: 200, 0: skip)")
+    p.add_argument("--no-curve", action="store_true", help="skip the launch-group-size curve and the HBM-resident side measurement")
+    p.add_argument("--resident", action="store_true", help="time the clip resident in HBM instead of streaming it from host memory")
     p.add_argument("--backend", type=str, default="nccl", help="torch.distributed backend (nccl = RCCL over xGMI; gloo for CPU rehearsals)")
-    p.add_argument("--gallery-exchange", type=int, default=0, help="configs[4]: all-gather the ReID gallery every K steps")
-    return p.parse_args()
+    p.add_argument("--gallery-exchange", type=int, default=0, help="configs[4]: all-gather a ReID gallery shard every K frames of stream time (0 = off)")
+    p.add_argument("--dry-run", action="store_true", help="no GPU work: rank/affinity/rendezvous/reduction path only (CPU rehearsal of the N > 1 launch)")
+    return p.parse_args(argv)
 
 
 def host_cores():
@@ -81,47 +86,73 @@ def host_cores():
     return n if n <= 32 else 16
 
 
-def cpu_baseline(args, ypath, rpath, budget_s=20.0):
-    """Oracle chain on the host cores: bounded sample (about 10-30 s) of the same workload."""
+def cpu_baseline(args, ypath, rpath):
+    """Oracle chain on the host cores: all-cores leg (>= 200 frames, per-stage split) + a bounded 1-thread leg."""
     import torch
     syn = importlib.import_module("ai-camera_amd.synthetic")
-    cfg = importlib.import_module("ai-camera_amd.config")
     from oracle import deepsort_oracle as O, image_oracle as I, nets_oracle as N
     cores = host_cores()
-    torch.set_num_threads(cores)
     yo, ro = N.EngineOracle(ypath), N.EngineOracle(rpath)
     sc = syn.Scene(seed=args.seed, n_targets=args.persons, width=args.width, height=args.height)
-    trk = O.OracleTracker()
 
-    def one(frame, f):
-        x, ratios, pad = I.preprocess_yolo_input(frame)
-        dfl, cls = yo.yolo_head(torch.from_numpy(x))
-        b, ml, lab = yo.decode(dfl.numpy(), cls.numpy())
-        keep = N.nms(b[0], ml[0], lab[0], 0.3, 0.5, 300)
-        I.scale_bboxes(b[0][keep], frame.shape[:2], ratios, pad)
-        boxes, conf, cids, _ = sc.detections(f)                       # inject: planted boxes downstream
-        crops, valid = I.crops_to_batch(frame, boxes)
-        emb = ro.run(torch.from_numpy(crops))[ro.outputs[0][0]][:, :, 0, 0].numpy()
-        tlwh = np.stack([boxes[:, 0], boxes[:, 1], boxes[:, 2] - boxes[:, 0], boxes[:, 3] - boxes[:, 1]], 1)
-        trk.predict()
-        trk.update(list(tlwh), list(conf), ["person"] * len(boxes), [emb[i] if valid[i] else None for i in range(len(boxes))])
-        return trk.output_tuples()
+    def leg(threads, n_frames, budget_s):
+        torch.set_num_threads(threads)
+        trk = O.OracleTracker()
+        st = dict(letterbox=0.0, yolo=0.0, decode_nms=0.0, crops=0.0, reid=0.0, deepsort=0.0)
 
-    one(sc.render(0), 0)           # warm-up, not timed
-    n = args.cpu_frames
-    spent, done, f = 0.0, 0, 1
-    while True:
-        frame = sc.render(f)       # rendering is outside the reference's timed span
-        t = time.perf_counter()
-        one(frame, f)
-        spent += time.perf_counter() - t
-        done += 1
-        f += 1
-        if (n > 0 and done >= n) or (n < 0 and (spent > budget_s or done >= 64)):
-            break
+        def one(frame, f, acc):
+            t0 = time.perf_counter()
+            x, ratios, pad = I.preprocess_yolo_input(frame)
+            t1 = time.perf_counter()
+            dfl, cls = yo.yolo_head(torch.from_numpy(x))
+            t2 = time.perf_counter()
+            b, ml, lab = yo.decode(dfl.numpy(), cls.numpy())
+            keep = N.nms(b[0], ml[0], lab[0], 0.3, 0.5, 300)
+            I.scale_bboxes(b[0][keep], frame.shape[:2], ratios, pad)
+            t3 = time.perf_counter()
+            boxes, conf, cids, _ = sc.detections(f)                       # inject: planted boxes downstream
+            crops, valid = I.crops_to_batch(frame, boxes)
+            t4 = time.perf_counter()
+            emb = ro.run(torch.from_numpy(crops))[ro.outputs[0][0]][:, :, 0, 0].numpy()
+            t5 = time.perf_counter()
+            tlwh = np.stack([boxes[:, 0], boxes[:, 1], boxes[:, 2] - boxes[:, 0], boxes[:, 3] - boxes[:, 1]], 1)
+            trk.predict()
+            trk.update(list(tlwh), list(conf), ["person"] * len(boxes), [emb[i] if valid[i] else None for i in range(len(boxes))])
+            trk.output_tuples()
+            t6 = time.perf_counter()
+            if acc:
+                for k, d in zip(st, (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4, t6 - t5)):
+                    st[k] += d
+            return t6 - t0
+
+        one(sc.render(0), 0, False)           # warm-up, not timed
+        spent, done, f = 0.0, 0, 1
+        while done < n_frames and spent < budget_s:
+            frame = sc.render(f)              # rendering is outside the reference's timed span
+            spent += one(frame, f, True)
+            done += 1
+            f += 1
+        return done, spent, {k: round(1e3 * v / max(done, 1), 2) for k, v in st.items()}
+
+    n_all = 200 if args.cpu_frames < 0 else args.cpu_frames
+    done, spent, stages = leg(cores, n_all, 90.0)
+    d1, s1, stages1 = leg(1, 40, 15.0)
     return {"value": round(done / spent, 3), "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": f"{done} consecutive frames of the same synthetic stream after 1 warm-up frame "
-                      f"(torch-CPU fp32 YOLOv8{args.model}+ReID on {cores} threads, NumPy/SciPy DeepSORT with BLAS threads=1)"}
+                      f"(torch-CPU fp32 YOLOv8{args.model}+ReID on {cores} threads, NumPy/SciPy DeepSORT with BLAS threads=1)",
+            "ms_per_frame_by_stage": stages,
+            "one_thread": {"value": round(d1 / s1, 3), "unit": "frames/s", "cores": 1, "sample": f"{d1} frames (bounded at 15 s)",
+                           "ms_per_frame_by_stage": stages1}}
+
+
+def pct(lat_s, frames, q):
+    """Latency percentile over FRAMES (every frame of a launch group shares the group's latency)."""
+    if len(lat_s) == 0:
+        return None
+    order = np.argsort(lat_s)
+    cum = np.cumsum(np.asarray(frames)[order])
+    k = int(np.searchsorted(cum, q * cum[-1]))
+    return round(1e3 * float(np.asarray(lat_s)[order][min(k, len(order) - 1)]), 3)
 
 
 def main():
@@ -132,22 +163,45 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+    D = importlib.import_module("ai-camera_amd.distributed")
+    # Before any GPU call: pin this rank's host threads (producer, tracker/consumer, copy engine submissions) to the cores of
+    # the NUMA node its GPU hangs off, so 8 ranks do not share cores and page-locked buffers are allocated node-locally.
+    affinity = D.bind_rank_to_gpu_numa(local_rank, world)
     import torch
     import torch.distributed as dist
+
+    ndev = max(torch.cuda.device_count(), 1)
+    dev = local_rank % ndev            # one GPU per rank on a real node; rehearsals may share a GPU
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        kw = {}
+        if args.backend == "nccl" and not args.dry_run:
+            torch.cuda.set_device(dev)
+            kw["device_id"] = torch.device("cuda", dev)     # eager communicator on this rank's GPU (no lazy-init warning, no guess)
+        dist.init_process_group(backend=args.backend, rank=rank, world_size=world, **kw)
+    if args.dry_run:                   # CPU rehearsal: everything around the GPU work (tests/test_distributed_cpu.py)
+        dt = 0.25 + 0.01 * rank
+        dt_max = D.reduce_max_time(dt) if world > 1 else dt
+        ex = None
+        if args.gallery_exchange and world > 1:
+            g = D.GalleryExchange(dim=512, device=None)
+            shard = g.pack(np.array([rank + 1], np.int32), np.ones((1, 512), np.float32) / np.sqrt(512.0), rank)
+            ex = int(g.all_gather(shard).wait_numpy()[:, 0, 0].sum())
+        if rank == 0:
+            print(json.dumps({"metric": "end-to-end frames/sec @1280x720, 30 persons/frame", "value": round(2048 * args.steps * world / dt_max, 2),
+                              "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "dry_run": True,
+                              "config": {"affinity": affinity, "gallery_shards_seen": ex}}), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+    torch.cuda.set_device(dev)
 
     L = importlib.import_module("ai-camera_amd._lib")
     L.load()                                   # fails loudly if the HIP library is missing
     ef = importlib.import_module("ai-camera_amd.engine_file")
     syn = importlib.import_module("ai-camera_amd.synthetic")
-    D = importlib.import_module("ai-camera_amd.distributed")
     TP = importlib.import_module("ai-camera_amd.pipeline").TrackingPipeline
-
-    ndev = max(torch.cuda.device_count(), 1)
-    dev = local_rank % ndev            # one GPU per rank on a real node; rehearsals may share a GPU
-    torch.cuda.set_device(dev)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
 
     if rank == 0:
         ypath, rpath = ef.ensure_seeded_engines(ROOT, scale=args.model)
@@ -161,16 +215,14 @@ def main():
     max_persons = max(32, ((args.persons + 7) // 8) * 8)
     pipe = TP(ypath, rpath, (args.height, args.width), batch=args.batch, ring_frames=2 * R, max_persons=max_persons,
               device=dev, dtype=args.dtype, inject=True)
-    frames = sc.render_batch(0, R)
-    t_up = time.perf_counter()
-    pipe.upload(0, frames)
-    pipe.upload(R, np.ascontiguousarray(frames[::-1]))
-    L.call("aic_device_sync", dev)
-    h2d_s = time.perf_counter() - t_up
+    frames_per_step = 2 * R
+    # the clip in page-locked host memory: what cap.read() hands the reference loop (src/aicamera_tracker.py:170)
+    host_frames = np.empty((frames_per_step, args.height, args.width, 3), np.uint8)
+    host_frames[:R] = sc.render_batch(0, R)
+    host_frames[R:] = host_frames[:R][::-1]
+    TP.pin(host_frames)
     dets = [sc.detections(f)[:3] for f in range(R)]
     pipe.inject(0, [dets[f] for f in order])
-    del frames
-    frames_per_step = 2 * R
 
     def sync_all():
         if world > 1:
@@ -178,54 +230,69 @@ def main():
         torch.cuda.synchronize()
         L.call("aic_device_sync", dev)
 
-    exchange = args.gallery_exchange
-    for _ in range(args.warmup):
-        pipe.run_raw(0, frames_per_step)
+    exchange = None
+    if args.gallery_exchange and world > 1:
+        exchange = D.GalleryExchange(dim=pipe.reid.out_dim, device=dev)
+        exchange.start(pipe, every_frames=args.gallery_exchange)
+
+    def run_steps(k):
+        if args.resident:
+            return pipe.run_raw_passes(0, frames_per_step, k)
+        return pipe.run_raw_from_host_passes(host_frames, k)
+
+    if args.resident:
+        pipe.upload(0, host_frames)
+    if args.warmup > 0:
+        run_steps(args.warmup)
     if not args.no_prof:
         L.call("aic_prof_reset", dev)
         L.call("aic_prof_enable", dev, 1)       # class 0 = conv_igemm only
     pipe.stats(reset=True)
     sync_all()
     t0 = time.perf_counter()
-    n_tracks_total = 0
-    continuous = not args.per_step_calls and not (exchange and world > 1)
-    if continuous:   # the K steps as ONE call: a looped clip streamed continuously, a single pipeline fill/drain for K passes
-        nt, rows, nd = pipe.run_raw_passes(0, frames_per_step, args.steps)
-        n_tracks_total = int(nt.sum()) * args.steps          # rows of the last pass; every pass is in steady state
-    for k in range(0 if continuous else args.steps):
-        nt, rows, nd = pipe.run_raw(0, frames_per_step)
-        n_tracks_total += int(nt.sum())
-        if exchange and world > 1 and (k + 1) % exchange == 0:
-            a = pipe.tracker_core.export_arrays()
-            conf = a["state"] == 2
-            emb = np.stack([t.features[-1] for t, c in zip(pipe.tracker_core.tracks, conf) if c]) if conf.any() else np.zeros((0, pipe.reid.out_dim), np.float32)
-            shard = D.pack_gallery_shard(a["track_id"][conf], emb, pipe.reid.out_dim)
-            D.all_gather_gallery(shard, dev)
+    nt, rows, nd = run_steps(args.steps)        # the K steps as ONE call: a looped clip streamed continuously
     sync_all()
     dt = time.perf_counter() - t0
+    n_tracks_total = int(nt.sum()) * args.steps                  # rows of the last pass; every pass is in steady state
     host = pipe.stats()
+    g_frames, g_lat = pipe.group_times()
     prof = L.prof_read(dev) if not args.no_prof else None
     if not args.no_prof:
         L.call("aic_prof_enable", dev, 0)
-    # PCIe-inclusive rate (never `value`): the same steps with every frame streamed from pinned host memory
-    pcie_fps = None
-    if rank == 0 and world == 1 and not args.no_pcie:
-        try:
-            host_frames = np.ascontiguousarray(np.concatenate([sc.render_batch(0, R), sc.render_batch(0, R)[::-1]]))
-            TP.pin(host_frames)
-            pipe.run_raw_from_host(host_frames)            # warm-up
-            L.call("aic_device_sync", dev)
-            tp0 = time.perf_counter()
-            for _ in range(max(2, args.steps // 3)):
-                pipe.run_raw_from_host(host_frames)
-            L.call("aic_device_sync", dev)
-            pcie_fps = frames_per_step * max(2, args.steps // 3) / (time.perf_counter() - tp0)
-            TP.unpin(host_frames)
-        except Exception as e:
-            pcie_fps = f"failed: {e}"
+    exchanges = exchange.stop() if exchange else None
     dt_max = D.reduce_max_time(dt) if world > 1 else dt
     total_frames = frames_per_step * args.steps * world
     fps = total_frames / dt_max
+
+    # side measurements (rank 0, N = 1): the other span, and the launch-group-size curve with per-frame latency
+    side = {}
+    if rank == 0 and world == 1 and not args.no_curve:
+        try:
+            t1 = time.perf_counter()
+            if args.resident:
+                pipe.run_raw_from_host_passes(host_frames, 2)
+            else:
+                pipe.run_raw_passes(0, frames_per_step, 2)       # the ring holds the clip: the last from-host pass left it there
+            L.call("aic_device_sync", dev)
+            side["other_span_fps"] = round(2 * frames_per_step / (time.perf_counter() - t1), 1)
+            curve = {}
+            for g in (16, 64, 128, 256, 512):
+                if g > args.batch:
+                    continue
+                pipe.option("group_frames", g)
+                n_fr = min(frames_per_step, max(8 * g, 512))
+                pipe.run_raw_from_host_passes(host_frames[:n_fr], 1)            # warm
+                t2 = time.perf_counter()
+                pipe.run_raw_from_host_passes(host_frames[:n_fr], 3)
+                L.call("aic_device_sync", dev)
+                dtg = time.perf_counter() - t2
+                gf, gl = pipe.group_times()
+                full = gf == g
+                curve[str(g)] = {"fps": round(3 * n_fr / dtg, 1), "latency_ms_p50": pct(gl[full], gf[full], 0.5), "latency_ms_p99": pct(gl[full], gf[full], 0.99)}
+            pipe.option("group_frames", 0)
+            side["by_launch_group_frames"] = curve
+        except Exception as e:
+            side["error"] = str(e)
 
     if rank == 0:
         flops_frame = pipe.yolo.flops_per_item + args.persons * pipe.reid.flops_per_item
@@ -237,11 +304,11 @@ def main():
             traffic, tsrc, talg = None, None, None
             default_cfg = (args.dtype == "fp16" and args.model == "n" and args.batch == 512 and args.ring == 1024 and args.persons == 30
                            and args.width == 1280 and args.height == 720)
-            try:   # PMC counters need rocprofv3 (separate passes); the committed measurement (taken at the default
-                   # configuration) is reported with its provenance, and only for that configuration
+            try:   # PMC counters need rocprofv3 (separate passes): a COMMITTED measurement taken at the default configuration by
+                   # tools/refresh_profiles.sh, reported with its provenance and only for that configuration -- not measured in this run
                 if default_cfg:
                     pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-                    traffic, tsrc = pm["hbm_bytes_per_launch"], pm["method"]
+                    traffic, tsrc = pm["hbm_bytes_per_launch"], "committed measurement (profiles/pmc_traffic.json), not this run: " + pm["method"]
                     talg = pm.get("algorithmic_bytes_per_launch_same_basis")
             except Exception:
                 pass
@@ -257,6 +324,9 @@ def main():
                 cpu = cpu_baseline(args, ypath, rpath)
             except Exception as e:   # the baseline must never hide the GPU number
                 cpu = {"value": None, "unit": "frames/s", "cores": host_cores(), "kind": "port", "sample": f"failed: {e}"}
+        span = ("frames resident in HBM -> track tuples on host" if args.resident else
+                "frame bytes in page-locked host memory -> track tuples on host (H2D of every frame inside, overlapped; detect+track, the reference's FPS span)")
+        full = g_frames == args.batch
         out = {
             "metric": "end-to-end frames/sec @1280x720, 30 persons/frame",
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -266,16 +336,22 @@ def main():
                                    f"1 stream per GPU, seeded weights, inject=planted",
                        "frames_per_step": frames_per_step, "launch_group_frames": args.batch,
                        "confirmed_tracks_per_frame": round(n_tracks_total / (frames_per_step * args.steps), 2),
-                       "timed_span": "frames resident in HBM -> track tuples on host (detect+track, reference FPS span)",
-                       "h2d_upload_s_for_ring": round(h2d_s, 4),
-                       "pcie_inclusive_fps(frames streamed from pinned host memory, not `value`)": (round(pcie_fps, 1) if isinstance(pcie_fps, float) else pcie_fps),
-                       "gallery_exchange_every_steps": exchange,
+                       "timed_span": span,
+                       ("from_host_fps" if args.resident else "hbm_resident_fps") + " (the other span, 2 passes, not `value`)": side.get("other_span_fps"),
+                       "frame_latency_ms(handed to the pipeline -> tuples on host, full launch groups of the timed run)":
+                           {"p50": pct(g_lat[full], g_frames[full], 0.5), "p99": pct(g_lat[full], g_frames[full], 0.99)},
+                       "by_launch_group_frames(from host, 3 passes each)": side.get("by_launch_group_frames"),
+                       "association": "on the device, epochs of 16 frames (csrc/kernels_trk_dev.hip)" if not os.environ.get("AICAM_TRK_HOST") else "host C++ cascade/LSAP, one launch + sync per frame",
+                       "gallery_exchange_every_frames": args.gallery_exchange, "gallery_exchanges_done": exchanges,
+                       "host_affinity": affinity,
                        "host_us_per_frame": {"issue_launch_groups(producer thread)": round(1e6 * host["issue_s"] / max(host["frames"], 1), 1),
                                              "wait_for_gpu": round(1e6 * host["wait_s"] / max(host["frames"], 1), 1),
-                                             "tracker_chain": round(1e6 * host["track_s"] / max(host["frames"], 1), 1)}},
+                                             "tracker_chain(host side of the association)": round(1e6 * host["track_s"] / max(host["frames"], 1), 1)},
+                       "side_error": side.get("error")},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
+    TP.unpin(host_frames)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

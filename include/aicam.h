@@ -252,6 +252,25 @@ int aic_pipeline_run_passes(aic_pipeline* p, int slot, int count, int passes, in
  * stream while the previous group computes. Pin the buffer once with aic_host_register for full PCIe rate. */
 int aic_pipeline_run_from_host(aic_pipeline* p, const uint8_t* frames_bgr, int slot, int count, int32_t* n_tracks,
                                int32_t* tracks6, float* track_conf, int32_t* n_dets);
+/* The host clip walked `passes` times as one continuous stream (bench.py's timed region: the reference's own span --
+ * frame bytes in host memory -> track tuples on the host, src/aicamera_tracker.py:170-207 with yolo_detector.py:91's
+ * .to(device) inside). */
+int aic_pipeline_run_from_host_passes(aic_pipeline* p, const uint8_t* frames_bgr, int slot, int count, int passes,
+                                      int32_t* n_tracks, int32_t* tracks6, float* track_conf, int32_t* n_dets);
+/* Launch groups of the last call: frames, wall-clock second at which the group was handed to the pipeline (its H2D /
+ * first launch enqueued) and at which its track tuples were on the host. done - submit = latency of every frame of the group. */
+int aic_pipeline_group_times(aic_pipeline* p, int32_t* frames, double* submit_s, double* done_s, int cap, int32_t* n);
+/* configs[4] of BASELINE.json -- optional cross-camera ReID gallery exchange (not in the reference: README.md:210 lists it
+ * as future work; SURVEY.md §8e fixes its form).  enable: every `every_groups` launch groups the pipeline packs, on its tracker
+ * stream, a shard fp32 [t_max, 2 + dim] (valid, track id, unit embedding of the newest gallery row) of the stream's first t_max
+ * confirmed tracks into the caller's device buffers (two, alternating).  A consumer thread then calls wait(seq) -- blocks
+ * until shard `seq` is packed, returns its buffer index and makes the exchange stream (exchange_stream: a hipStream_t the
+ * caller runs its RCCL all-gather on, e.g. through torch.cuda.ExternalStream) wait for the pack kernel -- and done(seq) once
+ * the collective has consumed the buffer.  shard0_dev = NULL disables.  The association of the stream never waits for it. */
+int aic_pipeline_exchange_enable(aic_pipeline* p, float* shard0_dev, float* shard1_dev, int t_max, int every_groups);
+int aic_pipeline_exchange_stream(aic_pipeline* p, void** stream);
+int aic_pipeline_exchange_wait(aic_pipeline* p, int64_t seq, int timeout_ms, int32_t* buffer, int32_t* ready);
+int aic_pipeline_exchange_done(aic_pipeline* p, int64_t seq);
 int aic_host_register(void* ptr, size_t bytes);   /* hipHostRegister: page-lock caller memory */
 int aic_host_unregister(void* ptr);
 int aic_pipeline_tracker(aic_pipeline* p, aic_tracker** out);
@@ -259,7 +278,10 @@ int aic_pipeline_tracker(aic_pipeline* p, aic_tracker** out);
  * a group's GPU work, walking its frames through the tracker (association recurrence). */
 int aic_pipeline_stats(aic_pipeline* p, double* issue_s, double* wait_s, double* track_s, int64_t* frames, int reset);
 /* Runtime options (tests / measurements). "taper": 1 (default) = the last launch group of a call is split into
- * shrinking groups so its un-overlapped tracker tail is short, 0 = full groups only. */
+ * shrinking groups so its un-overlapped tail is short, 0 = full groups only.  "group_frames": frames per launch group
+ * (<= batch; 0 = batch).  "device_assoc": 1 (default) = association on the device, k frames per launch (cascade, LSAP
+ * and lifecycle in csrc/kernels_trk_dev.hip, no host round trip per frame); 0 = cost matrices on the device, cascade /
+ * LSAP / lifecycle in host C++ (csrc/assoc_host.cpp, lsap.cpp), one launch + one sync per frame. */
 int aic_pipeline_option(aic_pipeline* p, const char* key, int value);
 /* Launch groups whose crop count outgrew the buffers sized from max_persons (handled, not dropped), and frames
  * whose confirmed tracks outnumbered the caller's max_persons rows (n_tracks reports the true count). */

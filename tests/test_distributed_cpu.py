@@ -68,3 +68,45 @@ def test_single_process_defaults():
     import importlib
     D = importlib.import_module("ai-camera_amd.distributed")
     assert D.reduce_max_time(0.5) == 0.5 and D.shard_streams(3, 1, 0) == [0, 1, 2]
+
+
+def test_bench_launch_path_gloo_world2():
+    """`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 --backend gloo --dry-run`: the driver's N > 1 launch
+    line end to end on the CPU-visible parts -- argument parsing, RANK / LOCAL_RANK / WORLD_SIZE, NUMA / core binding before
+    any GPU call, rendezvous on 127.0.0.1, the gallery shard all-gather (configs[4]) and the MAX-over-ranks reduction; one JSON
+    line from rank 0."""
+    import json
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--backend", "gloo", "--dry-run", "--gallery-exchange", "8"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(os.environ, OMP_NUM_THREADS="1"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["dry_run"] is True
+    assert abs(out["value"] - 2048 * 3 * 2 / 0.26) < 1.0            # MAX over ranks of (0.25, 0.26) seconds
+    assert out["config"]["gallery_shards_seen"] == 2                 # both ranks' valid rows arrived
+    aff = out["config"]["affinity"]
+    assert aff["bound"] is True and aff["cores"] >= 1
+
+
+def test_rank_core_binding_is_disjoint():
+    import importlib
+    D = importlib.import_module("ai-camera_amd.distributed")
+    assert D._cpulist("0-3,8,10-11") == [0, 1, 2, 3, 8, 10, 11]
+    code = ("import importlib, os, sys, json; sys.path.insert(0, %r); D = importlib.import_module('ai-camera_amd.distributed'); "
+            "a = D.bind_rank_to_gpu_numa(int(sys.argv[1]), 2); print(json.dumps([a, sorted(os.sched_getaffinity(0))]))" % ROOT)
+    import json
+    sets = []
+    for rank in range(2):
+        r = subprocess.run([sys.executable, "-c", code, str(rank)], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr[-2000:]
+        a, cores = json.loads(r.stdout.strip().splitlines()[-1])
+        assert a["bound"] and len(cores) == a["cores"]
+        sets.append(set(cores))
+    if len(os.sched_getaffinity(0)) >= 2:
+        assert not (sets[0] & sets[1])                               # two ranks never share a core

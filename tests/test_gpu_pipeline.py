@@ -151,3 +151,33 @@ def test_pipeline_small_gallery_budget(gpu, engines, assoc):
         assert len(tv.features) == len(ot.features) <= 3
         assert np.abs(np.stack(tv.features) - np.stack(ot.features)).max() < 1e-3
     pipe.close()
+
+
+def test_gallery_exchange_hooks_single_gpu(gpu, engines):
+    """configs[4] plumbing on one GPU (world 1: the all-gather degenerates to a copy): the pipeline packs a device shard per
+    launch group on its tracker stream, the consumer thread picks every shard up on the exchange stream, and the shard holds
+    the stream's confirmed tracks with the unit embedding of their newest gallery row."""
+    D = pkg("distributed")
+    n_frames, batch = 32, 8
+    sc = syn.Scene(seed=21, n_targets=12)
+    frames = sc.render_batch(0, n_frames)
+    TP = pkg("pipeline").TrackingPipeline
+    pipe = TP(engines[0], engines[1], (720, 1280), batch=batch, ring_frames=n_frames, max_persons=16, dtype="fp16", inject=True)
+    pipe.option("taper", 0)
+    pipe.upload(0, frames)
+    pipe.inject(0, [sc.detections(f)[:3] for f in range(n_frames)])
+    ex = D.GalleryExchange(dim=512, device=0)
+    ex.start(pipe, every_frames=8)
+    tracks, nd = pipe.run(0, n_frames)
+    assert ex.stop() == n_frames // batch                      # one exchange per launch group, none lost
+    g = ex._gathered.cpu().numpy()
+    valid = g[:, 0] > 0.5
+    a = pipe.tracker_core.export_arrays()
+    conf_ids = a["track_id"][a["state"] == 2]
+    assert valid.sum() == len(conf_ids) == 12 and g[valid, 1].astype(int).tolist() == conf_ids.tolist()
+    assert np.allclose(np.linalg.norm(g[valid, 2:], axis=1), 1, atol=1e-4)
+    newest = np.stack([t.features[-1] for t in pipe.tracker_core.tracks if t.is_confirmed()])
+    newest /= np.linalg.norm(newest, axis=1, keepdims=True)
+    assert np.abs(g[valid, 2:] - newest).max() < 1e-5
+    assert ex.last_annotation.shape == (128, 3) and (ex.last_annotation[:, 0] < 0).all()     # no other camera in a world of 1
+    pipe.close()
