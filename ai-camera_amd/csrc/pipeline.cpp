@@ -92,7 +92,11 @@ struct Pipeline {
     hipEvent_t prev_end = nullptr;   // measured: no gain on MI355X
     const uint8_t* host_frames = nullptr;   // run_from_host: frames of the current call in (pinned) host memory
     hipStream_t s_copy = nullptr;
-    hipEvent_t ev_copy[4] = {nullptr, nullptr, nullptr, nullptr};
+    static constexpr int NCOPY = 8;   // H2D copies in flight: a group's frames cross PCIe up to COPY_AHEAD groups before its launch group is issued
+    static constexpr int COPY_AHEAD = 2;
+    hipEvent_t ev_copy[NCOPY] = {};
+    std::vector<int> plan_off, plan_len;   // launch groups of the running call (ring slot offset, frames)
+    int plan_slot = 0, copies_issued = 0;
     int host_slot0 = 0;
 
     Pipeline(Model* y, Model* r, const aic_pipeline_params& p)
@@ -159,17 +163,37 @@ struct Pipeline {
 
     static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-    void stage_a(Chunk& c, int slot, int frames) {
+    // H2D of the launch groups up to index `upto` (one copy + one event each).  A group's ring slots may be overwritten once
+    // every earlier group that used an overlapping slot range has finished computing: the groups k-1 .. j-1 around the one
+    // being issued (k) are still in flight, so a copy that would touch their slots waits for its own turn.
+    void issue_copies(int upto) {
+        const int n = (int)plan_off.size();
+        while (copies_issued < n && copies_issued <= upto) {
+            const int j = copies_issued;
+            bool clash = false;
+            for (int i = std::max(0, cur_group - 1); i < j && !clash; ++i)
+                clash = plan_off[i] < plan_off[j] + plan_len[j] && plan_off[j] < plan_off[i] + plan_len[i];
+            if (clash && j > cur_group) break;               // copy it when its own group is issued
+            if (clash && cur_group > 0)                       // a short clip looped: group k-1 still reads these slots -> behind its launch group
+                HIP_CHECK(hipStreamWaitEvent(s_copy, ck[(cur_group - 1) % NCK].done, 0));
+            const int slot = plan_slot + plan_off[j];
+            HIP_CHECK(hipMemcpyAsync(ring.p + (size_t)slot * frame_bytes, host_frames + (size_t)(slot - host_slot0) * frame_bytes,
+                                     (size_t)plan_len[j] * frame_bytes, hipMemcpyHostToDevice, s_copy));
+            HIP_CHECK(hipEventRecord(ev_copy[j % NCOPY], s_copy));
+            copies_issued += 1;
+        }
+    }
+    int cur_group = 0;
+
+    void stage_a(Chunk& c, int slot, int frames, int group_index = 0) {
+        cur_group = group_index;
         const double t0 = now();
         hipStream_t s = dev->s_main;
         c.frames = frames, c.first_slot = slot;
-        if (host_frames) {   // PCIe-inclusive path: H2D of this group's frames on the copy stream, overlapped with the previous group's compute
-            const int ci = (int)(&c - &ck[0]);
-            HIP_CHECK(hipMemcpyAsync(ring.p + (size_t)slot * frame_bytes, host_frames + (size_t)(slot - host_slot0) * frame_bytes,
-                                     (size_t)frames * frame_bytes, hipMemcpyHostToDevice, s_copy));
-            HIP_CHECK(hipEventRecord(ev_copy[ci], s_copy));
-            HIP_CHECK(hipStreamWaitEvent(s, ev_copy[ci], 0));
-            if (split_streams) HIP_CHECK(hipStreamWaitEvent(dev->s_reid, ev_copy[ci], 0));
+        if (host_frames) {   // the reference's span: H2D of the group's frames on the copy stream, under the previous groups' compute
+            issue_copies(group_index + COPY_AHEAD);
+            HIP_CHECK(hipStreamWaitEvent(s, ev_copy[group_index % NCOPY], 0));
+            if (split_streams) HIP_CHECK(hipStreamWaitEvent(dev->s_reid, ev_copy[group_index % NCOPY], 0));
         }
         const uint8_t* f0 = ring.p + (size_t)slot * frame_bytes;
         if (pipe_times) HIP_CHECK(hipEventRecord(c.t_begin, s));
@@ -433,6 +457,7 @@ struct Pipeline {
         const int nchunks = (int)goff.size();
         group_times.clear();
         submit_t.assign(nchunks, 0.0);
+        plan_off = goff, plan_len = glen, plan_slot = slot, copies_issued = 0;
         // Two host threads: the producer issues the detection/ReID launch groups (stage A, ~100 launches
         // per group), this thread walks the frames of each finished group through the tracker (stage B:
         // small launches + syncs). A chunk context is reissued only after stage B released it.
@@ -449,7 +474,7 @@ struct Pipeline {
                         cv.wait(lk, [&] { return k < consumed + NCK; });
                     }
                     submit_t[k] = now();
-                    stage_a(ck[k % NCK], slot + goff[k], glen[k]);
+                    stage_a(ck[k % NCK], slot + goff[k], glen[k], k);
                     {
                         std::lock_guard<std::mutex> lk(mu);
                         issued = k + 1;
