@@ -442,6 +442,21 @@ def read_engine(path) -> Graph:
         return parse(f.read())
 
 
+def engine_nms_defaults(path):
+    """(conf, iou, max_det) an importer stored in the engine's meta[3..5] (the NMS plugin attributes of an ONNX file with an
+    embedded EfficientNMS node, ai-camera_amd/onnx_import.py), or None."""
+    with open(path, "rb") as f:
+        head = f.read(struct.calcsize("<II7i8i"))
+    if len(head) < struct.calcsize("<II7i8i"):
+        return None
+    meta = struct.unpack("<II7i8i", head)[9:]
+    if meta[3] <= 0:
+        return None
+    conf = struct.unpack("<f", struct.pack("<i", meta[4]))[0]
+    iou = struct.unpack("<f", struct.pack("<i", meta[5]))[0]
+    return conf, iou, int(meta[3])
+
+
 def default_engine_paths(root=None):
     """The reference's default locations (src/config.py:12-13) with this build's extension."""
     root = root or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -51,6 +51,11 @@ class HipEngine:
         self.kind, self.in_h, self.in_w, self.out_dim = k.value, ih.value, iw.value, od.value
         self.n_anchors, self.flops_per_item, self.n_convs = na.value, fl.value, ncv.value
         self.conf_thresh, self.iou_thresh, self.max_det = self.default_conf, self.default_iou, self.default_max_det
+        if self.kind == L.MODEL_YOLO:                       # an engine imported from an ONNX file with an embedded NMS plugin carries its thresholds
+            from .engine_file import engine_nms_defaults
+            nms = engine_nms_defaults(str(self.engine_path))
+            if nms:
+                self.conf_thresh, self.iou_thresh, self.max_det = nms[0], nms[1], min(nms[2], self.default_max_det)
         t = None
         try:
             t = _torch()

@@ -1,0 +1,95 @@
+"""ONNX ingestion (ai-camera_amd/onnx_import.py): engine graph -> ONNX bytes -> engine graph round trips on
+the host (module-path names and anonymous BN-folded names, folded and unfolded BatchNorm, with and without the embedded
+EfficientNMS plugin the reference detector reads, src/detector/yolo_detector.py:49-54), and -- on the GPU -- the head of the
+re-imported engine is identical to the head of the original."""
+import numpy as np
+import pytest
+
+from conftest import pkg
+
+ef = pkg("engine_file")
+oi = pkg("onnx_import")
+
+
+@pytest.mark.parametrize("module_names,fold_bn", [(True, True), (False, True), (True, False), (False, False)])
+def test_yolo_onnx_round_trip(module_names, fold_bn):
+    g = ef.build_yolov8("n", calibrate=False)
+    nms = {"score_threshold": 0.25, "iou_threshold": 0.65, "max_output_boxes": 100}
+    blob = oi.export_onnx(g, nms=nms, module_names=module_names, fold_bn=fold_bn)
+    m = oi.parse_onnx(blob)
+    assert [n for n, _ in m.outputs] == ["num_dets", "bboxes", "scores", "labels"] and m.inputs == [("images", [1, 3, 640, 640])]
+    assert sum(nd.op == "Conv" for nd in m.nodes) == 64 and any(nd.op == "EfficientNMS_TRT" for nd in m.nodes)     # 63 + the DFL projection
+    back, info = oi.onnx_to_engine(blob)
+    assert info["kind"] == "yolo" and info["scale"] == "n" and info["nc"] == 80 and info["in_hw"] == (640, 640)
+    assert info["mapping"] == ("by name" if module_names else "by order")
+    assert info["nms"] == dict(op="EfficientNMS_TRT", **{k: pytest.approx(v) for k, v in nms.items()})
+    assert back.ops == g.ops and back.buffers == g.buffers and back.outputs == g.outputs
+    for (w0, b0), (w1, b1) in zip(g.weights, back.weights):
+        if fold_bn:
+            assert np.array_equal(w0, w1) and np.array_equal(b0, b1)
+        else:
+            assert np.allclose(w0, w1, rtol=2e-6, atol=1e-7) and np.allclose(b0, b1, rtol=2e-6, atol=1e-7)
+    # the NMS attributes travel in the engine file and become the engine's defaults
+    blob2 = ef.serialize(back)
+    again = ef.parse(blob2)
+    assert again.meta[3] == 100
+    import struct
+    assert struct.unpack("<f", struct.pack("<i", again.meta[4]))[0] == pytest.approx(0.25)
+
+
+def test_yolo_onnx_without_nms_and_other_scale():
+    g = ef.build_yolov8("m", nc=3, in_hw=(320, 416), calibrate=False)
+    back, info = oi.onnx_to_engine(oi.export_onnx(g, nms=None, module_names=False))
+    assert info["scale"] == "m" and info["nc"] == 3 and info["in_hw"] == (320, 416) and info["nms"] is None and back.meta[3] == 0
+    assert len(back.weights) == 83 and all(np.array_equal(a[0], b[0]) for a, b in zip(g.weights, back.weights))
+    with pytest.raises(ValueError):
+        oi.onnx_to_engine(b"\x0a\x03abc")                         # not a graph
+    bad = ef.build_yolov8("n", calibrate=False)
+    bad.weights[5] = (bad.weights[5][0][:, :, :1, :1].copy(), bad.weights[5][1])         # a 3x3 conv exported as 1x1: does not fit the architecture
+    with pytest.raises(ValueError):
+        oi.onnx_to_engine(oi.export_onnx(bad, module_names=False))
+
+
+@pytest.mark.parametrize("fc,module_names,fold_bn", [(True, True, True), (False, False, True), (True, False, False)])
+def test_reid_onnx_round_trip(fc, module_names, fold_bn):
+    g = ef.build_reid(fc=fc, calibrate=False)
+    blob = oi.export_onnx(g, module_names=module_names, fold_bn=fold_bn)
+    back, info = oi.onnx_to_engine(blob)
+    assert info["kind"] == "reid" and info["embed_fc"] == fc and info["in_hw"] == (128, 64)
+    assert back.ops == g.ops and back.buffers == g.buffers
+    for (w0, b0), (w1, b1) in zip(g.weights, back.weights):
+        assert np.allclose(w0, w1, rtol=2e-6, atol=1e-7) and np.allclose(b0, b1, rtol=2e-6, atol=1e-7)
+    if fold_bn:
+        assert all(np.array_equal(a[0], b[0]) for a, b in zip(g.weights, back.weights))
+
+
+@pytest.mark.gpu
+def test_onnx_engine_identical_head_on_gpu(gpu, engines, tmp_path):
+    """Seeded engine -> ONNX bytes (anonymous tensor names, embedded NMS) -> engine file: same raw head, same detections, and
+    the plugin's thresholds are the imported engine's defaults."""
+    HipEngine = pkg("hip_engine").HipEngine
+    syn = pkg("synthetic")
+    from oracle import image_oracle as I
+    g = ef.read_engine(engines[0])
+    back, info = oi.onnx_to_engine(oi.export_onnx(g, nms={"score_threshold": 0.4, "iou_threshold": 0.6, "max_output_boxes": 50}, module_names=False))
+    path = str(tmp_path / "from_onnx.aicw")
+    ef.write_engine(path, back)
+    frame = syn.Scene(seed=0).render(0)
+    x = I.preprocess_yolo_input(frame)[0]
+    a, b = HipEngine(engines[0], dtype="fp32", max_items=1, warm_up=False), HipEngine(path, dtype="fp32", max_items=1, warm_up=False)
+    da, ca = a.yolo_head_np(x)
+    db, cb = b.yolo_head_np(x)
+    assert np.array_equal(da, db) and np.array_equal(ca, cb)
+    assert (b.conf_thresh, b.iou_thresh, b.max_det) == (pytest.approx(0.4), pytest.approx(0.6), 50)
+    nd_b, bb, sb, lb = b.yolo_infer_np(x)
+    nd_a, ba, sa, la = a.yolo_infer_np(x, conf=0.4, iou=0.6, max_det=50)
+    assert nd_a[0] == nd_b[0] > 0 and np.array_equal(ba, bb) and np.array_equal(la, lb)
+    # ReID: embeddings of the re-imported engine
+    gr = ef.read_engine(engines[1])
+    rb, _ = oi.onnx_to_engine(oi.export_onnx(gr, module_names=True))
+    rpath = str(tmp_path / "reid_from_onnx.aicw")
+    ef.write_engine(rpath, rb)
+    crops = np.random.default_rng(0).standard_normal((5, 3, 128, 64)).astype(np.float32)
+    e0 = HipEngine(engines[1], dtype="fp32", max_items=8, warm_up=False).reid_infer_np(crops)
+    e1 = HipEngine(rpath, dtype="fp32", max_items=8, warm_up=False).reid_infer_np(crops)
+    assert np.array_equal(e0, e1)
