@@ -45,7 +45,7 @@ def test_yolo_onnx_without_nms_and_other_scale():
     with pytest.raises(ValueError):
         oi.onnx_to_engine(b"\x0a\x03abc")                         # not a graph
     bad = ef.build_yolov8("n", calibrate=False)
-    bad.weights[5] = (bad.weights[5][0][:, :, :1, :1].copy(), bad.weights[5][1])         # a 3x3 conv exported as 1x1: does not fit the architecture
+    bad.weights[3] = (bad.weights[3][0][:, :, :1, :1].copy(), bad.weights[3][1])         # a 3x3 conv exported as 1x1: does not fit the architecture
     with pytest.raises(ValueError):
         oi.onnx_to_engine(oi.export_onnx(bad, module_names=False))
 
