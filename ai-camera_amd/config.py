@@ -68,3 +68,20 @@ def resolve_device(device) -> int:
         raise RuntimeError("this engine has no CPU path: a gfx950 GPU is required (reference TRTEngine "
                            "is likewise CUDA-only, src/trt_utils/trt_engine.py:33-39,153-154)")
     return int(s.split(":")[1]) if ":" in s else 0
+
+
+# --- Visualization (src/config.py:55-85) ---------------------------------------------------------------------------------------
+# The reference draws one random colour per class (random.randint at import, unseeded: different every run); here the table is
+# seeded so that outputs are reproducible.
+_rng_colors = __import__("numpy").random.default_rng(42)
+CLASS_COLORS = {name: [int(v) for v in _rng_colors.integers(0, 256, 3)] for name in CLASSES}
+DEFAULT_TRACK_COLOR = (0, 255, 0)   # green
+DEFAULT_OUTPUT_FPS = 30
+
+
+def get_track_color(class_name):
+    return CLASS_COLORS.get(class_name, DEFAULT_TRACK_COLOR)
+
+
+def get_class_color(class_name):
+    return CLASS_COLORS.get(class_name, (200, 200, 200))

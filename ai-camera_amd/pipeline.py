@@ -42,6 +42,12 @@ class TrackingPipeline:
         self.tracker_core._dim = self.reid.out_dim
 
     def close(self):
+        for b in getattr(self, "_staging", []):
+            try:
+                self.unpin(b)
+            except Exception:
+                pass
+        self._staging = []
         if getattr(self, "_h", None):
             L.call("aic_pipeline_destroy", self._h)
             self._h = C.c_void_p()
@@ -133,6 +139,65 @@ class TrackingPipeline:
         nt, rows, tconf, nd = self._raw_bufs()
         L.call("aic_pipeline_run_from_host_passes", self._h, L.ptr(f), int(slot), count, int(passes), L.ptr(nt), L.ptr(rows), L.ptr(tconf), L.ptr(nd))
         return nt[:count], rows[:count], nd[:count]
+
+    def run_from_host(self, frames_bgr, slot=0):
+        """Frames in host memory -> per-frame track tuples (deepsort_tracker.py:126-141), as run() returns them."""
+        nt, rows, nd = self.run_raw_from_host(frames_bgr, slot)
+        tconf = self._raw_bufs()[2]
+        return [[(int(r[0]), int(r[1]), int(r[2]), int(r[3]), int(r[4]), config.class_name(int(r[5])), float(c))
+                 for r, c in zip(rows[f, :min(nt[f], self.max_persons)], tconf[f, :min(nt[f], self.max_persons)])] for f in range(len(frames_bgr))]
+
+    def stream(self, frames_iter):
+        """Frame source -> (frame, tracks) per frame, in order, through DOUBLE-BUFFERED PAGE-LOCKED STAGING: two buffers of `batch`
+        frames are pinned once (never per call); a reader thread fills one from the source (cap.read() of
+        src/aicamera_tracker.py:170) while the GPU works on the other, whose frames cross PCIe on the copy stream under compute.
+        The yielded frame is a view of the staging buffer: use it before asking for the frame `batch` positions later."""
+        import queue
+        import threading
+        if not hasattr(self, "_staging"):
+            self._staging = [np.empty((self.batch, self.frame_h, self.frame_w, 3), np.uint8) for _ in range(2)]
+            for b in self._staging:
+                self.pin(b)
+        free, full = queue.Queue(), queue.Queue(maxsize=2)
+        free.put(0), free.put(1)
+        err = []
+
+        def reader():
+            try:
+                it = iter(frames_iter)
+                done = False
+                while not done:
+                    b = free.get()
+                    n = 0
+                    while n < self.batch:
+                        try:
+                            f = next(it)
+                        except StopIteration:
+                            done = True
+                            break
+                        if f.shape != (self.frame_h, self.frame_w, 3):
+                            raise ValueError(f"frame of shape {f.shape}, the pipeline was built for {(self.frame_h, self.frame_w, 3)}")
+                        self._staging[b][n] = f
+                        n += 1
+                    full.put((b, n))
+            except Exception as e:      # noqa: BLE001 -- handed to the consumer
+                err.append(e)
+            full.put((-1, 0))
+
+        th = threading.Thread(target=reader, daemon=True)
+        th.start()
+        while True:
+            b, n = full.get()
+            if b < 0:
+                break
+            if n:
+                tracks = self.run_from_host(self._staging[b][:n])
+                for i in range(n):
+                    yield self._staging[b][i], tracks[i]
+            free.put(b)
+        th.join()
+        if err:
+            raise err[0]
 
     def group_times(self):
         """Launch groups of the last call: (frames [G], latency seconds [G]) -- handed to the pipeline -> tuples on the host."""

@@ -293,6 +293,14 @@ int aic_pipeline_group_embeddings(aic_pipeline* p, float* emb, int cap_rows, int
 /* Embeddings of the last processed frame (parity tests): emb[n,dim] host. */
 int aic_pipeline_last_embeddings(aic_pipeline* p, float* emb, int cap_rows, int32_t* n, int32_t* dim);
 
+/* ------------------------------------------------------------------ overlay (the step after the path)
+ * draw_tracks / draw_detections / draw_info_panel (src/utils/visualization.py:9-124,170-228) as ONE kernel on the frame:
+ * prims[n,8] = (kind, x0, y0, x1, y1, color B|G<<8|R<<16, text offset, text length | scale<<16); kind 0 = box outline of
+ * thickness 2, 1 = filled rectangle (corners inclusive), 2 = 5x7 bitmap text with its top-left corner at (x0, y0).  Painter's
+ * order = list order.  The frame (u8 BGR, host or device) is modified in place.  Pixel spec: csrc/kernels_overlay.hip. */
+int aic_overlay(int device, uint8_t* frame_bgr, int h, int w, int mem, const int32_t* prims, int n, const uint8_t* text,
+                int text_bytes);
+
 /* ------------------------------------------------------------------ measurement
  * HIP-event timing of kernel classes on the streams they are launched on (bench.py roofline).
  * Classes: 0 conv_igemm (MFMA), 1 conv_direct (3-channel stems), 2 pool/upsample/misc,

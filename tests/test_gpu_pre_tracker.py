@@ -221,3 +221,33 @@ def test_track_lifecycle_standalone(gpu):
     t2.predict(kf)
     t2.mark_missed()
     assert t2.is_deleted() and t2.track_id == 2
+
+
+# ----------------------------------------------------------------------------- overlay (the step after the path, §8(f)-3)
+def test_overlay_bit_exact(gpu):
+    """draw_tracks / draw_detections / draw_info_panel / draw_fps (src/utils/visualization.py:9-228) as one kernel per call: every
+    pixel equals the NumPy restatement of the pixel spec, including boxes hanging over the frame border, overlapping boxes
+    (painter's order) and every printable ASCII glyph."""
+    from oracle import overlay_oracle as OV
+    vis = pkg("visualization")
+    cfg = pkg("config")
+    rng = np.random.default_rng(3)
+    frame = rng.integers(0, 256, (360, 640, 3), dtype=np.uint8)
+    tracks = [(50, 80, 120, 260, 1, "person", 0.91), (100, 120, 190, 300, 23, "car", 0.5), (-20, -10, 60, 90, 7, "person", 0.77),
+              (600, 300, 700, 400, 1234, "dog", 0.33), (300, 10, 380, 200, 5, "traffic light")]
+    pl = vis.info_prims(vis.track_prims(vis.PrimList(), tracks), ["AICamera: YOLOv8 + DeepSORT", "Input: synthetic", "FPS: 9876.54"])
+    pl.put_text(5, 330, "".join(chr(c) for c in range(32, 127))[:60], 1)
+    pl.put_text(5, 345, "".join(chr(c) for c in range(32, 127))[60:], 1, (0, 200, 255))
+    prims, text = pl.arrays()
+    exp = OV.paint(frame.copy(), prims, text)
+    got = vis.render(frame.copy(), pl)
+    assert np.array_equal(got, exp) and not np.array_equal(got, frame)
+    # the reference's entry points, one launch each
+    a = vis.draw_tracks(frame.copy(), tracks)
+    assert np.array_equal(a, OV.paint(frame.copy(), *vis.track_prims(vis.PrimList(), tracks).arrays()))
+    col = cfg.get_track_color("person")
+    assert tuple(a[170, 50]) == tuple(col) and tuple(a[170, 49]) == tuple(col) and tuple(a[170, 51]) == tuple(frame[170, 51])    # 2-px outline at x1-1, x1
+    b = vis.draw_detections(frame.copy(), np.array([[10, 40, 90, 140]], np.float32), np.array([0.8]), np.array([0]), cfg.CLASSES)
+    assert (b != frame).any() and np.array_equal(vis.draw_tracks(frame.copy(), []), frame)
+    c = vis.draw_fps(vis.draw_info_panel(frame.copy(), ["a", "bb"]), 30.0)
+    assert (c != frame).any()
