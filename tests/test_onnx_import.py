@@ -71,6 +71,7 @@ def test_onnx_engine_identical_head_on_gpu(gpu, engines, tmp_path):
     syn = pkg("synthetic")
     from oracle import image_oracle as I
     g = ef.read_engine(engines[0])
+    g.names = ef.build_yolov8("n", calibrate=False).names          # the engine file keeps no layer names; the architecture does
     back, info = oi.onnx_to_engine(oi.export_onnx(g, nms={"score_threshold": 0.4, "iou_threshold": 0.6, "max_output_boxes": 50}, module_names=False))
     path = str(tmp_path / "from_onnx.aicw")
     ef.write_engine(path, back)
@@ -86,6 +87,7 @@ def test_onnx_engine_identical_head_on_gpu(gpu, engines, tmp_path):
     assert nd_a[0] == nd_b[0] > 0 and np.array_equal(ba, bb) and np.array_equal(la, lb)
     # ReID: embeddings of the re-imported engine
     gr = ef.read_engine(engines[1])
+    gr.names = ef.build_reid(calibrate=False).names
     rb, _ = oi.onnx_to_engine(oi.export_onnx(gr, module_names=True))
     rpath = str(tmp_path / "reid_from_onnx.aicw")
     ef.write_engine(rpath, rb)
