@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """HBM bytes per conv launch from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE: separate runs, as
 MI355X_MICROARCH.md prescribes) -> profiles/pmc_traffic.json (read by bench.py's roofline.traffic).
-  python tools/pmc_traffic.py <fetch_dir> <write_dir> "<method note>" """
+  python tools/pmc_traffic.py <fetch_dir> <write_dir> "<method note>" [tag]   (tag: also profiles/<tag>_pmc_traffic.json) """
 import csv, glob, json, os, sys
 
 CONV = ("conv_igemm_dma_kernel", "conv3x3_patch_kernel", "conv_igemm_pp_kernel", "conv3x3_pp_patch_kernel", "conv_igemm_kernel", "conv3x3_c16_kernel", "conv3x3_c64_resident_kernel", "conv3x3_c64_block_kernel")
@@ -35,6 +35,7 @@ try:    # algorithmic bytes of the same launches (library counter, AICAM_NO_TAPE
         out["algorithmic_bytes_per_launch_same_basis"] = prev["algorithmic_bytes_per_launch_same_basis"]
 except Exception:
     pass
-for name in ("pmc_traffic.json", "r01_pmc_traffic.json"):
+tag = sys.argv[4] if len(sys.argv) > 4 else "r02"
+for name in ("pmc_traffic.json", f"{tag}_pmc_traffic.json"):
     json.dump(out, open(os.path.join(root, "profiles", name), "w"), indent=1)
 print(json.dumps(out, indent=1))

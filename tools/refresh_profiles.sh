@@ -1,28 +1,32 @@
 #!/bin/bash
 # Regenerate the judged artefacts under profiles/ on a GPU box (run from the repo root through gpurun):
 #   bench line (default bench.py), rocprofv3 kernel trace + stats of the same workload, per-layer conv table,
-#   HBM traffic per conv launch from two separate PMC passes (FETCH_SIZE, WRITE_SIZE; full 512-frame groups).
+#   HBM traffic per conv launch from two separate PMC passes (FETCH_SIZE, WRITE_SIZE; full 512-frame groups), SQ counters.
+#   tools/refresh_profiles.sh [tag]      tag (default r02) prefixes every file copied into profiles/
 set -e
 R=$PWD
-O=$R/gpurun_out/refresh
+TAG=${1:-r02}
+O=$R/gpurun_out/refresh_$TAG
 rm -rf $O && mkdir -p $O
-TAG=${1:-r01}
+B="--cpu-frames 0 --no-curve"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --cpu-frames 0 --no-pcie > $O/bench_under_rocprof.json 2> $O/trace.log
-AICAM_NO_TAPER=1 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -- python3 $R/bench.py --steps 1 --warmup 1 --cpu-frames 0 --no-pcie > /dev/null 2> $O/fetch.log
-AICAM_NO_TAPER=1 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -- python3 $R/bench.py --steps 1 --warmup 1 --cpu-frames 0 --no-pcie > /dev/null 2> $O/write.log
-AICAM_NO_TAPER=1 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $O/sqa -- python3 $R/bench.py --steps 1 --warmup 1 --cpu-frames 0 --no-pcie > /dev/null 2> $O/sqa.log
-AICAM_NO_TAPER=1 rocprofv3 --pmc SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $O/sqb -- python3 $R/bench.py --steps 1 --warmup 1 --cpu-frames 0 --no-pcie > /dev/null 2> $O/sqb.log
+# the bench command itself (from-host span) under the kernel trace: its conv durations must agree with the HIP-event figure of the bench line
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py $B > $O/bench_under_rocprof.json 2> $O/trace.log
+# counters: separate passes, full launch groups only, clip resident (the conv launches are the same)
+AICAM_NO_TAPER=1 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -- python3 $R/bench.py --steps 1 --warmup 1 --resident $B > /dev/null 2> $O/fetch.log
+AICAM_NO_TAPER=1 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -- python3 $R/bench.py --steps 1 --warmup 1 --resident $B > /dev/null 2> $O/write.log
+AICAM_NO_TAPER=1 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $O/sqa -- python3 $R/bench.py --steps 1 --warmup 1 --resident $B > /dev/null 2> $O/sqa.log
+AICAM_NO_TAPER=1 rocprofv3 --pmc SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $O/sqb -- python3 $R/bench.py --steps 1 --warmup 1 --resident $B > /dev/null 2> $O/sqb.log
 cd $R
 python tools/pmc_sq.py $O/sqa $O/sqb 40 > $O/sq_counters.txt
 T=$(ls -d $O/trace/*/ | head -1)
 python tools/prof_layers.py $T 512 15360 100 > $O/conv_layers.txt
-head -24 $O/conv_layers.txt > $O/kernel_summary.txt
+head -26 $O/conv_layers.txt > $O/kernel_summary.txt
 cp $(ls $T/*_kernel_stats.csv | head -1) $O/kernel_stats.csv
-python tools/pmc_traffic.py $O/fetch $O/write "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --steps 1 --warmup 1 with AICAM_NO_TAPER=1 (full 512-frame launch groups only); FETCH_SIZE x2 (gfx950 correction of MI355X_MICROARCH.md)" > $O/pmc_traffic.txt
-cp profiles/pmc_traffic.json $O/pmc_traffic.json
+python tools/pmc_traffic.py $O/fetch $O/write "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --steps 1 --warmup 1 --resident with AICAM_NO_TAPER=1 (full 512-frame launch groups only); FETCH_SIZE x2 (gfx950 correction of MI355X_MICROARCH.md)" $TAG > $O/pmc_traffic.txt
 # the bench line last: its roofline.traffic reads the profiles/pmc_traffic.json written just above
 python bench.py > $O/bench.json 2> $O/bench.err
 tail -1 $O/bench.json | cut -c1-300
 rm -rf $O/trace $O/fetch $O/write $O/sqa $O/sqb          # the raw traces stay on the box (tens of MB); the summaries travel back
+for f in bench.json bench_under_rocprof.json kernel_stats.csv kernel_summary.txt conv_layers.txt sq_counters.txt; do cp $O/$f profiles/${TAG}_$f; done
 ls -la $O
