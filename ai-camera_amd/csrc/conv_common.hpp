@@ -10,6 +10,12 @@
 
 namespace aic {
 
+// CUs the persistent (one-block-per-CU) conv kernels size their grids for: all of them, minus the one the association epoch
+// kernel occupies for ~1 ms at a time while the tracker runs on the device (a 256th persistent block would otherwise sit in
+// the queue until that CU or another block's whole share of the images is done).  AICAM_CONV_CUS overrides.
+int conv_cu_budget();
+void set_conv_cu_budget(int cus);
+
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));

@@ -20,6 +20,11 @@
 
 namespace aic {
 
+static int g_conv_cus = [] { const char* e = getenv("AICAM_CONV_CUS"); return e ? std::max(1, atoi(e)) : 256; }();
+int conv_cu_budget() { return g_conv_cus; }
+void set_conv_cu_budget(int cus) { if (getenv("AICAM_CONV_CUS") == nullptr) g_conv_cus = std::max(1, cus); }
+
+
 // 4 waves per block arranged WM x WN; each wave owns MT x NT tiles of 16 pixels x 16 channels.
 template <typename T, int MT, int NT, int WM, int WN>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {

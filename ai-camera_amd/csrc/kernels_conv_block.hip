@@ -232,7 +232,7 @@ bool conv_try_c64_block(const ConvArgs& c1, const ConvArgs& c2, hipStream_t s) {
     // images per block: n_img / 256 = one persistent block per CU, or AICAM_BLK_IPB for shorter-lived blocks (each pays 3 steps
     // of pipeline fill and a weight reload; in exchange the CU takes other streams' waiting blocks in between)
     static const int ipb_env = [] { const char* e = getenv("AICAM_BLK_IPB"); return e ? atoi(e) : 0; }();
-    const int grid = std::min(256, a.n_img);
+    const int grid = std::min(conv_cu_budget(), a.n_img);
     a.ipb = ipb_env > 0 ? ipb_env : (a.n_img + grid - 1) / grid;
     constexpr size_t lds = (size_t)(20 + 16) * 34 * 128 + 1024 + 512;
     static bool attr = false;

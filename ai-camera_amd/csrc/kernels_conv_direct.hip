@@ -373,7 +373,7 @@ static bool try_c64_resident(const ConvArgs& a, hipStream_t s) {
             attr = true;
         }
         static const int split = [] { const char* e = getenv("AICAM_C64R_SPLIT"); return e ? std::max(1, atoi(e)) : 1; }();
-        const int nblk = 256 * split;
+        const int nblk = conv_cu_budget() * split;
         hipLaunchKernelGGL(kfn, dim3(nblk), dim3(512), lds, s, a, n_tiles, tiles_x, tiles_y, nblk);
         KCHECK();
     };

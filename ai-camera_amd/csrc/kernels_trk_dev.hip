@@ -81,14 +81,21 @@ __device__ __forceinline__ void wave_lds_sync() {            // LDS traffic of O
 
 }  // namespace
 
-// grid: any (wave-task loop); block 256 = 4 waves, each with its own 16 x 33 LDS tile.
+// grid: any (wave-task loop); block 256 = 4 waves, each with its own 16 x 36 LDS tile (row pitch 36 floats: the four row groups
+// a lane quartet writes land in disjoint bank ranges).
+// SM task = (track, 32 detections): K is the OUTER loop and up to SMG = 7 gallery row groups (112 rows) are accumulated side by
+// side, so the detection features cross L2 -> registers once per task instead of once per row group (36 loads per 224 MFMAs
+// instead of 84); the accumulation order of every single dot product is unchanged (k ascending), so the values are
+// bit-identical to cos_tile's.  The suffix minima are then taken group by group, newest rows first.
+constexpr int SMG = 7;
+
 __global__ __launch_bounds__(256) void trk_epoch_prep_kernel(const DevTrkHdr* __restrict__ hdr, const DevTrack* __restrict__ trk,
                                                              const float* __restrict__ gal_n, int gmax, int dim,
                                                              const float* __restrict__ featn, int dn, int dn_pad, int k,
                                                              float* __restrict__ sm, float* __restrict__ gram) {
-    __shared__ float tiles[4][16][33];
+    __shared__ float tiles[4][16][36];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
-    float (*tile)[33] = tiles[wv];
+    float (*tile)[36] = tiles[wv];
     const int T0 = hdr->n_tracks;
     const int nchunk = dn_pad / 32;
     const int n_sm = T0 * nchunk, n_all = n_sm + (dn_pad / 16) * nchunk;
@@ -99,10 +106,10 @@ __global__ __launch_bounds__(256) void trk_epoch_prep_kernel(const DevTrkHdr* __
         const int d_base = c * 32;
         const float* pa = featn + (size_t)min(d_base + r, dn - 1) * dim;
         const float* pb = featn + (size_t)min(d_base + 16 + r, dn - 1) * dim;
-        floatx4 acc0, acc1;
         if (!is_sm) {
             const int a0 = rowi * 16;
             if (a0 >= d_base + 32) continue;                      // rows all later than the columns: never read (an appended row only meets LATER frames)
+            floatx4 acc0, acc1;
             cos_tile(featn + (size_t)min(a0 + r, dn - 1) * dim, pa, pb, dim, q, acc0, acc1);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -118,27 +125,87 @@ __global__ __launch_bounds__(256) void trk_epoch_prep_kernel(const DevTrkHdr* __
         if (lane < 32)
             for (int e = glen0; e <= k; ++e) smt[(size_t)e * dn_pad + lane] = kBig;       // empty suffix
         float R = kBig;
-        for (int g = (glen0 + 15) / 16 - 1; g >= 0; --g) {       // FIFO index groups, newest first
-            const int j = min(16 * g + r, glen0 - 1);
-            int pos = tr.ghead + j;
-            if (pos >= gmax) pos -= gmax;
-            cos_tile(gal_n + ((size_t)tr.slot * gmax + pos) * dim, pa, pb, dim, q, acc0, acc1);
+        const int G = (glen0 + 15) / 16;
+        for (int gb = ((G - 1) / SMG) * SMG; gb >= 0; gb -= SMG) {   // batches of SMG row groups, newest batch first
+            const int ng = min(SMG, G - gb);
+            const float* grow[SMG];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                tile[4 * q + e][r] = cos_dist(acc0[e]);
-                tile[4 * q + e][16 + r] = cos_dist(acc1[e]);
+            for (int g = 0; g < SMG; ++g) {
+                const int j = min(16 * (gb + min(g, ng - 1)) + r, glen0 - 1);      // groups past the end alias the last one (never read back)
+                int pos = tr.ghead + j;
+                if (pos >= gmax) pos -= gmax;
+                grow[g] = gal_n + ((size_t)tr.slot * gmax + pos) * dim;
             }
-            wave_lds_sync();
-            if (lane < 32) {
-                for (int jj = 15; jj >= 0; --jj) {
-                    const int row = 16 * g + jj;
-                    if (row < glen0) {
-                        R = fminf(R, tile[jj][lane]);
-                        if (row <= k) smt[(size_t)row * dn_pad + lane] = R;     // min over FIFO rows >= row
+            floatx4 acc[SMG][2];
+#pragma unroll
+            for (int g = 0; g < SMG; ++g) acc[g][0] = acc[g][1] = floatx4{0.f, 0.f, 0.f, 0.f};
+            int k0 = 0;
+            for (; k0 + 64 <= dim; k0 += 64) {
+                floatx4 b0[4], b1[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int kk = k0 + 16 * u + 4 * q;
+                    b0[u] = *reinterpret_cast<const floatx4*>(pa + kk);
+                    b1[u] = *reinterpret_cast<const floatx4*>(pb + kk);
+                }
+#pragma unroll
+                for (int g = 0; g < SMG; ++g) {
+                    if (g < ng) {
+                        floatx4 a[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) a[u] = *reinterpret_cast<const floatx4*>(grow[g] + k0 + 16 * u + 4 * q);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                acc[g][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][e], b0[u][e], acc[g][0], 0, 0, 0);
+                                acc[g][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][e], b1[u][e], acc[g][1], 0, 0, 0);
+                            }
                     }
                 }
             }
-            wave_lds_sync();
+            for (; k0 < dim; k0 += 16) {                          // tail: any dimension, element-guarded
+                const int kk = k0 + 4 * q;
+                floatx4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (kk + e < dim) { b0[e] = pa[kk + e]; b1[e] = pb[kk + e]; }
+#pragma unroll
+                for (int g = 0; g < SMG; ++g) {
+                    if (g < ng) {
+                        floatx4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (kk + e < dim) a[e] = grow[g][kk + e];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            acc[g][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b0[e], acc[g][0], 0, 0, 0);
+                            acc[g][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b1[e], acc[g][1], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int g = SMG - 1; g >= 0; --g) {                  // suffix minima, newest rows first
+                if (g < ng) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        tile[4 * q + e][r] = cos_dist(acc[g][0][e]);
+                        tile[4 * q + e][16 + r] = cos_dist(acc[g][1][e]);
+                    }
+                    wave_lds_sync();
+                    if (lane < 32) {
+                        for (int jj = 15; jj >= 0; --jj) {
+                            const int row = 16 * (gb + g) + jj;
+                            if (row < glen0) {
+                                R = fminf(R, tile[jj][lane]);
+                                if (row <= k) smt[(size_t)row * dn_pad + lane] = R;     // min over FIFO rows >= row
+                            }
+                        }
+                    }
+                    wave_lds_sync();
+                }
+            }
         }
     }
 }
@@ -253,6 +320,12 @@ __device__ __forceinline__ double wave_min_f64(double x) {
     const unsigned long long k = f64_key(x);
     const unsigned hi = (unsigned)(k >> 32), lo = (unsigned)k;
     const unsigned mh = wave_umin32(hi);
+    const unsigned long long top = __ballot(hi == mh);
+    if (__popcll(top) == 1) {                                   // one lane holds the smallest high word: it IS the minimum
+        const int l = __ffsll((long long)top) - 1;
+        const unsigned ml1 = (unsigned)__builtin_amdgcn_readlane((int)lo, l);
+        return key_f64(((unsigned long long)mh << 32) | ml1);
+    }
     const unsigned ml = wave_umin32(hi == mh ? lo : 0xffffffffu);
     return key_f64(((unsigned long long)mh << 32) | ml);
 }
@@ -902,7 +975,7 @@ void launch_gallery_shard(const DevTrkHdr* hdr, const DevTrack* trk, const float
 }
 
 // ------------------------------------------------------------------------------------------------ launchers
-static int epoch_lds_bytes() { return 152 * 1024; }
+static int epoch_lds_bytes() { return 159 * 1024; }
 
 void launch_trk_epoch_prep(const DevTrkHdr* hdr, const DevTrack* trk, const float* gal_n, int gmax, int dim, int cap, const float* featn,
                            int dn, int dn_pad, int k, float* sm, float* gram, hipStream_t s) {

@@ -14,6 +14,7 @@
 // src/tracker/deepsort_tracker.py:88-101).
 #include "engine.hpp"
 #include "tracker.hpp"
+#include "conv_common.hpp"
 
 #include <algorithm>
 #include <chrono>
@@ -436,6 +437,8 @@ struct Pipeline {
         AIC_REQUIRE(passes >= 1, AIC_ERR_INVALID, "passes must be >= 1");
         dev->use();
         if (count <= 0) return;
+        // the association epoch kernel holds one CU while the next group's convs run: persistent conv grids leave it free
+        set_conv_cu_budget(dev_assoc && trk.dev_capable() ? dev->n_cu - 1 : dev->n_cu);
         // Launch groups: full batches, then the last batch tapered (1/2, 1/4, ... down to 16 frames): stage B of the
         // final group cannot overlap any GPU work, so a short final group shortens the un-overlapped tail of the call.
         std::vector<int> goff, glen;

@@ -525,7 +525,8 @@ void Tracker::run_epochs(const EpochDets& dets, const int* h_n, const int* h_d0,
     d_sub.ensure((size_t)TRK_DEV_TMAX * TRK_DEV_NMAX);
     d_appends.ensure((size_t)3 * TRK_DEV_DNMAX);
     d_dbg.ensure(16 + 2 * TRK_DEV_TMAX);
-    const int kmax = std::max(1, std::min(TRK_KMAX, gmax));
+    static const int k_env = [] { const char* e = getenv("AICAM_TRK_K"); return e ? atoi(e) : 16; }();   // frames per epoch (measured: 8 / 16 / 32)
+    const int kmax = std::max(1, std::min(std::min(TRK_KMAX, k_env), gmax));
     int f = 0;
     while (f < frames) {
         int k = 0, dn = 0, nmax = 0;
@@ -544,7 +545,9 @@ void Tracker::run_epochs(const EpochDets& dets, const int* h_n, const int* h_d0,
             d_gram.ensure((size_t)dn_pad * dn_pad);
             scr.sm = d_sm.p, scr.gram = d_gram.p;
             Prof pr(*dev, PROF_TRK, s, 2.0 * ((double)cap * gmax + dn) * dn * dim, 0);
-            launch_trk_epoch_prep(tbl_hdr(), tbl_trk(), d_gal_n.p, gmax, dim, cap, dets.feat_n + (size_t)d_begin * dim, dn, dn_pad, k, d_sm.p, d_gram.p, s);
+            static const int rep = [] { const char* e = getenv("AICAM_TRK_PREP_REPEAT"); return e ? std::max(1, atoi(e)) : 1; }();   // measurement: the prep launch's share of the interference
+            for (int r = 0; r < rep; ++r)
+                launch_trk_epoch_prep(tbl_hdr(), tbl_trk(), d_gal_n.p, gmax, dim, cap, dets.feat_n + (size_t)d_begin * dim, dn, dn_pad, k, d_sm.p, d_gram.p, s);
         }
         EpochOut o = out;
         const bool last = f + k >= frames;

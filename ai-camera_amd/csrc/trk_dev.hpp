@@ -2,7 +2,7 @@
 // tracker.cpp / pipeline.cpp (host).  SURVEY.md §8(f)-4; what it replaces per frame: one launch + one stream sync + the host
 // cascade/LSAP/lifecycle of Tracker::update (src/tracker/core/tracker_core.py:51-81,83-177, linear_assignment.py:19-157).
 //
-// An EPOCH is k <= TRK_KMAX consecutive frames of one video stream.  Per epoch two launches, no host round trip:
+// An EPOCH is k <= TRK_KMAX (32) consecutive frames of one video stream.  Per epoch two launches, no host round trip:
 //   trk_epoch_prep_kernel   (many blocks)  every cosine distance the k frames can need, in bulk on the matrix cores:
 //                           SM[t][e][d]  = min over the rows of track t's gallery that are still alive after e evictions
 //                                          (suffix minima in FIFO order) of max(0, 1 - <row, det d>),
@@ -16,7 +16,7 @@
 
 namespace aic {
 
-constexpr int TRK_KMAX = 16;        // frames per epoch (also <= gallery budget: rows appended in an epoch are never evicted in it)
+constexpr int TRK_KMAX = 32;        // frames per epoch (also <= gallery budget: rows appended in an epoch are never evicted in it)
 constexpr int TRK_DEV_TMAX = 512;   // tracks the single-block kernel handles (= its thread count)
 constexpr int TRK_DEV_NMAX = 512;   // detections per frame
 constexpr int TRK_DEV_DNMAX = 2048; // detections per epoch

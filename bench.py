@@ -341,7 +341,7 @@ def main():
                        "frame_latency_ms(handed to the pipeline -> tuples on host, full launch groups of the timed run)":
                            {"p50": pct(g_lat[full], g_frames[full], 0.5), "p99": pct(g_lat[full], g_frames[full], 0.99)},
                        "by_launch_group_frames(from host, 3 passes each)": side.get("by_launch_group_frames"),
-                       "association": "on the device, epochs of 16 frames (csrc/kernels_trk_dev.hip)" if not os.environ.get("AICAM_TRK_HOST") else "host C++ cascade/LSAP, one launch + sync per frame",
+                       "association": "on the device, epochs of 32 frames (csrc/kernels_trk_dev.hip)" if not os.environ.get("AICAM_TRK_HOST") else "host C++ cascade/LSAP, one launch + sync per frame",
                        "gallery_exchange_every_frames": args.gallery_exchange, "gallery_exchanges_done": exchanges,
                        "host_affinity": affinity,
                        "host_us_per_frame": {"issue_launch_groups(producer thread)": round(1e6 * host["issue_s"] / max(host["frames"], 1), 1),
