@@ -505,6 +505,130 @@ __device__ bool lsap_wave64(const float* cm, int nr, int nc, const Lds& L, int l
     return true;
 }
 
+// Register-resident form for up to 64 * CPL columns: lane l holds columns l, l + 64, ... (and rows likewise).  Same algorithm and
+// tie rules as lsap_wave64 (CPL = 1 compiles to it); every register array is indexed by unrolled constants only.
+template <int CPL>
+__device__ bool lsap_wave_reg(const float* cm, int nr, int nc, const Lds& L, int lane) {
+    const bool tall = nr > nc;
+    const int R = tall ? nc : nr, C = tall ? nr : nc;
+    const double inf = __longlong_as_double(0x7ff0000000000000ll);
+    double v[CPL], u[CPL], dist[CPL];
+    int rowof[CPL], colof[CPL], pred[CPL], pos[CPL];
+    bool seen[CPL];
+#pragma unroll
+    for (int s = 0; s < CPL; ++s) { v[s] = 0.0; u[s] = 0.0; dist[s] = inf; rowof[s] = -1; colof[s] = -1; pred[s] = -1; }
+    auto pick_i = [&](const int (&a)[CPL], int idx) {            // a[idx >> 6] on lane idx & 63, idx uniform
+        int x = a[0];
+#pragma unroll
+        for (int s = 1; s < CPL; ++s) if ((idx >> 6) == s) x = a[s];
+        return __builtin_amdgcn_readlane(x, idx & 63);
+    };
+    for (int root = 0; root < R; ++root) {
+#pragma unroll
+        for (int s = 0; s < CPL; ++s) {
+            const int j = lane + 64 * s;
+            dist[s] = inf;
+            pos[s] = j < C ? C - 1 - j : -1;
+            seen[s] = false;
+        }
+        double base = 0.0;
+        int live = C, i = root, sink = -1;
+        while (sink < 0) {
+            double us = u[0];
+#pragma unroll
+            for (int s = 1; s < CPL; ++s) if ((i >> 6) == s) us = u[s];
+            const double ui = readlane_f64(us, i & 63);
+            double lmin = inf;
+#pragma unroll
+            for (int s = 0; s < CPL; ++s) {
+                if (pos[s] >= 0) {
+                    const int j = lane + 64 * s;
+                    const float cij = tall ? cm[(size_t)j * nc + i] : cm[(size_t)i * nc + j];
+                    const double red = ((base + (double)cij) - ui) - v[s];
+                    if (red < dist[s]) { dist[s] = red; pred[s] = i; }
+                    lmin = dist[s] < lmin ? dist[s] : lmin;
+                }
+            }
+            const double m = wave_min_f64(lmin);
+            if (!(m < inf)) return false;
+            unsigned pa = 0u, pb = 0xffffffffu;
+            int ncand = 0;
+#pragma unroll
+            for (int s = 0; s < CPL; ++s) {
+                const bool cand = pos[s] >= 0 && dist[s] == m;
+                ncand += __popcll(__ballot(cand));
+                if (cand) {
+                    pb = min(pb, (unsigned)pos[s]);
+                    if (rowof[s] < 0) pa = max(pa, (unsigned)pos[s] + 1u);
+                }
+            }
+            int pick;
+            if (ncand == 1) pick = (int)wave_umin32(pb);            // (one lane holds it; a 32-bit reduce is cheaper than locating it twice)
+            else {
+                const unsigned pam = wave_umax32(pa);
+                pick = pam ? (int)pam - 1 : (int)wave_umin32(pb);
+            }
+            base = m;
+            int jp = 0, jl = 0;
+#pragma unroll
+            for (int s = 0; s < CPL; ++s) {
+                const unsigned long long b1 = __ballot(pos[s] == pick);
+                if (b1) jp = 64 * s + __ffsll((long long)b1) - 1;
+                const unsigned long long b2 = __ballot(pos[s] == live - 1);
+                if (b2) jl = 64 * s + __ffsll((long long)b2) - 1;
+            }
+            const int rj = pick_i(rowof, jp);
+            if (rj < 0) sink = jp; else i = rj;
+#pragma unroll
+            for (int s = 0; s < CPL; ++s) {
+                const int j = lane + 64 * s;
+                if (j == jl) pos[s] = pick;                        // the list's last entry moves into the freed place
+                if (j == jp) { pos[s] = -1; seen[s] = true; }
+            }
+            --live;
+        }
+        // dual update (lsap.cpp:83-87)
+        double dlt[CPL];
+#pragma unroll
+        for (int s = 0; s < CPL; ++s) dlt[s] = base - dist[s];
+#pragma unroll
+        for (int s = 0; s < CPL; ++s) {                           // row (lane, s): partner column colof[s] = lane' + 64 * s2
+            const int cj = colof[s] >= 0 ? colof[s] : 0;
+            double dl = 0.0;
+            int sn = 0;
+#pragma unroll
+            for (int s2 = 0; s2 < CPL; ++s2) {
+                const double d2 = __shfl(dlt[s2], cj & 63);
+                const int n2 = __shfl((int)seen[s2], cj & 63);
+                if ((cj >> 6) == s2) { dl = d2; sn = n2; }
+            }
+            if (lane + 64 * s < R && colof[s] >= 0 && sn) u[s] = u[s] + dl;
+        }
+#pragma unroll
+        for (int s = 0; s < CPL; ++s) {
+            if (seen[s]) v[s] = v[s] - dlt[s];
+            if (lane + 64 * s == root) u[s] = u[s] + base;
+        }
+        int j = sink;
+        for (;;) {                                                 // flip the path back to the root
+            const int i2 = pick_i(pred, j);
+            const int t = pick_i(colof, i2);
+#pragma unroll
+            for (int s = 0; s < CPL; ++s) {
+                if (lane + 64 * s == j) rowof[s] = i2;
+                if (lane + 64 * s == i2) colof[s] = j;
+            }
+            j = t;
+            if (i2 == root) break;
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < CPL; ++s)
+        if (lane + 64 * s < nr) L.asg[lane + 64 * s] = tall ? rowof[s] : colof[s];
+    wave_lds_sync();
+    return true;
+}
+
 }  // namespace
 
 struct EpochArgs {
@@ -544,7 +668,11 @@ __device__ void match_block(const Lds& L, const EpochArgs& a, const FrameCosts& 
     __threadfence_block();
     __syncthreads();
     if (threadIdx.x < 64) {
-        const bool ok = (nr <= 64 && nc <= 64) ? lsap_wave64(sub, nr, nc, L, threadIdx.x) : lsap_wave(sub, nr, nc, L, threadIdx.x);
+        const int side = max(nr, nc);
+        const bool ok = side <= 64 ? lsap_wave64(sub, nr, nc, L, threadIdx.x)
+                      : side <= 128 ? lsap_wave_reg<2>(sub, nr, nc, L, threadIdx.x)
+                      : side <= 256 ? lsap_wave_reg<4>(sub, nr, nc, L, threadIdx.x)
+                                    : lsap_wave(sub, nr, nc, L, threadIdx.x);
         if (!ok && threadIdx.x == 0) *err = 2;
     }
     __syncthreads();

@@ -17,6 +17,7 @@
 #include "conv_common.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdlib>
 #include <condition_variable>
@@ -34,6 +35,7 @@ struct FrameDets {
 
 struct Chunk {
     int frames = 0, first_slot = 0, n_crops = 0;
+    bool dev_mode = false;           // this group's association runs on the device (decided when the group is issued)
     PinBuf<float> h_boxes;
     PinBuf<int> h_frame_of, h_valid;
     DevBuf<float> d_boxes, d_emb, d_emb_n;
@@ -69,7 +71,16 @@ struct Pipeline {
     // host-side wall time (seconds): issuing launch groups, waiting for a group, walking frames through the tracker
     double t_issue = 0, t_wait = 0, t_track = 0;
     long n_frames_done = 0;
-    bool dev_assoc = getenv("AICAM_TRK_HOST") == nullptr;   // association on the device, k frames per launch (aic_pipeline_option("device_assoc"))
+    // association on the device, k frames per launch (aic_pipeline_option("device_assoc")): 0 = host C++ cascade / LSAP, one launch +
+    // sync per frame; 2 = always on the device; 1 (default) = on the device while a frame's assignment problems fit ONE wavefront's
+    // registers (<= 64 tracks and <= 64 detections: lsap_wave64, cost matrices in LDS), else on the host for that launch group --
+    // beyond 64 x 64 the single-wave LSAP is slower than the host's (configs[2], 100 x 100: 290 vs 230 us per frame)
+    int dev_assoc = getenv("AICAM_TRK_HOST") ? 0 : (getenv("AICAM_TRK_DEV") ? 2 : 1);
+    std::atomic<int> tracks_seen{0};      // live tracks after the most recent launch group (sizes the next group's choice)
+    bool use_device(int n_max) const {
+        if (!dev_assoc || !trk.dev_capable()) return false;
+        return dev_assoc == 2 || (n_max <= 64 && tracks_seen.load() + n_max / 2 <= 64) || x_shard[0] != nullptr;
+    }
     bool taper = getenv("AICAM_NO_TAPER") == nullptr;   // aic_pipeline_option("taper")
     // configs[4]: cross-camera gallery exchange. The pipeline packs a shard of the stream's confirmed tracks on
     // the tracker stream every x_every launch groups; a consumer thread (ai-camera_amd/distributed.py) all-gathers it over
@@ -243,7 +254,10 @@ struct Pipeline {
                 c.h_frame_of.p[fd.crop0 + i] = f;
             }
         }
-        const bool dev_mode = dev_assoc && trk.dev_capable();
+        int n_max = 0;
+        for (int f = 0; f < frames; ++f) n_max = std::max(n_max, c.dets[f].n);
+        const bool dev_mode = use_device(n_max);
+        c.dev_mode = dev_mode;
         if (dev_mode) {   // what the epoch kernels read: frame_n[frames] | frame_d0[frames] | tlwh[nc,4] | conf[nc] | cls[nc]
             c.m_n = 0, c.m_d0 = (size_t)frames * 4, c.m_tlwh = (((size_t)frames * 8 + 15) / 16) * 16;
             c.m_conf = c.m_tlwh + (size_t)nc * 16, c.m_cls = c.m_conf + (size_t)nc * 4, c.m_bytes = c.m_cls + (size_t)nc * 4 + 16;
@@ -364,6 +378,7 @@ struct Pipeline {
             }
         }
         trk.defer_outputs = false;             // direct users of the tracker handle get synchronous outputs
+        tracks_seen = (int)trk.tracks.size();
         last_chunk = (int)(&c - &ck[0]);
         t_track += now() - t1;
         n_frames_done += c.frames;
@@ -402,6 +417,7 @@ struct Pipeline {
         t_track += t1 - t0;                                    // host time of the association: planning + launches
         HIP_CHECK(hipStreamSynchronize(s));
         trk.check_epochs();
+        tracks_seen = reinterpret_cast<const DevTrkHdr*>(trk.h_tbl.p)->n_tracks;
         const double t2 = now();
         t_wait += t2 - t1;
         const int* on = reinterpret_cast<const int*>(c.h_out.p);
@@ -439,6 +455,7 @@ struct Pipeline {
         if (count <= 0) return;
         // the association epoch kernel holds one CU while the next group's convs run: persistent conv grids leave it free
         set_conv_cu_budget(dev_assoc && trk.dev_capable() ? dev->n_cu - 1 : dev->n_cu);
+        tracks_seen = trk.on_device ? tracks_seen.load() : (int)trk.tracks.size();
         // Launch groups: full batches, then the last batch tapered (1/2, 1/4, ... down to 16 frames): stage B of the
         // final group cannot overlap any GPU work, so a short final group shortens the un-overlapped tail of the call.
         std::vector<int> goff, glen;
@@ -499,7 +516,7 @@ struct Pipeline {
                     cv.wait(lk, [&] { return issued > k; });
                     if (perr) break;
                 }
-                if (dev_assoc && trk.dev_capable()) {
+                if (ck[k % NCK].dev_mode) {
                     trk.dev_assoc = true;
                     stage_b_device(ck[k % NCK], goff[k], n_tracks, tracks6, track_conf, n_dets, det_boxes, det_scores, det_labels);
                 } else {
@@ -714,7 +731,10 @@ int aic_pipeline_option(aic_pipeline* p, const char* key, int value) {
         AIC_REQUIRE(p && key, AIC_ERR_INVALID, "NULL argument");
         const std::string k(key);
         if (k == "taper") p->p.taper = value != 0;
-        else if (k == "device_assoc") p->p.dev_assoc = value != 0;
+        else if (k == "device_assoc") {
+            AIC_REQUIRE(value >= 0 && value <= 2, AIC_ERR_INVALID, "device_assoc: 0 host, 1 auto, 2 always on the device");
+            p->p.dev_assoc = value;
+        }
         else if (k == "group_frames") {
             AIC_REQUIRE(value >= 0 && value <= p->p.prm.batch, AIC_ERR_INVALID, "group_frames must be in 0..batch");
             p->p.group_frames = value;

@@ -279,9 +279,11 @@ int aic_pipeline_tracker(aic_pipeline* p, aic_tracker** out);
 int aic_pipeline_stats(aic_pipeline* p, double* issue_s, double* wait_s, double* track_s, int64_t* frames, int reset);
 /* Runtime options (tests / measurements). "taper": 1 (default) = the last launch group of a call is split into
  * shrinking groups so its un-overlapped tail is short, 0 = full groups only.  "group_frames": frames per launch group
- * (<= batch; 0 = batch).  "device_assoc": 1 (default) = association on the device, k frames per launch (cascade, LSAP
- * and lifecycle in csrc/kernels_trk_dev.hip, no host round trip per frame); 0 = cost matrices on the device, cascade /
- * LSAP / lifecycle in host C++ (csrc/assoc_host.cpp, lsap.cpp), one launch + one sync per frame. */
+ * (<= batch; 0 = batch).  "device_assoc": 2 = association on the device, k frames per launch (cascade, LSAP and
+ * lifecycle in csrc/kernels_trk_dev.hip, no host round trip per frame); 0 = cost matrices on the device, cascade / LSAP /
+ * lifecycle in host C++ (csrc/assoc_host.cpp, lsap.cpp), one launch + one sync per frame; 1 (default) = per launch group, on
+ * the device while the assignment problems fit one wavefront's registers (<= 64 tracks x 64 detections), else on the host.
+ * Same results in every mode. */
 int aic_pipeline_option(aic_pipeline* p, const char* key, int value);
 /* Launch groups whose crop count outgrew the buffers sized from max_persons (handled, not dropped), and frames
  * whose confirmed tracks outnumbered the caller's max_persons rows (n_tracks reports the true count). */

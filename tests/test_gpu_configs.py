@@ -145,15 +145,17 @@ def test_yolov8m_head_decode_nms(gpu, engines_m, scene_1080, dtype, tol_logit, t
     eng.close()
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "fp16"])
-def test_configs2_pipeline_ids(gpu, engines_m, scene_1080, dtype):
+@pytest.mark.parametrize("dtype,assoc", [("fp32", 1), ("fp16", 1), ("fp16", 2)])
+def test_configs2_pipeline_ids(gpu, engines_m, scene_1080, dtype, assoc):
     """configs[2]-shaped run: YOLOv8m, 1920x1080, 100 planted persons (ReID groups of 400 crops, 100 x 100 association):
-    track ids, classes and boxes of every frame against the oracle chain."""
+    track ids, classes and boxes of every frame against the oracle chain.  assoc 1 = the pipeline's default (100 x 100 does not fit
+    one wavefront's registers: cascade / LSAP in host C++), 2 = forced onto the device (two columns per lane, cost matrices in HBM)."""
     n_frames, batch = 12, 4
     sc = scene_1080
     frames = sc.render_batch(0, n_frames)
     TP = pkg("pipeline").TrackingPipeline
     pipe = TP(engines_m[0], engines_m[1], (1080, 1920), batch=batch, ring_frames=n_frames, max_persons=104, dtype=dtype, inject=True)
+    pipe.option("device_assoc", assoc)
     pipe.upload(0, frames)
     pipe.inject(0, [sc.detections(f)[:3] for f in range(n_frames)])
     tracks, nd = pipe.run(0, n_frames)

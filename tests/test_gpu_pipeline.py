@@ -41,7 +41,7 @@ def test_pipeline_inject_matches_oracle(gpu, engines, dtype, assoc):
     frames = sc.render_batch(0, n_frames)
     TP = pkg("pipeline").TrackingPipeline
     pipe = TP(engines[0], engines[1], (720, 1280), batch=batch, ring_frames=n_frames, max_persons=16, dtype=dtype, inject=True)
-    pipe.option("device_assoc", int(assoc == "device"))     # association on the device (k frames per launch) / cascade + LSAP in host C++
+    pipe.option("device_assoc", 2 if assoc == "device" else 0)     # association on the device (k frames per launch) / cascade + LSAP in host C++
     pipe.upload(0, frames)
     pipe.inject(0, [sc.detections(f)[:3] for f in range(n_frames)])
     tracks, nd = pipe.run(0, n_frames)
@@ -133,7 +133,7 @@ def test_pipeline_small_gallery_budget(gpu, engines, assoc):
     TP = pkg("pipeline").TrackingPipeline
     pipe = TP(engines[0], engines[1], (720, 1280), batch=batch, ring_frames=n_frames, max_persons=16, dtype="fp32", inject=True,
               nn_budget=3, max_age=4)
-    pipe.option("device_assoc", int(assoc == "device"))     # device: epochs are capped at the gallery budget (3 frames per launch)
+    pipe.option("device_assoc", 2 if assoc == "device" else 0)     # device: epochs are capped at the gallery budget (3 frames per launch)
     pipe.upload(0, frames)
     pipe.inject(0, [sc.detections(f)[:3] for f in range(n_frames)])
     tracks, nd = pipe.run(0, n_frames)
