@@ -181,3 +181,29 @@ def test_gallery_exchange_hooks_single_gpu(gpu, engines):
     assert np.abs(g[valid, 2:] - newest).max() < 1e-5
     assert ex.last_annotation.shape == (128, 3) and (ex.last_annotation[:, 0] < 0).all()     # no other camera in a world of 1
     pipe.close()
+
+
+def test_association_mode_switches_between_launch_groups(gpu, engines):
+    """Default (auto) mode: the association of a launch group runs on the device while its problems fit one wavefront (<= 64 tracks x 64
+    detections) and in host C++ beyond.  A scene that grows from 40 to 76 persons crosses that line mid-run, so the track table
+    travels HBM -> host (and the Kalman state / galleries stay where they are): ids, classes, boxes of every frame and the final
+    table must still be the oracle's."""
+    n_frames, batch = 40, 8
+    births = {t: 4 + (t - 40) // 3 for t in range(40, 76)}            # 36 late births, three per frame from frame 4 on
+    sc = syn.Scene(seed=31, n_targets=76, births=births, w_range=(30.0, 50.0), h_range=(90.0, 140.0))
+    frames = sc.render_batch(0, n_frames)
+    TP = pkg("pipeline").TrackingPipeline
+    pipe = TP(engines[0], engines[1], (720, 1280), batch=batch, ring_frames=n_frames, max_persons=80, dtype="fp16", inject=True)
+    pipe.upload(0, frames)
+    pipe.inject(0, [sc.detections(f)[:3] for f in range(n_frames)])
+    tracks, nd = pipe.run(0, n_frames)
+    torch.set_num_threads(16)
+    ref, embs, otrk = oracle_tracks(sc, N.EngineOracle(engines[1]), frames, n_frames)
+    assert len(ref[3]) == 40 and len(ref[-1]) == 76
+    for f in range(n_frames):
+        assert [t[4:6] for t in tracks[f]] == [t[4:6] for t in ref[f]], f
+        if ref[f]:
+            assert np.abs(np.array([t[:4] for t in tracks[f]]) - np.array([t[:4] for t in ref[f]])).max() <= 1
+    a = pipe.tracker_core.export_arrays()
+    assert a["track_id"].tolist() == [t.track_id for t in otrk.tracks] and a["hits"].tolist() == [t.hits for t in otrk.tracks]
+    pipe.close()
