@@ -317,6 +317,19 @@ void Model::run_range(size_t op0, size_t op1, int i0, int n, hipStream_t s) {
                 if (!pair) fl = fl0, by = by0;
             }
             if (prof_conv && !span_open) { dev->prof_begin(PROF_CONV, s, 0, 0); span_open = true; }
+            // a C2f block with 16-channel halves (YOLOv8n's 160 x 160 stage: cv1, m.cv1, m.cv2 + shortcut, cv2) runs as ONE kernel where
+            // it applies; FLOPs and algorithmic bytes are accounted as for the four convs
+            if (!pair && dtype == AIC_F16 && oi + 3 < op1 && a.KH == 1 && a.Cin == 32 && a.Cout == 32 && ops[oi + 1].v[0] == OP_CONV &&
+                ops[oi + 2].v[0] == OP_CONV && ops[oi + 3].v[0] == OP_CONV && !ops[oi + 1].fuse && !ops[oi + 2].fuse && !ops[oi + 3].fuse) {
+                const double fl0 = fl, by0 = by;
+                const ConvArgs b1 = conv_args(oi + 1), b2 = conv_args(oi + 2), b3 = conv_args(oi + 3);
+                if (conv_try_c2f16(a, b1, b2, b3, s)) {
+                    if (prof_conv) dev->prof_account(PROF_CONV, fl, by);
+                    oi += 3;
+                    continue;
+                }
+                fl = fl0, by = by0;
+            }
             if (pair && conv_try_c64_block(a, a2, s)) {
                 if (prof_conv) dev->prof_account(PROF_CONV, fl, by);
                 ++oi;

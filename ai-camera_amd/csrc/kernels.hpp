@@ -30,6 +30,9 @@ void launch_conv_igemm(int dtype, const ConvArgs& a, hipStream_t s);
 // a whole 64-channel BasicBlock (c1: conv3x3+ReLU, c2: conv3x3 + block input, ReLU) in one fp16 kernel with the intermediate in
 // LDS (kernels_conv_block.hip); false = pattern / geometry not supported, nothing launched
 bool conv_try_c64_block(const ConvArgs& c1, const ConvArgs& c2, hipStream_t s);
+// a whole C2f block with 16-channel halves (cv1 1x1 32->32, m.cv1 / m.cv2 3x3 16->16 with shortcut, cv2 1x1 48->32) in one fp16 kernel,
+// concat buffer and intermediate in LDS (kernels_conv_c2f.hip); false = pattern / geometry not supported, nothing launched
+bool conv_try_c2f16(const ConvArgs& cv1, const ConvArgs& m_cv1, const ConvArgs& m_cv2, const ConvArgs& cv2, hipStream_t s);
 
 // letterbox + conv 3x3/2 (3->16) + SiLU fused (fp16 YOLOv8 stem); false = geometry not supported, nothing launched
 struct LetterboxGeom;

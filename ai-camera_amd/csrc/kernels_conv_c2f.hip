@@ -1,0 +1,213 @@
+// kernels_conv_c2f.hip -- a whole C2f block of YOLOv8n's 160 x 160 stage (Ultralytics yolov8.yaml layer 2: c1 = c2 = 32, n = 1,
+// shortcut) as ONE kernel: cv1 (1x1, 32 -> 32) -> split -> m.cv1 (3x3, 16 -> 16) -> m.cv2 (3x3, 16 -> 16, + its input) -> concat ->
+// cv2 (1x1, 48 -> 32), every conv + folded-BN bias + SiLU, fp16 in / fp32 accumulate / fp16 out.
+//
+// Why: as four launches the stage moves 17.5 MB per frame through HBM (the 48-channel concat buffer and the 16-channel
+// intermediate are written and read back) for 0.44 GFLOP -- 2.2 ms per 512-frame launch group at 40-180 TFLOP/s, four times its
+// HBM floor.  Fused, a block reads the 32-channel input of its tile once (with a halo of 2) and writes the 32-channel output once:
+// 4.9 MB per frame; the concat buffer and the intermediate never leave the CU.
+//
+// A block owns 8 x 32 output pixels of one image (4 waves).  LDS, pixel-major, 16-byte channel groups:
+//   X   [12 x 36][32]  the input tile with halo 2 (zeros outside the image)
+//   Y0  [12 x 36][32]  cv1's output: channels 0-15 = the pass-through half, 16-31 = the bottleneck's input; ZERO outside the
+//                      image (what the 3x3 convs' zero padding sees -- NOT cv1 applied to padding)
+//   T   [10 x 34][16]  m.cv1's output with halo 1, zero outside the image
+//   Y1  [ 8 x 32][16]  m.cv2's output + its input (the shortcut)
+// MFMA conventions are those of conv3x3_c16_kernel (kernels_conv_direct.hip): weights = A operand (lane (r, q): row r, K elements
+// 8q..8q+7 of a 32-deep step), pixels = B operand (one aligned 16-byte ds_read per lane and step), a 3x3 over 16 channels =
+// 5 steps of two taps each with the bias as accumulator init; the 1x1 convs add the bias after the accumulation like the generic
+// epilogue does.  Same K order per output as the unfused kernels.
+#include "conv_common.hpp"
+
+namespace aic {
+
+namespace {
+
+constexpr int TH = 8, TW = 32;
+constexpr int XR = TH + 4, XC = TW + 4;          // 12 x 36: cv1 region
+constexpr int TR = TH + 2, TC = TW + 2;          // 10 x 34: m.cv1 region
+constexpr int LDS_X = 0, LDS_Y0 = XR * XC * 64, LDS_T = LDS_Y0 + XR * XC * 64, LDS_Y1 = LDS_T + TR * TC * 32;
+constexpr int LDS_BYTES = LDS_Y1 + TH * TW * 32;
+
+}  // namespace
+
+struct C2fArgs {
+    const half_t* x; half_t* y;
+    const half_t *w1, *w2, *w3, *w4;
+    const float *b1, *b2, *b3, *b4;
+    int x_cs, x_coff, y_cs, y_coff, H, W, n_img, xcd_map;
+};
+
+__global__ __launch_bounds__(256) void c2f16_fused_kernel(const C2fArgs a, int tiles_x, int tiles_y) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, r = lane & 15, q = lane >> 4;
+    int bx = xcd_tile((int)blockIdx.x, (int)gridDim.x, a.xcd_map);
+    const int tx = bx % tiles_x; bx /= tiles_x;
+    const int ty = bx % tiles_y;
+    const int img = bx / tiles_y;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const half_t* xg = a.x + (size_t)img * a.H * a.W * a.x_cs + a.x_coff;
+
+    // ---- S1: input tile with halo 2 -> LDS (four 16-byte channel groups per pixel)
+    for (int idx = t; idx < XR * XC * 4; idx += 256) {
+        const int g = idx & 3, p = idx >> 2;
+        const int pr = p / XC, pc = p - pr * XC;
+        const int iy = oy0 - 2 + pr, ix = ox0 - 2 + pc;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
+            v = *reinterpret_cast<const uint4*>(xg + ((size_t)iy * a.W + ix) * a.x_cs + g * 8);
+        *reinterpret_cast<uint4*>(smem + LDS_X + p * 64 + g * 16) = v;
+    }
+    // weights as A fragments
+    half8 w1[2], w2[5], w3[5], w4[2][2];
+    floatx4 bi1[2], bi2, bi3, bi4[2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+        w1[ct] = *reinterpret_cast<const half8*>(a.w1 + (size_t)(16 * ct + r) * 32 + 8 * q);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) w4[ct][m] = *reinterpret_cast<const half8*>(a.w4 + (size_t)perm_row<2>(ct, r) * 64 + 32 * m + 8 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { bi1[ct][e] = a.b1[16 * ct + 4 * q + e]; bi4[ct][e] = a.b4[perm_ch<2>(ct, q, e)]; }
+    }
+#pragma unroll
+    for (int m = 0; m < 5; ++m) {
+        w2[m] = *reinterpret_cast<const half8*>(a.w2 + (size_t)r * 160 + 32 * m + 8 * q);
+        w3[m] = *reinterpret_cast<const half8*>(a.w3 + (size_t)r * 160 + 32 * m + 8 * q);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { bi2[e] = a.b2[4 * q + e]; bi3[e] = a.b3[4 * q + e]; }
+    __syncthreads();
+
+    // ---- S2: cv1 on the 12 x 36 region (27 tiles of 16 pixels): Y0 = SiLU(W1 x + b1), zero outside the image
+    for (int tile = wv; tile < (XR * XC) / 16; tile += 4) {
+        const int p = tile * 16 + r;
+        const half8 xb = *reinterpret_cast<const half8*>(smem + LDS_X + p * 64 + q * 16);
+        const int pr = p / XC, pc = p - pr * XC;
+        const bool inside = (unsigned)(oy0 - 2 + pr) < (unsigned)a.H && (unsigned)(ox0 - 2 + pc) < (unsigned)a.W;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[ct], xb, acc, 0, 0, 0);
+            half4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = inside ? (half_t)act_fast<1>(acc[e] + bi1[ct][e]) : (half_t)0.f;
+            *reinterpret_cast<half4*>(smem + LDS_Y0 + p * 64 + ct * 32 + q * 8) = o;
+        }
+    }
+    __syncthreads();
+
+    // ---- S3: m.cv1 (3x3 over Y0's channels 16-31) on the 10 x 34 region: T = SiLU(W2 * Y0b + b2), zero outside the image
+    {
+        int d[5];
+#pragma unroll
+        for (int m = 0; m < 5; ++m) {
+            const int tap = min(2 * m + (q >> 1), 8), kh = tap / 3, kw = tap - 3 * kh;
+            d[m] = (kh * XC + kw) * 64 + 32 + (q & 1) * 16;
+        }
+        for (int tile = wv; tile < (TR * TC + 15) / 16; tile += 4) {
+            const int p = min(tile * 16 + r, TR * TC - 1);
+            const int pr = p / TC, pc = p - pr * TC;
+            const int base = LDS_Y0 + (pr * XC + pc) * 64;          // top-left tap of this output pixel
+            floatx4 acc = bi2;
+#pragma unroll
+            for (int m = 0; m < 5; ++m)
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2[m], *reinterpret_cast<const half8*>(smem + base + d[m]), acc, 0, 0, 0);
+            const bool inside = (unsigned)(oy0 - 1 + pr) < (unsigned)a.H && (unsigned)(ox0 - 1 + pc) < (unsigned)a.W;
+            half4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = inside ? (half_t)act_fast<1>(acc[e]) : (half_t)0.f;
+            if (tile * 16 + r < TR * TC) *reinterpret_cast<half4*>(smem + LDS_T + p * 32 + q * 8) = o;
+        }
+    }
+    __syncthreads();
+
+    // ---- S4: m.cv2 (3x3 over T) on the 8 x 32 outputs, + the bottleneck's input (shortcut): Y1 = SiLU(W3 * T + b3) + Y0b
+    {
+        int d[5];
+#pragma unroll
+        for (int m = 0; m < 5; ++m) {
+            const int tap = min(2 * m + (q >> 1), 8), kh = tap / 3, kw = tap - 3 * kh;
+            d[m] = (kh * TC + kw) * 32 + (q & 1) * 16;
+        }
+#pragma unroll
+        for (int tile = 0; tile < 4; ++tile) {
+            const int oyl = 2 * wv + (tile >> 1), oxl = (tile & 1) * 16 + r;
+            const int base = LDS_T + (oyl * TC + oxl) * 32;
+            floatx4 acc = bi3;
+#pragma unroll
+            for (int m = 0; m < 5; ++m)
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w3[m], *reinterpret_cast<const half8*>(smem + base + d[m]), acc, 0, 0, 0);
+            const half4 res = *reinterpret_cast<const half4*>(smem + LDS_Y0 + ((oyl + 2) * XC + oxl + 2) * 64 + 32 + q * 8);
+            half4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (half_t)(act_fast<1>(acc[e]) + (float)res[e]);
+            *reinterpret_cast<half4*>(smem + LDS_Y1 + (oyl * TW + oxl) * 32 + q * 8) = o;
+        }
+    }
+    __syncthreads();
+
+    // ---- S5: cv2 (1x1 over the 48 concatenated channels) -> global: out = SiLU(W4 [Y0a, Y0b, Y1] + b4)
+    half_t* yg = a.y + (size_t)img * a.H * a.W * a.y_cs + a.y_coff;
+#pragma unroll
+    for (int tile = 0; tile < 4; ++tile) {
+        const int oyl = 2 * wv + (tile >> 1), oxl = (tile & 1) * 16 + r;
+        const half8 x0 = *reinterpret_cast<const half8*>(smem + LDS_Y0 + ((oyl + 2) * XC + oxl + 2) * 64 + q * 16);
+        const half8 x1 = *reinterpret_cast<const half8*>(smem + LDS_Y1 + (oyl * TW + oxl) * 32 + (q & 1) * 16);   // k 32..47; k 48..63 meet zero weights
+        float v[2][4];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w4[ct][0], x0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w4[ct][1], x1, acc, 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[ct][e] = act_fast<1>(acc[e] + bi4[ct][e]);
+        }
+        const half8 o = {(half_t)v[0][0], (half_t)v[0][1], (half_t)v[0][2], (half_t)v[0][3],
+                         (half_t)v[1][0], (half_t)v[1][1], (half_t)v[1][2], (half_t)v[1][3]};
+        *reinterpret_cast<half8*>(yg + ((size_t)(oy0 + oyl) * a.W + ox0 + oxl) * a.y_cs + 8 * q) = o;   // perm_ch<2>: lane owns channels 8q..8q+7
+    }
+}
+
+// cv1 -> m.cv1 -> m.cv2 (+ shortcut) -> cv2 of a C2f with 16-channel halves, when the four convs are wired as engine_file.py's c2f()
+// wires them; false = pattern / geometry not supported, nothing launched.
+bool conv_try_c2f16(const ConvArgs& c1, const ConvArgs& m1, const ConvArgs& m2, const ConvArgs& c2, hipStream_t s) {
+    static const bool off = getenv("AICAM_NO_C2F") != nullptr;
+    if (off) return false;
+    auto one = [](const ConvArgs& c, int cin, int cout, int kp) {
+        return c.KH == 1 && c.KW == 1 && c.stride == 1 && c.pad == 0 && c.Cin == cin && c.Cout == cout && c.Kp == kp && c.act == 1 &&
+               c.res_mode == 0 && !c.out_f32;
+    };
+    auto three = [](const ConvArgs& c) {
+        return c.KH == 3 && c.KW == 3 && c.stride == 1 && c.pad == 1 && c.Cin == 16 && c.Cout == 16 && c.Kp == 160 && c.act == 1 && !c.out_f32;
+    };
+    if (!one(c1, 32, 32, 32) || !one(c2, 48, 32, 64) || !three(m1) || !three(m2) || m1.res_mode != 0 || m2.res_mode != 2) return false;
+    const int H = c1.H, W = c1.W;
+    for (const ConvArgs* c : {&c1, &m1, &m2, &c2})
+        if (c->H != H || c->W != W || c->Ho != H || c->Wo != W || c->M != c1.M) return false;
+    if (H % TH || W % TW) return false;
+    // wiring: cv1 writes cat[0:32]; m.cv1 reads cat[16:32] -> tmp; m.cv2 reads tmp, adds cat[16:32], writes cat[32:48]; cv2 reads cat[0:48]
+    const void* cat = c1.y;
+    if (c1.y_coff != 0 || m1.x != cat || m1.x_coff != 16 || m1.x_cs != c1.y_cs || m2.x != m1.y || m2.x_coff != m1.y_coff || m2.x_cs != m1.y_cs ||
+        m2.y != cat || m2.y_coff != 32 || m2.res != cat || m2.r_coff != 16 || m2.r_cs != c1.y_cs || c2.x != cat || c2.x_coff != 0 ||
+        c2.x_cs != c1.y_cs || c1.y_cs < 48)
+        return false;
+    if ((c1.x_cs | c1.x_coff | c2.y_cs | c2.y_coff) % 8) return false;
+    C2fArgs a{};
+    a.x = reinterpret_cast<const half_t*>(c1.x), a.y = reinterpret_cast<half_t*>(c2.y);
+    a.w1 = reinterpret_cast<const half_t*>(c1.w), a.w2 = reinterpret_cast<const half_t*>(m1.w);
+    a.w3 = reinterpret_cast<const half_t*>(m2.w), a.w4 = reinterpret_cast<const half_t*>(c2.w);
+    a.b1 = c1.bias, a.b2 = m1.bias, a.b3 = m2.bias, a.b4 = c2.bias;
+    a.x_cs = c1.x_cs, a.x_coff = c1.x_coff, a.y_cs = c2.y_cs, a.y_coff = c2.y_coff, a.H = H, a.W = W;
+    a.n_img = c1.M / (H * W), a.xcd_map = xcd_map_on();
+    static bool attr = false;
+    if (!attr) {
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(c2f16_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        attr = true;
+    }
+    const int tiles_x = W / TW, tiles_y = H / TH;
+    hipLaunchKernelGGL(c2f16_fused_kernel, dim3(a.n_img * tiles_x * tiles_y), dim3(256), (size_t)LDS_BYTES, s, a, tiles_x, tiles_y);
+    KCHECK();
+    return true;
+}
+
+}  // namespace aic

@@ -304,3 +304,56 @@ def test_hip_engine_trt_surface(gpu, engines):
     assert o.shape == (3, 512) and torch.allclose(o.norm(dim=1), torch.ones(3, device=o.device), atol=1e-4)
     with pytest.raises(RuntimeError):
         r({"input": torch.randn(17, 3, 128, 64)})         # beyond engine capacity -> loud, not silent
+
+
+def _c2f_graph(path):
+    """stem conv 3 -> 32, then a C2f wired exactly like engine_file.build_yolov8's layer 2 (cv1 32->32, m.cv1 / m.cv2 3x3 16->16 with
+    shortcut, cv2 48->32) on a 24 x 64 map (3 x 2 tiles of the fused kernel: every border and corner case), pooled to an embedding."""
+    g = ef.Graph(ef.KIND_REID, 24, 64)
+    wg = ef._WeightGen(5)
+    def conv(name, src, dst, cin, cout, k, s, act, **kw):
+        g.conv(name, src, dst, cin, cout, k, s, act, wb=wg(cout, cin, k, act), **kw)
+    inp = g.buf(24, 64, 8)
+    b1 = g.buf(24, 64, 32); conv("stem", inp, b1, 3, 32, 3, 1, ef.ACT_SILU)
+    cat = g.buf(24, 64, 48); tmp = g.buf(24, 64, 16); out = g.buf(24, 64, 32)
+    conv("c2f.cv1", b1, cat, 32, 32, 1, 1, ef.ACT_SILU)
+    conv("c2f.m0.cv1", cat, tmp, 16, 16, 3, 1, ef.ACT_SILU, src_coff=16)
+    conv("c2f.m0.cv2", tmp, cat, 16, 16, 3, 1, ef.ACT_SILU, dst_coff=32, res=(cat, 16), res_mode=ef.RES_ACT_THEN_ADD)
+    conv("c2f.cv2", cat, out, 48, 32, 1, 1, ef.ACT_SILU)
+    # a strided "probe": keep spatial structure in the output (an average pool would hide a wrong border ring)
+    probe = g.buf(12, 32, 16); conv("probe", out, probe, 32, 16, 3, 2, ef.ACT_NONE)
+    p = g.buf(1, 1, 16); g.simple(ef.OP_AVGPOOL, probe, p, 16)
+    q = g.buf(1, 1, 64); conv("fc", p, q, 16, 64, 1, 1, ef.ACT_NONE)
+    emb = g.buf(1, 1, 64, ef.DT_F32); g.simple(ef.OP_L2NORM, q, emb, 64)
+    g.outputs.append([emb, 64, 0, 0, 0, 0, 0, 0]); g.meta = [64, 0, 0, 0, 0, 0, 0, 0]
+    ef.write_engine(path, g)
+    return out, probe
+
+
+def test_fused_c2f_block(gpu, tmp_path):
+    """The one-kernel C2f (csrc/kernels_conv_c2f.hip) against the fp32 oracle on a map where every tile touches a border, and
+    against the four-launch form of the same engine (child process, AICAM_NO_C2F=1): differences = fp16 rounding only."""
+    import subprocess
+    import sys
+    path = str(tmp_path / "c2f.aicw")
+    _c2f_graph(path)
+    x = np.random.default_rng(2).standard_normal((5, 3, 24, 64)).astype(np.float32)
+    eo = N.EngineOracle(path)
+    ref = eo.run(torch.from_numpy(x))[eo.outputs[0][0]][:, :, 0, 0].numpy()
+    eng = HipEngine(path, dtype="fp16", max_items=8, warm_up=False)
+    got = eng.reid_infer_np(x)
+    eng.close()
+    err = np.abs(got - ref).max()
+    code = r"""
+import importlib, sys, numpy as np
+sys.path.insert(0, %r)
+he = importlib.import_module("ai-camera_amd.hip_engine")
+x = np.load(%r)
+np.save(%r, he.HipEngine(%r, dtype="fp16", max_items=8, warm_up=False).reid_infer_np(x))
+""" % (ROOT, str(tmp_path / "x.npy"), str(tmp_path / "unfused.npy"), path)
+    np.save(tmp_path / "x.npy", x)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, AICAM_NO_C2F="1"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-1500:]
+    unf = np.load(tmp_path / "unfused.npy")
+    print(f"fused C2f: err vs fp32 oracle {err:.2e} (four-launch form: {np.abs(unf - ref).max():.2e}); fused vs four launches {np.abs(got - unf).max():.2e}")
+    assert err < 5e-3 and np.abs(got - unf).max() < 2e-3

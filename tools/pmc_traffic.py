@@ -4,7 +4,7 @@ MI355X_MICROARCH.md prescribes) -> profiles/pmc_traffic.json (read by bench.py's
   python tools/pmc_traffic.py <fetch_dir> <write_dir> "<method note>" [tag]   (tag: also profiles/<tag>_pmc_traffic.json) """
 import csv, glob, json, os, sys
 
-CONV = ("conv_igemm_dma_kernel", "conv3x3_patch_kernel", "conv_igemm_pp_kernel", "conv3x3_pp_patch_kernel", "conv_igemm_kernel", "conv3x3_c16_kernel", "conv3x3_c64_resident_kernel", "conv3x3_c64_block_kernel")
+CONV = ("conv_igemm_dma_kernel", "conv3x3_patch_kernel", "conv_igemm_pp_kernel", "conv3x3_pp_patch_kernel", "conv_igemm_kernel", "conv3x3_c16_kernel", "conv3x3_c64_resident_kernel", "conv3x3_c64_block_kernel", "c2f16_fused_kernel")
 
 
 def per_launch(d, counter):

@@ -34,7 +34,7 @@ def main(d, frames=16, crops=480, top=30, fused_stem=1, fused_yolo_stem=1, fused
     print(f"{'kernel':42s} {'calls':>7s} {'total ms':>9s} {'%':>6s} {'avg us':>8s}")
     for n, (c, us) in sorted(tot.items(), key=lambda kv: -kv[1][1])[:24]:
         print(f"{n[:42]:42s} {c:7d} {us / 1e3:9.2f} {100 * us / all_us:6.1f} {us / c:8.1f}")
-    conv = [r for r in rows if any(k in r["Kernel_Name"] for k in ("conv_igemm", "conv3x3_patch", "conv3x3_pp_patch", "conv3x3_c16", "conv3x3_c64_resident", "conv3x3_c64_block"))]
+    conv = [r for r in rows if any(k in r["Kernel_Name"] for k in ("conv_igemm", "conv3x3_patch", "conv3x3_pp_patch", "conv3x3_c16", "conv3x3_c64_resident", "conv3x3_c64_block", "c2f16_fused"))]
     layers = []
     for name, g, n in (("yolo", ef.build_yolov8("n", calibrate=False), frames), ("reid", ef.build_reid(calibrate=False), crops)):
         for o in g.ops:
@@ -51,10 +51,22 @@ def main(d, frames=16, crops=480, top=30, fused_stem=1, fused_yolo_stem=1, fused
             else:
                 merged.append(L)
         layers = merged
+    if fused_block:     # YOLOv8n's 160 x 160 C2f (cv1, m0.cv1, m0.cv2, cv2) is ONE launch of c2f16_fused_kernel: N*K = sum over the four convs
+        merged, i = [], 0
+        while i < len(layers):
+            L = layers[i]
+            if L[0] == "yolo" and L[1] == "2.c2f.cv1" and i + 3 < len(layers) and layers[i + 3][1] == "2.c2f.cv2":
+                nk = sum(x[3] * x[4] for x in layers[i:i + 4])
+                merged.append(("yolo", "2.c2f (fused x4)", L[2], 1, nk))
+                i += 4
+            else:
+                merged.append(L)
+                i += 1
+        layers = merged
     per = len(layers)
     # a launch group starts at its (fused) YOLO stem; groups of other sizes (tapered tail of a call: fewer frames, and below
     # the fused-block threshold two more launches) are dropped: keep the groups with `per` conv launches and the modal grid
-    is_conv = lambda r: any(k in r["Kernel_Name"] for k in ("conv_igemm", "conv3x3_patch", "conv3x3_pp_patch", "conv3x3_c16", "conv3x3_c64_resident", "conv3x3_c64_block"))
+    is_conv = lambda r: any(k in r["Kernel_Name"] for k in ("conv_igemm", "conv3x3_patch", "conv3x3_pp_patch", "conv3x3_c16", "conv3x3_c64_resident", "conv3x3_c64_block", "c2f16_fused"))
     glist, cur = [], None
     for r in rows:
         if "yolo_stem_fused" in r["Kernel_Name"] or "letterbox" in r["Kernel_Name"]:
