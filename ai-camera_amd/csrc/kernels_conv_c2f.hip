@@ -7,12 +7,14 @@
 // HBM floor.  Fused, a block reads the 32-channel input of its tile once (with a halo of 2) and writes the 32-channel output once:
 // 4.9 MB per frame; the concat buffer and the intermediate never leave the CU.
 //
-// A block owns 8 x 32 output pixels of one image (4 waves).  LDS, pixel-major, 16-byte channel groups:
-//   X   [12 x 36][32]  the input tile with halo 2 (zeros outside the image)
-//   Y0  [12 x 36][32]  cv1's output: channels 0-15 = the pass-through half, 16-31 = the bottleneck's input; ZERO outside the
-//                      image (what the 3x3 convs' zero padding sees -- NOT cv1 applied to padding)
-//   T   [10 x 34][16]  m.cv1's output with halo 1, zero outside the image
-//   Y1  [ 8 x 32][16]  m.cv2's output + its input (the shortcut)
+// A block owns 8 x 32 output pixels of one image (4 waves).  LDS: every tensor as PLANES of 8 channels, [plane][pixel] x 16 bytes, so
+// the 16 lanes that share a K slice read 16 consecutive pixels = 256 contiguous bytes (pixel-major 64- or 32-byte pixels put
+// lanes r and r + 4 / r + 8 on the same banks: 63 % LDS bank-conflict cycles measured, SQ_LDS_BANK_CONFLICT):
+//   X   4 planes [12 x 36]  the input tile with halo 2 (zeros outside the image)
+//   Y0  4 planes [12 x 36]  cv1's output: planes 0-1 = the pass-through half, 2-3 = the bottleneck's input; ZERO outside the
+//                           image (what the 3x3 convs' zero padding sees -- NOT cv1 applied to padding)
+//   T   2 planes [10 x 34]  m.cv1's output with halo 1, zero outside the image
+//   Y1  2 planes [ 8 x 32]  m.cv2's output + its input (the shortcut)
 // MFMA conventions are those of conv3x3_c16_kernel (kernels_conv_direct.hip): weights = A operand (lane (r, q): row r, K elements
 // 8q..8q+7 of a 32-deep step), pixels = B operand (one aligned 16-byte ds_read per lane and step), a 3x3 over 16 channels =
 // 5 steps of two taps each with the bias as accumulator init; the 1x1 convs add the bias after the accumulation like the generic
@@ -26,8 +28,9 @@ namespace {
 constexpr int TH = 8, TW = 32;
 constexpr int XR = TH + 4, XC = TW + 4;          // 12 x 36: cv1 region
 constexpr int TR = TH + 2, TC = TW + 2;          // 10 x 34: m.cv1 region
-constexpr int LDS_X = 0, LDS_Y0 = XR * XC * 64, LDS_T = LDS_Y0 + XR * XC * 64, LDS_Y1 = LDS_T + TR * TC * 32;
-constexpr int LDS_BYTES = LDS_Y1 + TH * TW * 32;
+constexpr int PX = XR * XC * 16, PT = TR * TC * 16, PY = TH * TW * 16;      // bytes of one 8-channel plane of X / Y0, T, Y1
+constexpr int LDS_X = 0, LDS_Y0 = 4 * PX, LDS_T = LDS_Y0 + 4 * PX, LDS_Y1 = LDS_T + 2 * PT;
+constexpr int LDS_BYTES = LDS_Y1 + 2 * PY;
 
 }  // namespace
 
@@ -56,7 +59,7 @@ __global__ __launch_bounds__(256) void c2f16_fused_kernel(const C2fArgs a, int t
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
         if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
             v = *reinterpret_cast<const uint4*>(xg + ((size_t)iy * a.W + ix) * a.x_cs + g * 8);
-        *reinterpret_cast<uint4*>(smem + LDS_X + p * 64 + g * 16) = v;
+        *reinterpret_cast<uint4*>(smem + LDS_X + g * PX + p * 16) = v;
     }
     // weights as A fragments
     half8 w1[2], w2[5], w3[5], w4[2][2];
@@ -81,7 +84,7 @@ __global__ __launch_bounds__(256) void c2f16_fused_kernel(const C2fArgs a, int t
     // ---- S2: cv1 on the 12 x 36 region (27 tiles of 16 pixels): Y0 = SiLU(W1 x + b1), zero outside the image
     for (int tile = wv; tile < (XR * XC) / 16; tile += 4) {
         const int p = tile * 16 + r;
-        const half8 xb = *reinterpret_cast<const half8*>(smem + LDS_X + p * 64 + q * 16);
+        const half8 xb = *reinterpret_cast<const half8*>(smem + LDS_X + q * PX + p * 16);
         const int pr = p / XC, pc = p - pr * XC;
         const bool inside = (unsigned)(oy0 - 2 + pr) < (unsigned)a.H && (unsigned)(ox0 - 2 + pc) < (unsigned)a.W;
 #pragma unroll
@@ -91,7 +94,7 @@ __global__ __launch_bounds__(256) void c2f16_fused_kernel(const C2fArgs a, int t
             half4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = inside ? (half_t)act_fast<1>(acc[e] + bi1[ct][e]) : (half_t)0.f;
-            *reinterpret_cast<half4*>(smem + LDS_Y0 + p * 64 + ct * 32 + q * 8) = o;
+            *reinterpret_cast<half4*>(smem + LDS_Y0 + (2 * ct + (q >> 1)) * PX + p * 16 + (q & 1) * 8) = o;
         }
     }
     __syncthreads();
@@ -102,12 +105,12 @@ __global__ __launch_bounds__(256) void c2f16_fused_kernel(const C2fArgs a, int t
 #pragma unroll
         for (int m = 0; m < 5; ++m) {
             const int tap = min(2 * m + (q >> 1), 8), kh = tap / 3, kw = tap - 3 * kh;
-            d[m] = (kh * XC + kw) * 64 + 32 + (q & 1) * 16;
+            d[m] = (2 + (q & 1)) * PX + (kh * XC + kw) * 16;
         }
         for (int tile = wv; tile < (TR * TC + 15) / 16; tile += 4) {
             const int p = min(tile * 16 + r, TR * TC - 1);
             const int pr = p / TC, pc = p - pr * TC;
-            const int base = LDS_Y0 + (pr * XC + pc) * 64;          // top-left tap of this output pixel
+            const int base = LDS_Y0 + (pr * XC + pc) * 16;          // top-left tap of this output pixel
             floatx4 acc = bi2;
 #pragma unroll
             for (int m = 0; m < 5; ++m)
@@ -116,7 +119,7 @@ __global__ __launch_bounds__(256) void c2f16_fused_kernel(const C2fArgs a, int t
             half4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = inside ? (half_t)act_fast<1>(acc[e]) : (half_t)0.f;
-            if (tile * 16 + r < TR * TC) *reinterpret_cast<half4*>(smem + LDS_T + p * 32 + q * 8) = o;
+            if (tile * 16 + r < TR * TC) *reinterpret_cast<half4*>(smem + LDS_T + (q >> 1) * PT + p * 16 + (q & 1) * 8) = o;
         }
     }
     __syncthreads();
@@ -127,21 +130,21 @@ __global__ __launch_bounds__(256) void c2f16_fused_kernel(const C2fArgs a, int t
 #pragma unroll
         for (int m = 0; m < 5; ++m) {
             const int tap = min(2 * m + (q >> 1), 8), kh = tap / 3, kw = tap - 3 * kh;
-            d[m] = (kh * TC + kw) * 32 + (q & 1) * 16;
+            d[m] = (q & 1) * PT + (kh * TC + kw) * 16;
         }
 #pragma unroll
         for (int tile = 0; tile < 4; ++tile) {
             const int oyl = 2 * wv + (tile >> 1), oxl = (tile & 1) * 16 + r;
-            const int base = LDS_T + (oyl * TC + oxl) * 32;
+            const int base = LDS_T + (oyl * TC + oxl) * 16;
             floatx4 acc = bi3;
 #pragma unroll
             for (int m = 0; m < 5; ++m)
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w3[m], *reinterpret_cast<const half8*>(smem + base + d[m]), acc, 0, 0, 0);
-            const half4 res = *reinterpret_cast<const half4*>(smem + LDS_Y0 + ((oyl + 2) * XC + oxl + 2) * 64 + 32 + q * 8);
+            const half4 res = *reinterpret_cast<const half4*>(smem + LDS_Y0 + (2 + (q >> 1)) * PX + ((oyl + 2) * XC + oxl + 2) * 16 + (q & 1) * 8);
             half4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = (half_t)(act_fast<1>(acc[e]) + (float)res[e]);
-            *reinterpret_cast<half4*>(smem + LDS_Y1 + (oyl * TW + oxl) * 32 + q * 8) = o;
+            *reinterpret_cast<half4*>(smem + LDS_Y1 + (q >> 1) * PY + (oyl * TW + oxl) * 16 + (q & 1) * 8) = o;
         }
     }
     __syncthreads();
@@ -151,8 +154,8 @@ __global__ __launch_bounds__(256) void c2f16_fused_kernel(const C2fArgs a, int t
 #pragma unroll
     for (int tile = 0; tile < 4; ++tile) {
         const int oyl = 2 * wv + (tile >> 1), oxl = (tile & 1) * 16 + r;
-        const half8 x0 = *reinterpret_cast<const half8*>(smem + LDS_Y0 + ((oyl + 2) * XC + oxl + 2) * 64 + q * 16);
-        const half8 x1 = *reinterpret_cast<const half8*>(smem + LDS_Y1 + (oyl * TW + oxl) * 32 + (q & 1) * 16);   // k 32..47; k 48..63 meet zero weights
+        const half8 x0 = *reinterpret_cast<const half8*>(smem + LDS_Y0 + q * PX + ((oyl + 2) * XC + oxl + 2) * 16);
+        const half8 x1 = *reinterpret_cast<const half8*>(smem + LDS_Y1 + (q & 1) * PY + (oyl * TW + oxl) * 16);   // k 32..47; k 48..63 meet zero weights
         float v[2][4];
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
