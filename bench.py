@@ -220,7 +220,11 @@ def main():
     host_frames = np.empty((frames_per_step, args.height, args.width, 3), np.uint8)
     host_frames[:R] = sc.render_batch(0, R)
     host_frames[R:] = host_frames[:R][::-1]
-    TP.pin(host_frames)
+    pinned = True
+    try:
+        TP.pin(host_frames)
+    except Exception as e:      # e.g. a memlock limit: the span stays the same, the copies become staged (noted in the line)
+        pinned = f"no ({e})"
     dets = [sc.detections(f)[:3] for f in range(R)]
     pipe.inject(0, [dets[f] for f in order])
 
@@ -343,7 +347,7 @@ def main():
                        "by_launch_group_frames(from host, 3 passes each)": side.get("by_launch_group_frames"),
                        "association": "on the device, epochs of 32 frames (csrc/kernels_trk_dev.hip)" if not os.environ.get("AICAM_TRK_HOST") else "host C++ cascade/LSAP, one launch + sync per frame",
                        "gallery_exchange_every_frames": args.gallery_exchange, "gallery_exchanges_done": exchanges,
-                       "host_affinity": affinity,
+                       "host_affinity": affinity, "host_clip_page_locked": pinned,
                        "host_us_per_frame": {"issue_launch_groups(producer thread)": round(1e6 * host["issue_s"] / max(host["frames"], 1), 1),
                                              "wait_for_gpu": round(1e6 * host["wait_s"] / max(host["frames"], 1), 1),
                                              "tracker_chain(host side of the association)": round(1e6 * host["track_s"] / max(host["frames"], 1), 1)},
@@ -351,7 +355,8 @@ def main():
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
-    TP.unpin(host_frames)
+    if pinned is True:
+        TP.unpin(host_frames)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
