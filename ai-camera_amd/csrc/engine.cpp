@@ -278,7 +278,8 @@ void Model::run_range(size_t op0, size_t op1, int i0, int n, hipStream_t s) {
             pb.p = at(pb);
             const double fl = 2.0 * n * sb.h * sb.w * 64.0 * 27.0;
             Prof pr(*dev, PROF_CONV_DIRECT, s, fl, (double)n * (sb.h * sb.w * 16.0 + pb.h * pb.w * 128.0));
-            launch_reid_stem_pool(sb.p, w.w.p, w.bias.p, pb.p, n, sb.h, sb.w, w.Kp, pb.c, pv[5], in_pix4 ? 4 : 8, s);
+            launch_reid_stem_pool(sb.p, w.w.p, w.bias.p, pb.p, n, sb.h, sb.w, w.Kp, pb.c, pv[5], in_pix4 ? 4 : 8, s,
+                                  (crop_src.frames && in_pix4 && i0 == 0) ? &crop_src : nullptr);
             continue;
         }
         if (v[0] == OP_CONV) {

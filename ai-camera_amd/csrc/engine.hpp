@@ -40,6 +40,8 @@ struct Model {
     // fp16 ReID engines with the fused stem take NHWC4 crops (8 bytes per pixel: half the crop traffic); whoever fills
     // input() says which layout it wrote
     bool in_pix4 = false;
+    // set around run(): the fused stem takes its crops straight from these frames / boxes (pipeline; no crop tensor in HBM)
+    CropSrc crop_src{nullptr, 0, 0, nullptr, nullptr, nullptr};
     bool input_pix4_ok() const;
     void run(int n_items, hipStream_t s);
     // u8 BGR frames -> letterbox -> the whole graph; fp16 YOLO engines fuse the letterbox into the stem conv

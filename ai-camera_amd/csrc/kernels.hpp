@@ -41,8 +41,10 @@ bool launch_yolo_stem_fused(const uint8_t* frames, int n, const LetterboxGeom& g
 
 // conv 3x3/1 (3->64) + ReLU + max-pool 3x3/2 fused (fp16, W == 64, H % 8 == 0): ReID stem
 // in_stride: halves per input pixel, 8 (NHWC8) or 4 (NHWC4 = RGB0; only where reid_stem2_usable(H, W))
+// frames != NULL: the fused fp16 ReID stem resamples every crop from the u8 frames itself (boxes [n,4] xyxy, frame_of[n] or NULL, valid[n] written)
+struct CropSrc { const uint8_t* frames; int fh, fw; const float* boxes; const int* frame_of; int* valid; };
 void launch_reid_stem_pool(const void* x, const void* w, const float* bias, void* y, int n, int H, int W, int Kp, int y_cs,
-                           int y_coff, int in_stride, hipStream_t s);
+                           int y_coff, int in_stride, hipStream_t s, const CropSrc* crop = nullptr);
 bool reid_stem2_usable(int H, int W);
 
 struct EltArgs {

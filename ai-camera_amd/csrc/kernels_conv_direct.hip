@@ -1,6 +1,7 @@
 // kernels_conv_direct.hip -- conv kernels that keep the input PATCH in LDS instead of gathering im2col tiles: the 4-wave
 // patch kernel (v3), the 16-input-channel direct kernel, the persistent weights-resident kernel, the fused ReID stem.
 #include "conv_common.hpp"
+#include "pre_math.hpp"
 
 namespace aic {
 
@@ -595,6 +596,9 @@ struct StemArgs {
     const void* x; const void* w; const float* bias; void* y;
     int n, H, W, Kp, y_cs, y_coff;   // input [n][H][W][in_stride]; output [n][H/2][W/2][y_cs]
     int in_stride;                   // halves per input pixel: 8 (NHWC8) or 4 (NHWC4, RGB0)
+    // fused crop (second stem form only): frames != NULL = the block resamples its crop from the u8 frame itself
+    // (_extract_image_crops + preprocess_reid_input, deepsort_tracker.py:143-159 / image_processing.py:105-138) instead of reading x
+    const uint8_t* frames; int fh, fw; const float* boxes; const int* frame_of; int* valid;
 };
 
 __global__ __launch_bounds__(256) void reid_stem_pool_kernel(const StemArgs a) {
@@ -717,12 +721,79 @@ __global__ __launch_bounds__(512) void reid_stem_pool2_kernel(const StemArgs a) 
     const int img = blockIdx.x;
     const half_t* xg = reinterpret_cast<const half_t*>(a.x) + (size_t)img * H * CW * a.in_stride;
 
-    for (int idx = t; idx < (H + 2) * PW; idx += 512) {
-        const int iy = idx / PW, ix = idx - iy * PW;
-        const int gy = iy - 1, gx = ix - 1;
-        uint2 v = make_uint2(0u, 0u);
-        if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)CW) v = *reinterpret_cast<const uint2*>(xg + ((size_t)gy * CW + gx) * a.in_stride);
-        patch[idx] = v;
+    if (a.frames == nullptr) {
+        for (int idx = t; idx < (H + 2) * PW; idx += 512) {
+            const int iy = idx / PW, ix = idx - iy * PW;
+            const int gy = iy - 1, gx = ix - 1;
+            uint2 v = make_uint2(0u, 0u);
+            if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)CW) v = *reinterpret_cast<const uint2*>(xg + ((size_t)gy * CW + gx) * a.in_stride);
+            patch[idx] = v;
+        }
+    } else {
+        // crop + resize + normalise straight into the patch: the arithmetic of crop_resize_kernel (kernels_pre.hip), pixel for pixel --
+        // int() truncation + clamp of the box, cv2 taps (fp64 coordinates), 11-bit fixed point, (v/255 - mean)/std in fp32, fp16 RGB0.
+        // The 1 GB crop tensor of a 15 360-crop launch group is never written or read back.
+        __shared__ Taps xt[CW];
+        __shared__ Taps yt[256];
+        __shared__ float lut[3][256];
+        const float* bb = a.boxes + (size_t)img * 4;
+        const float lim = 1.0e9f;
+        int x1 = (int)fminf(fmaxf(bb[0], -lim), lim), y1 = (int)fminf(fmaxf(bb[1], -lim), lim);
+        int x2 = (int)fminf(fmaxf(bb[2], -lim), lim), y2 = (int)fminf(fmaxf(bb[3], -lim), lim);
+        x1 = max(0, x1); y1 = max(0, y1); x2 = min(a.fw, x2); y2 = min(a.fh, y2);
+        const bool ok = x1 < x2 && y1 < y2;
+        if (t == 0 && a.valid) a.valid[img] = ok ? 1 : 0;
+        const int sw = x2 - x1, sh = y2 - y1;
+        const bool area2 = ok && is_area2(sw, sh, CW, H);
+        if (ok && !area2) {
+            if (t < CW) xt[t] = taps_x(t, 1.0 / ((double)CW / (double)sw), sw);
+            else if (t - CW < H) yt[t - CW] = taps_y(t - CW, 1.0 / ((double)H / (double)sh), sh);
+        }
+        if (t < 256) {
+            const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+#pragma unroll
+            for (int c = 0; c < 3; ++c) lut[c][t] = ((float)t / 255.0f - mean[c]) / stdv[c];      // image_processing.py:126-131 (fp32)
+        }
+        __syncthreads();
+        const uint8_t* f = a.frames + (size_t)(a.frame_of ? a.frame_of[img] : 0) * a.fh * a.fw * 3;
+        const int pitch = a.fw * 3;
+        for (int idx = t; idx < (H + 2) * PW; idx += 512) {
+            const int iy = idx / PW, ix = idx - iy * PW;
+            const int oy = iy - 1, ox = ix - 1;
+            uint2 v = make_uint2(0u, 0u);                      // the convolution's zero padding; an empty crop is all zeros
+            if (ok && (unsigned)oy < (unsigned)H && (unsigned)ox < (unsigned)CW) {
+                int px[3];
+                if (area2) {
+                    const uint8_t* p0 = f + (size_t)(y1 + 2 * oy) * pitch + (size_t)(x1 + 2 * ox) * 3;
+                    const uint8_t* p1 = p0 + pitch;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) px[c] = ((int)p0[c] + (int)p0[3 + c] + (int)p1[c] + (int)p1[3 + c] + 2) >> 2;
+                } else {
+                    // both taps of a row are 6 consecutive bytes: one aligned 12-byte load per row (the frame ring has >= 16 bytes of slack)
+                    const Taps tx = xt[ox], ty = yt[oy];
+                    const bool two = tx.i1 != tx.i0;
+                    int b0[2][3], b1[2][3];
+#pragma unroll
+                    for (int rr = 0; rr < 2; ++rr) {
+                        const uintptr_t A = reinterpret_cast<uintptr_t>(f + (size_t)(y1 + (rr ? ty.i1 : ty.i0)) * pitch + (size_t)(x1 + tx.i0) * 3);
+                        const uint3 w3 = *reinterpret_cast<const uint3*>(A & ~(uintptr_t)3);
+                        const unsigned shb = (unsigned)(A & 3);
+                        const unsigned q0 = __builtin_amdgcn_alignbyte(w3.y, w3.x, shb), q1 = __builtin_amdgcn_alignbyte(w3.z, w3.y, shb);
+                        b0[rr][0] = q0 & 255u, b0[rr][1] = (q0 >> 8) & 255u, b0[rr][2] = (q0 >> 16) & 255u;
+                        b1[rr][0] = two ? (q0 >> 24) : b0[rr][0], b1[rr][1] = two ? (q1 & 255u) : b0[rr][1], b1[rr][2] = two ? ((q1 >> 8) & 255u) : b0[rr][2];
+                    }
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const int h0 = b0[0][c] * tx.w0 + b1[0][c] * tx.w1;
+                        const int h1 = b0[1][c] * tx.w0 + b1[1][c] * tx.w1;
+                        px[c] = (((ty.w0 * (h0 >> 4)) >> 16) + ((ty.w1 * (h1 >> 4)) >> 16) + 2) >> 2;
+                    }
+                }
+                const half4 hv = {(half_t)lut[0][px[2]], (half_t)lut[1][px[1]], (half_t)lut[2][px[0]], (half_t)0.f};     // BGR -> RGB
+                v = __builtin_bit_cast(uint2, hv);
+            }
+            patch[idx] = v;
+        }
     }
 
     // A operands: MFMA row rho of channel tile ct carries channel perm_row<4>(ct, rho); lane (rho = r, q) holds k = 8q..8q+7
@@ -809,19 +880,23 @@ __global__ __launch_bounds__(512) void reid_stem_pool2_kernel(const StemArgs a) 
 
 bool reid_stem2_usable(int H, int W) {
     static const bool v1 = [] { const char* e = getenv("AICAM_STEM"); return e && e[0] == 'v' && e[1] == '1'; }();
-    return !v1 && W == 64 && H % 16 == 0 && (size_t)(H + 2) * 66 * 8 <= 160 * 1024;
+    return !v1 && W == 64 && H % 16 == 0 && (size_t)(H + 2) * 66 * 8 <= 150 * 1024;
 }
 
 void launch_reid_stem_pool(const void* x, const void* w, const float* bias, void* y, int n, int H, int W, int Kp, int y_cs,
-                           int y_coff, int in_stride, hipStream_t s) {
+                           int y_coff, int in_stride, hipStream_t s, const CropSrc* crop) {
     if (n <= 0) return;
-    StemArgs a{x, w, bias, y, n, H, W, Kp, y_cs, y_coff, in_stride};
+    StemArgs a{x, w, bias, y, n, H, W, Kp, y_cs, y_coff, in_stride, nullptr, 0, 0, nullptr, nullptr, nullptr};
+    if (crop && crop->frames) {
+        AIC_REQUIRE(reid_stem2_usable(H, W) && H <= 256 - 64, AIC_ERR_INVALID, "fused crop needs the second stem form");
+        a.frames = crop->frames, a.fh = crop->fh, a.fw = crop->fw, a.boxes = crop->boxes, a.frame_of = crop->frame_of, a.valid = crop->valid;
+    }
     AIC_REQUIRE(in_stride == 8 || (in_stride == 4 && reid_stem2_usable(H, W)), AIC_ERR_INVALID, "NHWC4 input needs the second stem form");
     const size_t lds2 = (size_t)(H + 2) * 66 * 8;
     if (reid_stem2_usable(H, W)) {
         static bool attr2 = false;
         if (!attr2) {
-            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(reid_stem_pool2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(reid_stem_pool2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));   // + 8 KB of static tap tables
             attr2 = true;
         }
         hipLaunchKernelGGL(reid_stem_pool2_kernel, dim3(n), dim3(512), lds2, s, a);

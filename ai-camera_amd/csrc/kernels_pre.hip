@@ -11,6 +11,7 @@
 // frame in HBM (rows are contiguous, neighbouring threads read neighbouring bytes) and writes one
 // 16-byte NHWC8 pixel (engine input) or three fp32 planes (API parity output).
 #include "kernels.hpp"
+#include "pre_math.hpp"
 
 #include <cmath>
 
@@ -43,35 +44,6 @@ LetterboxGeom letterbox_geometry(int h, int w, int out_h, int out_w) {
     return g;
 }
 
-struct Taps { int i0, i1, w0, w1; };
-
-// cv2 horizontal taps: clamp with the weight forced onto the surviving tap
-__device__ __forceinline__ Taps taps_x(int d, double scale, int n) {
-    float f = (float)(((double)d + 0.5) * scale - 0.5);
-    int s = (int)floorf(f);
-    f = f - (float)s;
-    if (s < 0) { f = 0.f; s = 0; }
-    if (s >= n - 1) { f = 0.f; s = n - 1; }
-    Taps t;
-    t.i0 = s;
-    t.i1 = min(s + 1, n - 1);
-    t.w0 = __float2int_rn((1.f - f) * 2048.f);
-    t.w1 = __float2int_rn(f * 2048.f);
-    return t;
-}
-// cv2 vertical taps: rows clipped, weights kept
-__device__ __forceinline__ Taps taps_y(int d, double scale, int n) {
-    float f = (float)(((double)d + 0.5) * scale - 0.5);
-    const int s = (int)floorf(f);
-    f = f - (float)s;
-    Taps t;
-    t.i0 = min(max(s, 0), n - 1);
-    t.i1 = min(max(s + 1, 0), n - 1);
-    t.w0 = __float2int_rn((1.f - f) * 2048.f);
-    t.w1 = __float2int_rn(f * 2048.f);
-    return t;
-}
-
 // Resample one output pixel (3 channels, BGR order as stored) from a u8 region.
 // region origin (x0,y0), size (sw,sh) inside a frame with row pitch `pitch` bytes.
 __device__ __forceinline__ void sample_px(const uint8_t* __restrict__ img, int pitch, int x0, int y0, int sw, int sh,
@@ -96,7 +68,6 @@ __device__ __forceinline__ void sample_px(const uint8_t* __restrict__ img, int p
     }
 }
 
-__device__ __forceinline__ bool is_area2(int sw, int sh, int dw, int dh) { return sw == 2 * dw && sh == 2 * dh; }
 
 template <typename T>
 __device__ __forceinline__ void store_nhwc8(T* dst, float r, float g, float b) {

@@ -284,14 +284,19 @@ struct Pipeline {
             HIP_CHECK(hipMemcpyAsync(c.d_boxes.p, c.h_boxes.p, (size_t)nc * 16, hipMemcpyHostToDevice, sr));
             HIP_CHECK(hipMemcpyAsync(c.d_frame_of.p, c.h_frame_of.p, (size_t)nc * 4, hipMemcpyHostToDevice, sr));
             reid->in_pix4 = reid->input_pix4_ok();
+            static const bool fuse_crop = getenv("AICAM_NO_FUSE_CROP") == nullptr;
             for (int c0 = 0; c0 < nc; c0 += reid->max_items) {   // more crops than the ReID arena holds: several launch groups, nothing dropped
                 const int k = std::min(reid->max_items, nc - c0);
-                {
+                if (fuse_crop && reid->in_pix4) {
+                    // crop + resize + normalise inside the ReID stem kernel: the crop tensor (1 GB per 15 360 crops) never exists
+                    reid->crop_src = CropSrc{f0, prm.frame_h, prm.frame_w, c.d_boxes.p + (size_t)c0 * 4, c.d_frame_of.p + c0, c.d_valid.p + c0};
+                } else {
                     Prof pr(*dev, PROF_CROP, sr, 0, (double)k * reid->in_h * reid->in_w * 19);
                     launch_crop_resize(f0, prm.frame_h, prm.frame_w, c.d_boxes.p + (size_t)c0 * 4, c.d_frame_of.p + c0, k, nullptr, reid->in_h,
                                        reid->in_w, reid->in_pix4 ? 2 : 1, reid->dtype, reid->input(), c.d_valid.p + c0, sr, true);
                 }
                 reid->run(k, sr);
+                reid->crop_src.frames = nullptr;
                 HIP_CHECK(hipMemcpyAsync(c.d_emb.p + (size_t)c0 * dim, reid->embeddings(), (size_t)k * dim * 4, hipMemcpyDeviceToDevice, sr));
             }
             {   // matching.py:126-130 for every detection of the launch group at once
