@@ -135,3 +135,30 @@ def test_device_and_host_association_same_costs(gpu):
     assert np.array_equal(ea["mean"], eb["mean"]) and np.array_equal(ea["cov"], eb["cov"])
     for ta, tb in zip(a.tracks, b.tracks):
         assert np.array_equal(np.stack(ta.features), np.stack(tb.features))
+
+
+def test_device_tracker_capacity_and_option_errors(gpu, lib):
+    """Capacity is checked on the device BEFORE a frame mutates anything: the failing update raises AIC_ERR_CAPACITY and the tracker
+    still holds the state of the frame before it; unlimited galleries (nn_budget=None) are refused for the device path."""
+    TC = pkg("core.tracker_core").TrackerCore
+    syn = pkg("synthetic")
+    trk = TC(max_tracks=4)
+    trk.option("device_assoc", 1)
+    boxes = np.array([[10 + 60 * i, 20, 40, 90] for i in range(6)], np.float32)
+    feats = syn.identity_features(np.arange(6), 0, dim=64)
+    trk.predict()
+    trk.update_arrays(boxes[:3], np.full(3, 0.9, np.float32), np.zeros(3, np.int32), feats[:3])
+    assert trk.export_arrays()["track_id"].tolist() == [1, 2, 3]
+    trk.option("device_assoc", 1)
+    trk.predict()
+    with pytest.raises(lib.AicError) as e:
+        trk.update_arrays(boxes + 500, np.full(6, 0.9, np.float32), np.zeros(6, np.int32), feats)      # six new tracks, one free slot
+    assert e.value.code == lib.ERR_CAPACITY and "capacity" in str(e.value)
+    a = trk.export_arrays()
+    assert a["track_id"].tolist() == [1, 2, 3] and a["hits"].tolist() == [1, 1, 1] and a["age"].tolist() == [2, 2, 2]   # predict() was applied, the update was not
+    trk.predict()
+    trk.update_arrays(boxes[:3], np.full(3, 0.9, np.float32), np.zeros(3, np.int32), feats[:3])          # and it keeps working
+    assert trk.export_arrays()["hits"].tolist() == [2, 2, 2]
+    unlimited = TC(nn_budget=None)
+    with pytest.raises(lib.AicError):
+        unlimited.option("device_assoc", 1)
