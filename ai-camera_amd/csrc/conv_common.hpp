@@ -39,15 +39,47 @@ template <> struct Frag<float> {
     // accumulator with one fp32 add.  A single chain over K = 576 .. 5 184 rounds K/4 times in sequence; this form rounds
     // 4 + K/16 times, which puts the fp32 engine ~4x closer to the fp64 evaluation of the same graph than a plain chain
     // (measured against oracle/nets_oracle.py in fp64: tests/test_gpu_nets.py, tests/test_gpu_configs.py).
-    static __device__ __forceinline__ floatx4 mma(const floatx4& a, const floatx4& b, floatx4 c) {
+    static __device__ __forceinline__ floatx4 partial(const floatx4& a, const floatx4& b) {
         floatx4 p = {0.f, 0.f, 0.f, 0.f};
         p = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], p, 0, 0, 0);
         p = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], p, 0, 0, 0);
         p = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], p, 0, 0, 0);
         p = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], p, 0, 0, 0);
-        return c + p;
+        return p;
     }
+    static __device__ __forceinline__ floatx4 mma(const floatx4& a, const floatx4& b, floatx4 c) { return c + partial(a, b); }
 };
+
+// acc[i][j] += w[j] x x[i] for one K-step of a wave's MT x NT tile grid.
+// fp16: plain accumulating MFMAs.  fp32 (two-level summation): every tile's partial chain starts from zero and joins the
+// accumulator with a VALU add.  Two things go wrong when that add is left to the compiler in the fully unrolled 3x3 kernels,
+// whose accumulators have no use before the epilogue block: MachineSink moves the adds, link by link, down into the epilogue,
+// so every partial of every K-step stays live (576 of them on the 4x4 patch kernel: 11 KB of scratch per lane, 8x slower);
+// and the scheduler interleaves the independent chains.  Hence (1) an empty volatile asm on the accumulator after each add
+// -- it cannot be sunk or reordered -- and (2) a pinned order: chain of tile t, then the add of tile t-1, whose MFMAs have
+// retired by then; two partials live.
+template <typename T, int MT, int NT>
+__device__ __forceinline__ void mma_tiles(floatx4 (&acc)[MT][NT], const typename Frag<T>::type (&wf)[NT], const typename Frag<T>::type (&xf)[MT]) {
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = Frag<T>::mma(wf[j], xf[i], acc[i][j]);
+    } else {
+        floatx4 prev = Frag<T>::partial(wf[0], xf[0]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 1; t < MT * NT; ++t) {
+            const floatx4 p = Frag<T>::partial(wf[t % NT], xf[t / NT]);
+            acc[(t - 1) / NT][(t - 1) % NT] += prev;
+            asm volatile("" : "+v"(acc[(t - 1) / NT][(t - 1) % NT]));
+            prev = p;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        acc[MT - 1][NT - 1] += prev;
+        asm volatile("" : "+v"(acc[MT - 1][NT - 1]));
+    }
+}
 
 // swz(row) = ((row>>1)&3) ^ ((row>>3)&2): conflict-free for 16 consecutive rows (pixel tiles, identity weight tiles) AND
 // for the permuted weight rows {c + 8k + s} of perm_row() (brute-forced over the ds_read_b128 lane groups).

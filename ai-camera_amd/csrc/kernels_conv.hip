@@ -149,10 +149,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
             const int row = (wn * NT + j) * 16 + r;
             wf[j] = *reinterpret_cast<const frag_t*>(base + BM * 64 + lds_off(row, q));
         }
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j) acc[i][j] = Frag<T>::mma(wf[j], xf[i], acc[i][j]);
+        mma_tiles<T, MT, NT>(acc, wf, xf);
         if (more) store_step(cur ^ 1);
         __syncthreads();
     }
@@ -303,10 +300,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const Conv
         for (int i = 0; i < MT; ++i) xf[i] = *reinterpret_cast<const frag_t*>(base + xoff[i]);
 #pragma unroll
         for (int j = 0; j < NT; ++j) wf[j] = *reinterpret_cast<const frag_t*>(base + woff[j]);
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j) acc[i][j] = Frag<T>::mma(wf[j], xf[i], acc[i][j]);
+        mma_tiles<T, MT, NT>(acc, wf, xf);
     };
     char* const sdst = smem + (16 * wv) * 64;   // this wave's 16 rows inside a staging pass
 

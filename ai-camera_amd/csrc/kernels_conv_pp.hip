@@ -166,10 +166,7 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(const ConvArgs a) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-                for (int i = 0; i < MT; ++i)
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) acc[i][j] = Frag<T>::mma(wf[j], xf[i], acc[i][j]);
+                mma_tiles<T, MT, NT>(acc, wf, xf);
                 __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
@@ -418,10 +415,7 @@ __global__ __launch_bounds__(512) void conv3x3_pp_patch_kernel(const ConvArgs a,
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j) acc[i][j] = Frag<T>::mma(wf[j], xf[i], acc[i][j]);
+            mma_tiles<T, MT, NT>(acc, wf, xf);
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
