@@ -99,6 +99,7 @@ struct Pipeline {
     int last_chunk = -1;             // chunk context of the most recently finished launch group (aic_pipeline_group_embeddings)
     long n_grow = 0;                 // launch groups whose crop count outgrew the buffers sized from max_persons
     long n_rows_clipped = 0;         // frames with more confirmed tracks than the caller's max_persons output rows
+    long n_assoc_dev = 0, n_assoc_host = 0;   // frames whose association ran in the epoch kernels / in host C++
     bool split_streams = getenv("AICAM_SPLIT_STREAMS") != nullptr;
     bool pipe_times = getenv("AICAM_PIPE_TIMES") != nullptr;
     hipEvent_t prev_end = nullptr;   // measured: no gain on MI355X
@@ -319,6 +320,7 @@ struct Pipeline {
     void stage_b(Chunk& c, int out_base, int32_t* n_tracks, int32_t* tracks6, float* track_conf, int32_t* n_dets,
                  float* det_boxes, float* det_scores, int32_t* det_labels) {
         const double t0 = now();
+        n_assoc_host += c.frames;
         HIP_CHECK(hipEventSynchronize(c.done));
         if (pipe_times) {
             float a = 0, b = 0, g = 0;
@@ -394,6 +396,7 @@ struct Pipeline {
     void stage_b_device(Chunk& c, int out_base, int32_t* n_tracks, int32_t* tracks6, float* track_conf, int32_t* n_dets,
                         float* det_boxes, float* det_scores, int32_t* det_labels) {
         const double t0 = now();
+        n_assoc_dev += c.frames;
         hipStream_t s = dev->s_trk;
         const int mp = prm.max_persons;
         const size_t o_rows = (((size_t)c.frames * 4 + 15) / 16) * 16, o_conf = o_rows + (size_t)c.frames * mp * 24;
@@ -753,6 +756,14 @@ int aic_pipeline_counters(aic_pipeline* p, int64_t* grown_groups, int64_t* clipp
         AIC_REQUIRE(p, AIC_ERR_INVALID, "NULL pipeline");
         if (grown_groups) *grown_groups = p->p.n_grow;
         if (clipped_frames) *clipped_frames = p->p.n_rows_clipped;
+    });
+}
+
+int aic_pipeline_assoc_frames(aic_pipeline* p, int64_t* device_frames, int64_t* host_frames) {
+    return guarded([&] {
+        AIC_REQUIRE(p, AIC_ERR_INVALID, "NULL pipeline");
+        if (device_frames) *device_frames = p->p.n_assoc_dev;
+        if (host_frames) *host_frames = p->p.n_assoc_host;
     });
 }
 

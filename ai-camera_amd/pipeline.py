@@ -224,7 +224,9 @@ class TrackingPipeline:
     def counters(self):
         a, b = C.c_int64(), C.c_int64()
         L.call("aic_pipeline_counters", self._h, C.byref(a), C.byref(b))
-        return dict(grown_groups=a.value, clipped_frames=b.value)
+        d, h = C.c_int64(), C.c_int64()
+        L.call("aic_pipeline_assoc_frames", self._h, C.byref(d), C.byref(h))
+        return dict(grown_groups=a.value, clipped_frames=b.value, assoc_device_frames=d.value, assoc_host_frames=h.value)
 
     def group_embeddings(self):
         """Embeddings of every crop of the most recently finished launch group: (emb [rows, dim], crops_per_frame [frames])."""

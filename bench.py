@@ -264,6 +264,12 @@ def main():
     if not args.no_prof:
         L.call("aic_prof_enable", dev, 0)
     exchanges = exchange.stop() if exchange else None
+    cnt = pipe.counters()                                        # what the library did, not what the flags asked for
+    k_epoch = int(os.environ.get("AICAM_TRK_K", "16"))
+    on_dev, on_host = cnt["assoc_device_frames"], cnt["assoc_host_frames"]
+    association = (f"on the device, epochs of {k_epoch} frames (csrc/kernels_trk_dev.hip)" if on_host == 0 else
+                   "host C++ cascade/LSAP, one launch + sync per frame" if on_dev == 0 else
+                   f"mixed: {on_dev} frames on the device (epochs of {k_epoch}), {on_host} on the host")
     dt_max = D.reduce_max_time(dt) if world > 1 else dt
     total_frames = frames_per_step * args.steps * world
     fps = total_frames / dt_max
@@ -345,7 +351,7 @@ def main():
                        "frame_latency_ms(handed to the pipeline -> tuples on host, full launch groups of the timed run)":
                            {"p50": pct(g_lat[full], g_frames[full], 0.5), "p99": pct(g_lat[full], g_frames[full], 0.99)},
                        "by_launch_group_frames(from host, 3 passes each)": side.get("by_launch_group_frames"),
-                       "association": "on the device, epochs of 32 frames (csrc/kernels_trk_dev.hip)" if not os.environ.get("AICAM_TRK_HOST") else "host C++ cascade/LSAP, one launch + sync per frame",
+                       "association": association,
                        "gallery_exchange_every_frames": args.gallery_exchange, "gallery_exchanges_done": exchanges,
                        "host_affinity": affinity, "host_clip_page_locked": pinned,
                        "host_us_per_frame": {"issue_launch_groups(producer thread)": round(1e6 * host["issue_s"] / max(host["frames"], 1), 1),

@@ -288,6 +288,9 @@ int aic_pipeline_option(aic_pipeline* p, const char* key, int value);
 /* Launch groups whose crop count outgrew the buffers sized from max_persons (handled, not dropped), and frames
  * whose confirmed tracks outnumbered the caller's max_persons rows (n_tracks reports the true count). */
 int aic_pipeline_counters(aic_pipeline* p, int64_t* grown_groups, int64_t* clipped_frames);
+/* Frames, since creation, whose association (src/tracker/core/tracker_core.py:83-177) ran on the device in the epoch
+ * kernels / on the host in C++: what the "device_assoc" auto mode actually chose. Either pointer may be NULL. */
+int aic_pipeline_assoc_frames(aic_pipeline* p, int64_t* device_frames, int64_t* host_frames);
 /* ReID embeddings of every crop of the most recently finished launch group, frame-major (parity tests of the
  * production-size kernel mix): emb[n_rows, dim] host, crops_per_frame[n_frames]. Any output pointer may be NULL. */
 int aic_pipeline_group_embeddings(aic_pipeline* p, float* emb, int cap_rows, int32_t* crops_per_frame, int cap_frames,

@@ -206,8 +206,13 @@ def test_association_mode_switches_between_launch_groups(gpu, engines):
         p2.upload(0, frames)
         p2.inject(0, [sc.detections(f)[:3] for f in range(n_frames)])
         modes[mode] = p2.run(0, n_frames)[0]
+        c2 = p2.counters()                                # the library's own account of where the association ran
+        assert (c2["assoc_device_frames"], c2["assoc_host_frames"]) == ((0, n_frames) if mode == 0 else (n_frames, 0)), c2
         p2.close()
     assert modes[0] == tracks and modes[2] == tracks
+    c1 = pipe.counters()                                  # auto: device while the problems fit, host after the scene outgrew them
+    assert c1["assoc_device_frames"] >= batch and c1["assoc_host_frames"] >= batch, c1
+    assert c1["assoc_device_frames"] + c1["assoc_host_frames"] == n_frames, c1
     torch.set_num_threads(16)
     ref, embs, otrk = oracle_tracks(sc, N.EngineOracle(engines[1]), frames, n_frames)
     assert len(ref[3]) == 40 and len(ref[-1]) == 76
