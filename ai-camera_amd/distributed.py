@@ -231,6 +231,13 @@ class GalleryExchange:
         self._thread = None
         self.count = 0
         self.last_annotation = None
+        self.error = None
+        # The exchange runs on its own thread while the caller's thread keeps using the default group (barriers, the bench's
+        # max-reduce).  Collectives of one communicator must be issued in the same order on every rank, which two threads cannot
+        # promise: the exchange gets a communicator of its own.  new_group() is itself collective -- every rank constructs its
+        # GalleryExchange at the same point of the program.
+        self.backend = dist.get_backend() if self.world > 1 else None
+        self.group = dist.new_group() if self.world > 1 else None
         dev = torch.device("cpu") if device is None else torch.device("cuda", device)
         self._shards = [torch.zeros((self.t_max, 2 + self.dim), dtype=torch.float32, device=dev) for _ in range(2)]
         self._gathered = torch.zeros((self.world * self.t_max, 2 + self.dim), dtype=torch.float32, device=dev)
@@ -240,11 +247,19 @@ class GalleryExchange:
         return torch.from_numpy(pack_gallery_shard(track_ids, embeddings, self.dim, self.t_max))
 
     def all_gather(self, shard, async_op=True):
+        import torch
         import torch.distributed as dist
         if self.world == 1:
             self._gathered.copy_(shard)
             return _Handle(None, self._gathered, 1)
-        work = dist.all_gather_into_tensor(self._gathered, shard.to(self._gathered.device), async_op=async_op)
+        if self.backend == "gloo" and self._gathered.is_cuda:
+            # rehearsal of the device path without RCCL (ranks sharing one GPU): gloo gathers host tensors, so the shard takes a
+            # host hop here -- and only here; the copies are ordered on the current (exchange) stream
+            out = torch.empty(self._gathered.shape, dtype=self._gathered.dtype)
+            dist.all_gather_into_tensor(out, shard.cpu(), group=self.group)
+            self._gathered.copy_(out)
+            return _Handle(None, self._gathered, self.world)
+        work = dist.all_gather_into_tensor(self._gathered, shard.to(self._gathered.device), group=self.group, async_op=async_op)
         return _Handle(work if async_op else None, self._gathered, self.world)
 
     # ---- device path: driven by the pipeline's per-launch-group hook, on its own thread and stream
@@ -263,21 +278,26 @@ class GalleryExchange:
 
         def loop():
             seq = 0
-            while True:
-                buf, got = C.c_int32(), C.c_int32()
-                L.call("aic_pipeline_exchange_wait", pipe._h, seq, 200, C.byref(buf), C.byref(got))   # the shard of exchange `seq` is packed (stream-ordered)
-                if not got.value:
-                    if self._stop:
-                        break
-                    continue
-                with torch.cuda.stream(stream):
-                    h = self.all_gather(self._shards[buf.value])
-                    g = h.wait()
-                    self.last_annotation = annotate_device(g, self.rank, self.world)
-                    stream.synchronize()
-                L.call("aic_pipeline_exchange_done", pipe._h, seq)
-                seq += 1
-                self.count = seq
+            try:
+                while True:
+                    buf, got = C.c_int32(), C.c_int32()
+                    L.call("aic_pipeline_exchange_wait", pipe._h, seq, 200, C.byref(buf), C.byref(got))   # the shard of exchange `seq` is packed (stream-ordered)
+                    if not got.value:
+                        if self._stop:
+                            break
+                        continue
+                    with torch.cuda.stream(stream):
+                        h = self.all_gather(self._shards[buf.value])
+                        g = h.wait()
+                        self.last_annotation = annotate_device(g, self.rank, self.world)
+                        stream.synchronize()
+                    L.call("aic_pipeline_exchange_done", pipe._h, seq)
+                    seq += 1
+                    self.count = seq
+            except BaseException as e:   # noqa: BLE001 -- a dead consumer must not leave the pipeline waiting for its buffer forever
+                self.error = e
+                L.call("aic_pipeline_exchange_done", pipe._h, C.c_int64(1 << 60))   # every later exchange counts as consumed: the run
+                                                                                   # finishes, stop() raises
 
         self._thread = threading.Thread(target=loop, daemon=True)
         self._thread.start()
@@ -291,6 +311,8 @@ class GalleryExchange:
         self._thread.join()
         L.call("aic_pipeline_exchange_enable", self._pipe._h, None, None, 0, 0)
         self._thread = None
+        if self.error is not None:
+            raise RuntimeError(f"gallery exchange failed after {self.count} exchanges on rank {self.rank}") from self.error
         return self.count
 
 

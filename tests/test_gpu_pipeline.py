@@ -183,6 +183,40 @@ def test_gallery_exchange_hooks_single_gpu(gpu, engines):
     pipe.close()
 
 
+def test_gallery_exchange_consumer_failure_is_loud_not_a_hang(gpu, engines, monkeypatch):
+    """The pipeline waits for the consumer before it reuses a shard buffer.  A consumer that dies (a collective that raises) must
+    release it: the run finishes with the same tracks, and stop() raises with the cause."""
+    D = pkg("distributed")
+    n_frames, batch = 32, 8
+    sc = syn.Scene(seed=21, n_targets=12)
+    frames = sc.render_batch(0, n_frames)
+    TP = pkg("pipeline").TrackingPipeline
+    pipe = TP(engines[0], engines[1], (720, 1280), batch=batch, ring_frames=n_frames, max_persons=16, dtype="fp16", inject=True)
+    pipe.upload(0, frames)
+    pipe.inject(0, [sc.detections(f)[:3] for f in range(n_frames)])
+    ref, _ = pipe.run(0, n_frames)
+    pipe.close()
+    pipe = TP(engines[0], engines[1], (720, 1280), batch=batch, ring_frames=n_frames, max_persons=16, dtype="fp16", inject=True)
+    pipe.upload(0, frames)
+    pipe.inject(0, [sc.detections(f)[:3] for f in range(n_frames)])
+    calls = []
+
+    def broken(*a, **k):
+        calls.append(1)
+        if len(calls) == 2:                                  # the second exchange of four fails
+            raise RuntimeError("collective failed (injected)")
+        return None
+    monkeypatch.setattr(D, "annotate_device", broken)
+    ex = D.GalleryExchange(dim=512, device=0)
+    ex.start(pipe, every_frames=8)
+    tracks, _ = pipe.run(0, n_frames)                        # returns: the dead consumer released the shard buffers
+    assert tracks == ref
+    with pytest.raises(RuntimeError, match="gallery exchange failed after 1 exchanges") as ei:
+        ex.stop()
+    assert "injected" in str(ei.value.__cause__)
+    pipe.close()
+
+
 def test_association_mode_switches_between_launch_groups(gpu, engines):
     """Default (auto) mode: the association of a launch group runs on the device while its problems fit one wavefront (<= 64 tracks x 64
     detections) and in host C++ beyond.  A scene that grows from 40 to 76 persons crosses that line mid-run, so the track table

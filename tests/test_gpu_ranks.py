@@ -1,0 +1,54 @@
+"""The driver's N > 1 launch line on a box with ONE GPU: two ranks of bench.py share cuda:0 and talk over gloo.
+
+Everything of the multi-rank path runs for real except RCCL itself -- NUMA / core binding before the first GPU call, rendezvous on
+127.0.0.1, per-rank stream seeds, the barrier-bracketed timed region, MAX over ranks, one JSON line from rank 0 -- with a live
+pipeline per rank, and, in the second case, the configs[4] gallery exchange (device shards packed by the pipeline, all-gathered by
+the consumer thread on its own process group while the main thread keeps using the default one).  A hang here is a failure: the
+children run under a timeout.  Three processes touch the card (this one and two ranks).
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _launch(extra, timeout=420):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo",
+           "--steps", "2", "--warmup", "1", "--ring", "32", "--batch", "8", "--no-prof"] + extra
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=dict(os.environ, OMP_NUM_THREADS="1"))
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                  # rank 0 only
+    return json.loads(lines[0])
+
+
+def test_two_ranks_share_the_gpu(gpu):
+    out = _launch([])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "weak"
+    c = out["config"]
+    assert c["frames_per_step"] == 64 and c["launch_group_frames"] == 8
+    assert abs(out["value"] - 2 * 2 * 64 / (2 * out["ms_per_step"] / 1e3)) / out["value"] < 1e-3     # whole job: both ranks' frames / max time
+    assert c["confirmed_tracks_per_frame"] == 30.0            # rank 0's stream is in steady state
+    assert c["host_affinity"]["bound"] is True
+    assert c["gallery_exchanges_done"] is None and "cpu_baseline" in out and out["cpu_baseline"] is None
+
+
+def test_two_ranks_with_gallery_exchange(gpu):
+    out = _launch(["--gallery-exchange", "8"])
+    c = out["config"]
+    assert out["n_gpus"] == 2 and c["gallery_exchange_every_frames"] == 8
+    # one exchange per 8-frame launch group of every pass since the exchange started (warm-up included): 3 passes x 8 groups
+    assert c["gallery_exchanges_done"] == 3 * 64 // 8, c["gallery_exchanges_done"]
+    assert c["association"].startswith("on the device")        # the shard is packed from the HBM-resident track table
+    assert c["confirmed_tracks_per_frame"] == 30.0
