@@ -52,3 +52,42 @@ def test_two_ranks_with_gallery_exchange(gpu):
     assert c["gallery_exchanges_done"] == 3 * 64 // 8, c["gallery_exchanges_done"]
     assert c["association"].startswith("on the device")        # the shard is packed from the HBM-resident track table
     assert c["confirmed_tracks_per_frame"] == 30.0
+
+
+def test_rccl_calls_of_the_rank_path_world_of_one(gpu):
+    """RCCL itself cannot pair two ranks on one GPU, but every call the N > 1 path makes can run in a world of 1: the eager
+    communicator bound to the rank's device, barrier, the MAX-reduce of bench.py on a device tensor, the exchange's own group and
+    its all_gather_into_tensor on a side stream.  In a child process: the process group must not leak into this one."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    code = f"""
+import os, sys, importlib
+sys.path.insert(0, {ROOT!r})
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="{port}")
+import torch, torch.distributed as dist
+D = importlib.import_module("ai-camera_amd.distributed")
+torch.cuda.set_device(0)
+dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+assert dist.get_backend() == "nccl"
+dist.barrier()
+t = torch.tensor([0.75], dtype=torch.float64).cuda()
+dist.all_reduce(t, op=dist.ReduceOp.MAX)
+assert t.item() == 0.75
+grp = dist.new_group()
+side = torch.cuda.Stream()
+shard = torch.arange(128 * 514, dtype=torch.float32, device="cuda").view(128, 514)
+out = torch.zeros_like(shard)
+side.wait_stream(torch.cuda.current_stream())
+with torch.cuda.stream(side):
+    w = dist.all_gather_into_tensor(out, shard, group=grp, async_op=True)
+    w.wait()
+    ann = D.annotate_device(out.view(1, 128, 514), 0, 1)
+    side.synchronize()
+assert torch.equal(out, shard) and ann.shape == (128, 3)
+dist.barrier()
+dist.destroy_process_group()
+print("RCCL_OK")
+"""
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "RCCL_OK" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
