@@ -29,3 +29,19 @@ for k in keys[:int(sys.argv[3]) if len(sys.argv) > 3 else 30]:
     wc = max(x.get("SQ_WAVE_CYCLES", 0), 1)
     busy = max(x.get("SQ_BUSY_CYCLES", 0), 1)
     print(f"{k[0][:48]:48s} {k[1]:8d} {k[2]:4d} {int(x['_n']):4d} | {100*x.get('SQ_VALU_MFMA_BUSY_CYCLES',0)/busy/32:9.1f} {x.get('SQ_INSTS_VALU',0)/mf:9.2f} {y.get('SQ_INSTS_LDS',0)/mf:8.2f} {y.get('SQ_INSTS_SALU',0)/mf:9.2f} {y.get('SQ_INSTS_VMEM',0)/mf:9.2f} {100*x.get('SQ_WAIT_ANY',0)/wc:9.1f} {100*x.get('SQ_WAIT_INST_ANY',0)/wc:10.1f} {100*y.get('SQ_WAIT_INST_LDS',0)/wc:9.1f} {100*y.get('SQ_LDS_BANK_CONFLICT',0)/max(y.get('SQ_LDS_IDX_ACTIVE',1),1):9.1f} {100*y.get('SQ_LDS_IDX_ACTIVE',0)/busy/8:8.1f}")
+
+# The conv class as bench.py defines it (every MFMA conv kernel except the two fused 3-channel stems), weighted by busy cycles
+# = by time: the figure to hold against the north star's "MFMA utilisation on the conv kernels".
+def conv_class(name):
+    return any(t in name for t in ("conv_igemm", "conv3x3", "c2f16"))
+
+num = sum(a[k].get("SQ_VALU_MFMA_BUSY_CYCLES", 0) * a[k]["_n"] for k in a if conv_class(k[0]))
+den = sum(a[k].get("SQ_BUSY_CYCLES", 0) * a[k]["_n"] for k in a if conv_class(k[0]))
+nl = sum(int(a[k]["_n"]) for k in a if conv_class(k[0]))
+reid = lambda k: conv_class(k[0]) and ("c64_block" in k[0] or "pp_patch" in k[0] or "igemm_pp" in k[0])
+num_r = sum(a[k].get("SQ_VALU_MFMA_BUSY_CYCLES", 0) * a[k]["_n"] for k in a if reid(k))
+den_r = sum(a[k].get("SQ_BUSY_CYCLES", 0) * a[k]["_n"] for k in a if reid(k))
+if den:
+    print(f"\nconv class, time-weighted over {nl} launches: MFMA busy {100 * num / den / 32:.1f} % of the busy cycles "
+          f"(ReID trunk kernels c64_block / pp_patch / igemm_pp alone: {100 * num_r / max(den_r, 1) / 32:.1f} %, "
+          f"{100 * den_r / den:.0f} % of the class's time)")
