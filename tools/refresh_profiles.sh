@@ -29,4 +29,8 @@ python bench.py > $O/bench.json 2> $O/bench.err
 tail -1 $O/bench.json | cut -c1-300
 rm -rf $O/trace $O/fetch $O/write $O/sqa $O/sqb          # the raw traces stay on the box (tens of MB); the summaries travel back
 for f in bench.json bench_under_rocprof.json kernel_stats.csv kernel_summary.txt conv_layers.txt sq_counters.txt; do cp $O/$f profiles/${TAG}_$f; done
+# profiles/ of the GPU box does not travel back, gpurun_out/ does: stage the judged files there as well.
+# Afterwards, in the container:  cp gpurun_out/profiles_$TAG/* profiles/
+mkdir -p $R/gpurun_out/profiles_$TAG
+cp profiles/${TAG}_* profiles/pmc_traffic.json $R/gpurun_out/profiles_$TAG/
 ls -la $O
