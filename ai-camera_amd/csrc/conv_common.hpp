@@ -310,6 +310,69 @@ __device__ __forceinline__ void epilogue_dispatch(const ConvArgs& a, floatx4 (&a
 #undef AIC_EPI
 }
 
+// ---- a 1x1 conv in the epilogue of the conv before it (ConvArgs::w_tail; fp16) -----------------------------------------
+// For a wave that owns ALL channels of its pixels (WN == 1, Cout == 16 NT) the permuted accumulator layout IS the B operand of
+// the next conv: after bias + SiLU + rounding to fp16 -- exactly what the conv would have stored -- lane (r, q) holds, per tile
+// pair p, channels 32 p + 8 q .. + 7 of pixel r, i.e. K elements 8 q .. 8 q + 7 of K-step p.  No LDS round trip, no HBM round
+// trip.  An odd last tile (Cout = 80: channels 64 .. 79) holds 4 channels per lane; K-step NP wants 8 (64 + 8 q .. + 7) from
+// lanes (r, 2 q) and (r, 2 q + 1): four ds_bpermute per pixel tile, zeros for q >= 2 (the K padding 80 .. 95).
+// The 1x1's weights come straight from L2 as A fragments (row perm_row(j2, r), K elements 32 s + 8 q .. + 7), once per wave.
+// Same products, same K-step order, same roundings as the two kernels run one after the other: bit-identical outputs
+// (tests/test_gpu_nets.py::test_fused_head_tail).
+template <int MT, int NT>
+__device__ __forceinline__ void tail_1x1(const ConvArgs& a, floatx4 (&acc)[MT][NT], const int (&mrow)[MT], int lane) {
+    constexpr int NP = NT / 2, KS = NP + (NT & 1);
+    const int r = lane & 15, q = lane >> 4;
+    // the loads below depend on nothing the K loop computes: without this fence the scheduler hoists them into the (fully
+    // unrolled) loop, where they stay live to the end -- 182 -> 278 registers on the patch kernel, 2 -> 1 waves per SIMD
+    __builtin_amdgcn_sched_barrier(0);
+    const half_t* __restrict__ wt = reinterpret_cast<const half_t*>(a.w_tail);
+    half8 wf[NT][KS];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) wf[j][s] = *reinterpret_cast<const half8*>(wt + (size_t)perm_row<NT>(j, r) * a.t_kp + 32 * s + 8 * q);
+    floatx4 b1[NT];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        b1[2 * p] = *reinterpret_cast<const floatx4*>(a.bias + 32 * p + 8 * q);
+        b1[2 * p + 1] = *reinterpret_cast<const floatx4*>(a.bias + 32 * p + 8 * q + 4);
+    }
+    if constexpr (NT & 1) b1[NT - 1] = *reinterpret_cast<const floatx4*>(a.bias + 16 * (NT - 1) + 4 * q);
+    ConvArgs a2 = a;                       // the tail's epilogue: its own bias / activation / output, no residual
+    a2.y = a.y_tail, a2.bias = a.b_tail, a2.Cout = a.t_cout, a2.y_cs = a.t_y_cs, a2.y_coff = a.t_y_coff;
+    a2.act = a.t_act, a2.res_mode = 0, a2.out_f32 = a.t_out_f32;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        half8 bf[KS];
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bf[p][e] = (half_t)act_fast<1>(acc[i][2 * p + (e >> 2)][e & 3] + b1[2 * p + (e >> 2)][e & 3]);
+        if constexpr (NT & 1) {
+            half4 own;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) own[e] = (half_t)act_fast<1>(acc[i][NT - 1][e] + b1[NT - 1][e]);
+            const int2 u = *reinterpret_cast<const int2*>(&own);
+            const int s0 = (((2 * q) & 3) * 16 + r) * 4, s1 = (((2 * q + 1) & 3) * 16 + r) * 4;
+            int4 g;
+            g.x = __builtin_amdgcn_ds_bpermute(s0, u.x), g.y = __builtin_amdgcn_ds_bpermute(s0, u.y);
+            g.z = __builtin_amdgcn_ds_bpermute(s1, u.x), g.w = __builtin_amdgcn_ds_bpermute(s1, u.y);
+            if (q >= 2) g = make_int4(0, 0, 0, 0);
+            bf[NP] = *reinterpret_cast<const half8*>(&g);
+        }
+        floatx4 acc2[1][NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc2[0][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc2[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j][s], bf[s], acc2[0][j], 0, 0, 0);
+        const int m1[1] = {mrow[i]};
+        epilogue_dispatch<half_t, 1, NT, true>(a2, acc2, m1, 0, q);
+    }
+}
+
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
@@ -366,6 +429,7 @@ inline int conv_impl() {   // AICAM_CONV=v1 selects the register-staged kernel (
 bool conv_try_pp_patch(int dtype, const ConvArgs& a, hipStream_t s);   // kernels_conv_pp.hip: v5 ping-pong patch (3x3/s1, Cout 128 / 256k)
 bool conv_try_pp(int dtype, const ConvArgs& a, hipStream_t s);         // kernels_conv_pp.hip: v4 ping-pong im2col (long K, Cout 128 / 256k)
 bool conv_try_patch(int dtype, const ConvArgs& a, hipStream_t s);      // kernels_conv_direct.hip: 4-wave patch kernel (Cout 64 / 32)
+bool conv_try_patch_tail(const ConvArgs& a, hipStream_t s);            // same kernel, Cout 64, with a.w_tail's 1x1 in its epilogue (fp16)
 bool conv_try_c16(const ConvArgs& a, hipStream_t s);                   // kernels_conv_direct.hip: 16 input channels, fp16
 bool conv_try_c64_resident(const ConvArgs& a, hipStream_t s);          // kernels_conv_direct.hip: persistent Cin = Cout = 64, fp16
 

@@ -174,6 +174,26 @@ Model::Model(Device& d, const void* blob, size_t nbytes, int dtype_, int max_ite
             if (conv_ok && pool_ok && !other_reader) { ops[i].fuse = 1; ops[i + 1].fuse = 2; }
         }
     }
+    // ---- fusion: a SiLU conv with 64 or 80 output channels whose output feeds exactly one 1x1/1/0 conv and nothing else (YOLOv8's
+    // detect branches: 22.box*.1 -> .2, 22.cls*.1 -> .2).  The 1x1 runs in the first conv's epilogue on the tile in registers;
+    // the intermediate tensor is never written.  Marked here (graph properties); run_range() asks conv_tail_supported() for the rest.
+    if (dtype == AIC_F16 && !getenv("AICAM_NO_FUSE")) {
+        for (size_t i = 0; i + 1 < ops.size(); ++i) {
+            const int* c = ops[i].v;
+            const int* p = ops[i + 1].v;
+            if (c[0] != OP_CONV || p[0] != OP_CONV || ops[i].fuse || ops[i + 1].fuse) continue;
+            const bool lead_ok = (c[6] == 64 || c[6] == 80) && c[11] == 1 && c[14] == 0 && !bufs[c[4]].f32;
+            const bool tail_ok = p[7] == 1 && p[8] == 1 && p[9] == 1 && p[10] == 0 && p[14] == 0 && p[1] == c[4] && p[2] == c[5] &&
+                                 p[3] == c[6] && p[6] <= c[6];
+            if (!lead_ok || !tail_ok) continue;
+            bool other_reader = false;
+            for (size_t j = 0; j < ops.size(); ++j)
+                if (j != i + 1 && (ops[j].v[1] == c[4] || (ops[j].v[0] == OP_CONV && ops[j].v[14] && ops[j].v[12] == c[4]))) other_reader = true;
+            for (auto& o : outs)
+                if (o.v[0] == c[4] || (kind == KIND_YOLO && o.v[1] == c[4])) other_reader = true;
+            if (!other_reader) ops[i].fuse = 3;          // the follower keeps fuse = 0: it runs on its own whenever the lead cannot take it
+        }
+    }
     {   // sub-batching plan: the maximal prefix of ops whose outputs are >= min_kb per item
         const char* e_items = getenv("AICAM_SB_ITEMS");
         const char* e_kb = getenv("AICAM_SB_MINKB");
@@ -337,6 +357,22 @@ void Model::run_range(size_t op0, size_t op1, int i0, int n, hipStream_t s) {
                 continue;
             }
             if (pair) { fl = 0, by = 0; (void)conv_args(oi); }          // not fused after all: account this conv alone
+            // a conv whose only consumer is the 1x1 conv after it (marked at load time) takes that conv into its epilogue where the
+            // kernels can; FLOPs and algorithmic bytes are accounted as for the two convs
+            if (o.fuse == 3 && oi + 1 < op1) {
+                const double fl0 = fl, by0 = by;
+                const ConvArgs t = conv_args(oi + 1);
+                if (conv_tail_supported(dtype, a, t)) {
+                    ConvArgs at = a;
+                    at.w_tail = t.w, at.b_tail = t.bias, at.y_tail = t.y, at.t_cout = t.Cout, at.t_kp = t.Kp;
+                    at.t_y_cs = t.y_cs, at.t_y_coff = t.y_coff, at.t_out_f32 = t.out_f32, at.t_act = t.act;
+                    if (prof_conv) dev->prof_account(PROF_CONV, fl, by);
+                    launch_conv_igemm(dtype, at, s);
+                    ++oi;
+                    continue;
+                }
+                fl = fl0, by = by0;
+            }
             if (prof_conv) dev->prof_account(PROF_CONV, fl, by);
             launch_conv_igemm(dtype, a, s);
         } else {

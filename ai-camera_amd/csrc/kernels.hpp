@@ -24,7 +24,17 @@ struct ConvArgs {
     unsigned tap_rows;  // bit kh*KW set for kh < KH (replication pattern of the tap-validity mask)
     const void* zero;   // 64 bytes of zeros in HBM: LDS-DMA source for padded / out-of-range chunks
     int xcd_map;        // 1: blocks take tiles through xcd_tile() (set by launch_conv_igemm)
+    // ---- optional 1x1 "tail" conv run in this conv's epilogue (fp16 only; conv_tail_supported()).  This conv's own output
+    // (SiLU(acc + bias) rounded to fp16, exactly what it would have stored) never leaves the registers: it is the B operand of
+    // the tail's MFMAs.  y / y_cs / y_coff of THIS conv are then unused.  w_tail == NULL: no tail.
+    const void* w_tail;   // packed weights of the 1x1 [t_cout_pad][t_kp], K = this conv's Cout
+    const float* b_tail;  // [t_cout_pad]
+    void* y_tail;         // NHWC output of the tail (fp16, or float when t_out_f32)
+    int t_cout, t_kp, t_y_cs, t_y_coff, t_out_f32, t_act;
 };
+// true when launch_conv_igemm can run `lead` with `tail` (a 1x1 / stride 1 / pad 0 conv reading exactly lead's output) in its epilogue:
+// fp16, lead = SiLU without residual with Cout 64 or 80 (a wave then owns every channel of its pixels), tail.Cout <= lead.Cout
+bool conv_tail_supported(int dtype, const ConvArgs& lead, const ConvArgs& tail);
 // dtype: AIC_F16 or AIC_F32 (type of x / w / res and, unless out_f32, y)
 void launch_conv_igemm(int dtype, const ConvArgs& a, hipStream_t s);
 // a whole 64-channel BasicBlock (c1: conv3x3+ReLU, c2: conv3x3 + block input, ReLU) in one fp16 kernel with the intermediate in

@@ -218,7 +218,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
 //    arithmetic is uniform (also in the drain iterations, which load zeros nobody reads);
 //  * im2col address = per-row base pointer + one per-thread tap offset; in-bounds is a precomputed
 //    bit per (row, tap).
-template <typename T, int MT, int NT, int WM, int WN, int NSTAGE>
+//  * TAIL: the conv's output feeds a 1x1 conv (a.w_tail) that runs in this kernel's epilogue (tail_1x1, conv_common.hpp)
+template <typename T, int MT, int NT, int WM, int WN, int NSTAGE, bool TAIL = false>
 __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const ConvArgs a) {
     constexpr int CH = 16 / (int)sizeof(T);
     constexpr int BKE = 4 * CH;
@@ -421,16 +422,21 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const Conv
         const int m = m0 + (wm * MT + i) * 16 + r;
         mrow[i] = m < a.M ? m : -1;
     }
-    epilogue_dispatch<T, MT, NT, true>(a, acc, mrow, n0 + wn * NT * 16, q);
+    if constexpr (TAIL) {
+        static_assert(sizeof(T) == 2 && WN == 1, "the tail needs fp16 and a wave that owns every channel of its pixels");
+        tail_1x1<MT, NT>(a, acc, mrow, lane);
+    } else {
+        epilogue_dispatch<T, MT, NT, true>(a, acc, mrow, n0 + wn * NT * 16, q);
+    }
 }
 
-template <typename T, int MT, int NT, int WM, int WN, int NSTAGE>
+template <typename T, int MT, int NT, int WM, int WN, int NSTAGE, bool TAIL = false>
 static void launch_dma(const ConvArgs& a, hipStream_t s) {
     constexpr int RP = 16 * WM * WN;
     constexpr int BM = WM * MT * 16, BN = WN * NT * 16, BNP = (BN + RP - 1) / RP * RP;
     dim3 grid(ceil_div(a.M, BM), ceil_div(a.Cout, BN));
     const size_t lds = (size_t)NSTAGE * (BM + BNP) * 64;
-    auto kfn = conv_igemm_dma_kernel<T, MT, NT, WM, WN, NSTAGE>;
+    auto kfn = conv_igemm_dma_kernel<T, MT, NT, WM, WN, NSTAGE, TAIL>;
     static bool attr = false;
     if (!attr && lds > 64 * 1024) {
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -485,10 +491,41 @@ static void launch_conv_t(const ConvArgs& a, hipStream_t s) {
     }
 }
 
+// Lead conv of a (conv, 1x1) pair with the 1x1 in its epilogue.  Only the kernels whose waves own all channels of their pixels:
+// the 3x3 patch kernel where it applies (Cout 64), else the LDS-DMA implicit GEMM with NT = Cout / 16 and WN = 1 -- the same
+// choices the conv gets on its own.
+bool conv_tail_supported(int dtype, const ConvArgs& lead, const ConvArgs& tail) {
+    static const bool off = getenv("AICAM_NO_TAIL") != nullptr;
+    if (off || dtype != AIC_F16 || conv_impl() != 2) return false;
+    if ((lead.Cout != 64 && lead.Cout != 80) || lead.act != 1 || lead.res_mode != 0 || lead.out_f32) return false;
+    if (tail.KH != 1 || tail.KW != 1 || tail.stride != 1 || tail.pad != 0 || tail.res_mode != 0) return false;
+    if (tail.x != lead.y || tail.x_cs != lead.y_cs || tail.x_coff != lead.y_coff || tail.M != lead.M || tail.Cin != lead.Cout) return false;
+    if (tail.Cout > lead.Cout || tail.Kp != 32 * ((lead.Cout + 31) / 32) || tail.cout_pad < lead.Cout) return false;
+    if (lead.cout_pad < lead.Cout || (tail.y_cs | tail.y_coff) % 8) return false;
+    return true;
+}
+
+static void launch_conv_tail(const ConvArgs& a, hipStream_t s) {
+    if (a.Cout == 64) {
+        if (conv_try_patch_tail(a, s)) return;
+        if ((long)ceil_div(a.M, 128) >= 512) launch_dma<half_t, 4, 4, 4, 1, 4, true>(a, s);   // 256 px x 64 ch
+        else launch_dma<half_t, 2, 4, 4, 1, 4, true>(a, s);                                   // 128 px x 64 ch
+    } else {                                                                                  // 80
+        if (ceil_div(a.M, 512) >= 256) launch_dma<half_t, 4, 5, 8, 1, 3, true>(a, s);          // 512 px x 80 ch
+        else launch_dma<half_t, 2, 5, 4, 1, 4, true>(a, s);                                   // 128 px x 80 ch
+    }
+}
+
 void launch_conv_igemm(int dtype, const ConvArgs& a0, hipStream_t s) {
     if (a0.M <= 0) return;
     ConvArgs a = a0;
     a.xcd_map = xcd_map_on();
+    if (a.w_tail) {
+        AIC_REQUIRE(dtype == AIC_F16 && (a.Cout == 64 || a.Cout == 80) && a.act == 1 && a.res_mode == 0, AIC_ERR_INVALID,
+                    "conv with a 1x1 tail: unsupported lead (check conv_tail_supported before setting w_tail)");
+        launch_conv_tail(a, s);
+        return;
+    }
     if (dtype == AIC_F16 && conv_try_c16(a, s)) return;
     if (dtype == AIC_F16 && conv_try_c64_resident(a, s)) return;
     if (dtype == AIC_F16) launch_conv_t<half_t>(a, s);

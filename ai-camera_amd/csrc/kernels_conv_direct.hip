@@ -403,7 +403,8 @@ template <int CPP> __device__ __forceinline__ int patch_swz(int p) { return CPP 
 //    3*CSTEPS*MT precomputed VGPRs and the tap row kh is a ds_read immediate;
 //  * taps, chunks and ring stages are fully unrolled; the weight stream is a pointer increment.
 // VALU per MFMA drops from ~12 to <1 (SQ_INSTS_VALU / SQ_INSTS_MFMA, profiles/).
-template <typename T, int MT, int NT, int WM, int WN, int TH, int TW, int NSTAGE, int LGCPP>
+// TAIL: a 1x1 conv (a.w_tail) runs in the epilogue on the tile in registers (tail_1x1, conv_common.hpp).
+template <typename T, int MT, int NT, int WM, int WN, int TH, int TW, int NSTAGE, int LGCPP, bool TAIL = false>
 __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(const ConvArgs a, int tiles_x, int tiles_y) {
     constexpr int CH = 16 / (int)sizeof(T);
     constexpr int BKE = 4 * CH;
@@ -526,10 +527,15 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(const ConvA
         const int oy = oy0 + pt / TW, ox = ox0 + pt % TW;
         mrow[i] = (oy < a.Ho && ox < a.Wo) ? (img * a.Ho + oy) * a.Wo + ox : -1;
     }
-    epilogue_dispatch<T, MT, NT, true>(a, acc, mrow, n0 + wn * NT * 16, q);
+    if constexpr (TAIL) {
+        static_assert(sizeof(T) == 2 && WN == 1, "the tail needs fp16 and a wave that owns every channel of its pixels");
+        tail_1x1<MT, NT>(a, acc, mrow, lane);
+    } else {
+        epilogue_dispatch<T, MT, NT, true>(a, acc, mrow, n0 + wn * NT * 16, q);
+    }
 }
 
-template <typename T, int MT, int NT, int WM, int WN, int TH, int TW, int NSTAGE, int LGCPP>
+template <typename T, int MT, int NT, int WM, int WN, int TH, int TW, int NSTAGE, int LGCPP, bool TAIL = false>
 static bool launch_patch(const ConvArgs& a, hipStream_t s) {
     constexpr int CH = 16 / (int)sizeof(T), NTHR = 64 * WM * WN, RP = NTHR / 4;
     constexpr int BN = WN * NT * 16, BNP = (BN + RP - 1) / RP * RP;
@@ -540,7 +546,7 @@ static bool launch_patch(const ConvArgs& a, hipStream_t s) {
     if (a.Cin != CPP * CH) return false;
     const int tiles_x = ceil_div(a.Wo, TW), tiles_y = ceil_div(a.Ho, TH);
     const int n_img = a.M / (a.Ho * a.Wo);
-    auto kfn = conv3x3_patch_kernel<T, MT, NT, WM, WN, TH, TW, NSTAGE, LGCPP>;
+    auto kfn = conv3x3_patch_kernel<T, MT, NT, WM, WN, TH, TW, NSTAGE, LGCPP, TAIL>;
     static bool attr = false;
     if (lds > 64 * 1024 && !attr) {
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -574,6 +580,15 @@ static bool try_patch(const ConvArgs& a, hipStream_t s) {
         return launch_patch<T, 4, 2, 4, 1, 16, 16, 3, LG32>(a, s);
     }
     return false;
+}
+
+// the Cout = 64 patch kernel with a 1x1 tail (same eligibility as try_patch)
+bool conv_try_patch_tail(const ConvArgs& a, hipStream_t s) {
+    static const bool off = getenv("AICAM_NO_PATCH") != nullptr;
+    if (off || a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.Wo < 16 || a.Ho < 8 || a.M < 200000 || a.Cout != 64) return false;
+    const bool wide = a.Wo % 32 == 0 || (a.Wo % 16 != 0 && a.Wo >= 32);
+    if (wide) return launch_patch<half_t, 4, 4, 4, 1, 8, 32, 3, 3, true>(a, s);
+    return launch_patch<half_t, 4, 4, 4, 1, 16, 16, 3, 3, true>(a, s);
 }
 
 bool conv_try_patch(int dtype, const ConvArgs& a, hipStream_t s) {

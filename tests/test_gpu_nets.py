@@ -357,3 +357,87 @@ np.save(%r, he.HipEngine(%r, dtype="fp16", max_items=8, warm_up=False).reid_infe
     unf = np.load(tmp_path / "unfused.npy")
     print(f"fused C2f: err vs fp32 oracle {err:.2e} (four-launch form: {np.abs(unf - ref).max():.2e}); fused vs four launches {np.abs(got - unf).max():.2e}")
     assert err < 5e-3 and np.abs(got - unf).max() < 2e-3
+
+
+_TAIL_CHILD = r"""
+import importlib, sys, numpy as np
+sys.path.insert(0, %r)
+he = importlib.import_module("ai-camera_amd.hip_engine")
+L = importlib.import_module("ai-camera_amd._lib")
+x = np.load(%r)
+eng = he.HipEngine(%r, dtype="fp16", max_items=%d, warm_up=False)
+L.call("aic_prof_reset", 0)
+L.call("aic_prof_enable", 0, 1)
+out = eng.%s(x)
+n = L.prof_read(0)["conv_igemm"]["launches"]
+L.call("aic_prof_enable", 0, 0)
+np.savez(%r, n=n, **{"o%%d" %% i: o for i, o in enumerate(out if isinstance(out, tuple) else (out,))})
+"""
+
+
+def _run_with_and_without_tail(tmp_path, path, x, items, method):
+    """-> (outputs, conv launches) of this process (1x1 tails fused) and of a child with AICAM_NO_TAIL=1 (every conv on its own)."""
+    import subprocess
+    import sys
+    L = pkg("_lib")
+    eng = HipEngine(path, dtype="fp16", max_items=items, warm_up=False)
+    L.call("aic_prof_reset", 0)                       # counters are cumulative per process
+    L.call("aic_prof_enable", 0, 1)
+    out = getattr(eng, method)(x)
+    n_fused = L.prof_read(0)["conv_igemm"]["launches"]
+    L.call("aic_prof_enable", 0, 0)
+    eng.close()
+    out = out if isinstance(out, tuple) else (out,)
+    np.save(tmp_path / "x.npy", x)
+    code = _TAIL_CHILD % (ROOT, str(tmp_path / "x.npy"), path, items, method, str(tmp_path / "unfused.npz"))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, AICAM_NO_TAIL="1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-1500:]
+    z = np.load(tmp_path / "unfused.npz")
+    return out, n_fused, tuple(z["o%d" % i] for i in range(len(out))), int(z["n"])
+
+
+def test_fused_head_tail(gpu, engines, tmp_path):
+    """YOLOv8n's detect branches end in a 1x1 conv (22.box*.2, 22.cls*.2) that now runs in the epilogue of the 3x3 before it, on the
+    tile in registers (tail_1x1, csrc/conv_common.hpp).  Same products, same K order, same roundings: the raw head must be
+    BIT-IDENTICAL to the engine run with every conv on its own (child process, AICAM_NO_TAIL=1), with seven launches fewer: the six
+    branch ends, and 3.conv (3x3 / stride 2, 32 -> 64) whose only reader is 4.c2f.cv1 (1x1, 64 -> 64) -- the same graph property.
+    48 images: level 0 takes the patch kernel (box) and the 512-pixel DMA tile (cls), levels 1 and 2 the smaller DMA tiles."""
+    x = np.random.default_rng(7).standard_normal((48, 3, 640, 640)).astype(np.float32) * 0.5
+    (dfl, cls), n_f, (dfl_u, cls_u), n_u = _run_with_and_without_tail(tmp_path, engines[0], x, 48, "yolo_head_np")
+    print(f"fused head tails: conv launches {n_u} -> {n_f}; max |dfl| {np.abs(dfl).max():.2f}, max |cls| {np.abs(cls).max():.2f}")
+    assert n_u - n_f == 7, (n_u, n_f)
+    assert np.isfinite(dfl).all() and np.abs(dfl).max() > 0.1 and np.abs(cls).max() > 0.1
+    assert np.array_equal(dfl, dfl_u) and np.array_equal(cls, cls_u)
+
+
+def test_fused_tail_wide_patch_and_narrow_tail(gpu, tmp_path):
+    """The forms the YOLOv8 engines do not reach: the 8 x 32-tile patch kernel with a tail (map width a multiple of 32), a tail
+    with FEWER output channels than its lead (24 of 64: part of the MFMA tiles is padding), SiLU on the tail and fp16 output,
+    an 80-channel lead whose tail has 48 outputs.  Bit-identical to the unfused engine; oracle within fp16 rounding."""
+    g = ef.Graph(ef.KIND_REID, 64, 64)
+    wg = ef._WeightGen(11)
+
+    def conv(name, src, dst, cin, cout, k, s, act, **kw):
+        g.conv(name, src, dst, cin, cout, k, s, act, wb=wg(cout, cin, k, act), **kw)
+    inp = g.buf(64, 64, 8)
+    a = g.buf(64, 64, 64); conv("c0", inp, a, 3, 64, 3, 1, ef.ACT_SILU)
+    b = g.buf(64, 64, 64); conv("lead64", a, b, 64, 64, 3, 1, ef.ACT_SILU)
+    c = g.buf(64, 64, 24); conv("tail24", b, c, 64, 24, 1, 1, ef.ACT_SILU)
+    d = g.buf(64, 64, 80); conv("lead80", c, d, 24, 80, 3, 1, ef.ACT_SILU)
+    e = g.buf(64, 64, 48); conv("tail48", d, e, 80, 48, 1, 1, ef.ACT_NONE)
+    p = g.buf(1, 1, 48); g.simple(ef.OP_AVGPOOL, e, p, 48)
+    q = g.buf(1, 1, 64); conv("fc", p, q, 48, 64, 1, 1, ef.ACT_NONE)
+    emb = g.buf(1, 1, 64, ef.DT_F32); g.simple(ef.OP_L2NORM, q, emb, 64)
+    g.outputs.append([emb, 64, 0, 0, 0, 0, 0, 0]); g.meta = [64, 0, 0, 0, 0, 0, 0, 0]
+    path = str(tmp_path / "tail.aicw")
+    ef.write_engine(path, g)
+    x = np.random.default_rng(5).standard_normal((56, 3, 64, 64)).astype(np.float32)     # 56 x 4096 pixels: the patch kernel applies
+    (got,), n_f, (unf,), n_u = _run_with_and_without_tail(tmp_path, path, x, 56, "reid_infer_np")
+    assert n_u - n_f == 2, (n_u, n_f)
+    assert np.array_equal(got, unf)
+    eo = N.EngineOracle(path)
+    torch.set_num_threads(8)
+    ref = eo.run(torch.from_numpy(x[:8]))[eo.outputs[0][0]][:, :, 0, 0].numpy()
+    err = np.abs(got[:8] - ref).max()
+    print(f"fused tails (wide patch, narrow tails): conv launches {n_u} -> {n_f}; err vs fp32 oracle {err:.2e}")
+    assert err < 5e-3
