@@ -29,10 +29,15 @@ out = {
     "method": sys.argv[3],
 }
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-try:    # algorithmic bytes of the same launches (library counter, AICAM_NO_TAPER=1 run): does not change with the kernels
+try:    # algorithmic bytes of the same workload (library counter, AICAM_NO_TAPER=1 run).  What does not change with the kernels is the
+        # TOTAL over the sampled launch groups; per launch it moves whenever launches are merged, so it is re-derived from the total
     prev = json.load(open(os.path.join(root, "profiles", "pmc_traffic.json")))
-    if "algorithmic_bytes_per_launch_same_basis" in prev:
-        out["algorithmic_bytes_per_launch_same_basis"] = prev["algorithmic_bytes_per_launch_same_basis"]
+    total = prev.get("algorithmic_bytes_sampled_total")
+    if total is None and "algorithmic_bytes_per_launch_same_basis" in prev:
+        total = prev["algorithmic_bytes_per_launch_same_basis"] * prev["launches_sampled"]
+    if total is not None and n1:
+        out["algorithmic_bytes_sampled_total"] = total
+        out["algorithmic_bytes_per_launch_same_basis"] = total / n1
 except Exception:
     pass
 tag = sys.argv[4] if len(sys.argv) > 4 else "r02"

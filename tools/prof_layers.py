@@ -66,10 +66,11 @@ def main(d, frames=16, crops=480, top=30, fused_stem=1, fused_yolo_stem=1, fused
     if fused_block:     # the detect branches' last 1x1 (22.box*.2 / 22.cls*.2, n-scale: 64 / 80 channels) runs in the epilogue of the 3x3 before it
         merged = []
         for L in layers:
-            if (merged and L[0] == "yolo" and L[1].startswith("22.") and L[1].endswith(".2") and merged[-1][1] == L[1][:-1] + "1"
-                    and merged[-1][3] in (64, 80) and L[3] <= merged[-1][3]):
+            head = L[1].startswith("22.") and L[1].endswith(".2") and bool(merged) and merged[-1][1] == L[1][:-1] + "1"
+            c2f_in = L[1] == "4.c2f.cv1" and bool(merged) and merged[-1][1] == "3.conv"      # same graph property: 3.conv's only reader is this 1x1
+            if merged and L[0] == "yolo" and (head or c2f_in) and merged[-1][3] in (64, 80) and L[3] <= merged[-1][3]:
                 p = merged.pop()
-                merged.append((p[0], p[1] + "+.2", p[2], 1, p[3] * p[4] + L[3] * L[4]))
+                merged.append((p[0], p[1] + ("+.2" if head else "+4.c2f.cv1"), p[2], 1, p[3] * p[4] + L[3] * L[4]))
             else:
                 merged.append(L)
         layers = merged
