@@ -1,0 +1,14 @@
+"""Does the fp16 ReID engine give the same bits for a crop whatever the batch it is in?  (kernel variants are chosen by batch size)
+    python tools/inv_check.py        [AICAM_NO_SIDE=1 / AICAM_NO_TAIL=1 to rule a fusion in or out]"""
+import importlib, os, sys, numpy as np
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+he = importlib.import_module("ai-camera_amd.hip_engine")
+ef = importlib.import_module("ai-camera_amd.engine_file")
+root = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
+yp, rp = ef.ensure_seeded_engines(root, scale="n")
+x = np.random.default_rng(3).standard_normal((832, 3, 256, 128)).astype(np.float32)
+big = he.HipEngine(rp, dtype="fp16", max_items=832, warm_up=False).reid_infer_np(x)
+for n in (256, 64, 8):
+    e = he.HipEngine(rp, dtype="fp16", max_items=n, warm_up=False).reid_infer_np(x[:n])
+    d = np.abs(e - big[:n])
+    print(os.environ.get("AICAM_NO_SIDE", "-"), os.environ.get("AICAM_NO_TAIL", "-"), n, "equal", np.array_equal(e, big[:n]), "max diff", d.max(), "rows differing", int((d.max(1) > 0).sum()))
