@@ -707,7 +707,7 @@ __device__ __forceinline__ int ring_push(int& glen, int& ghead, int gmax) {
 
 __global__ __launch_bounds__(TRK_DEV_TMAX) void trk_epoch_kernel(EpochArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    __shared__ int s_err, s_napp_total;
+    __shared__ int s_err;
     long long t_ph = a.prof ? clock64() : 0;
     const Lds L = lds_carve(smem, a.prm.cap, a.nmax, a.lds_bytes);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -723,7 +723,7 @@ __global__ __launch_bounds__(TRK_DEV_TMAX) void trk_epoch_kernel(EpochArgs a) {
 
     // ---- load the track table (uniform copies of the scalars in registers)
     int T = a.hdr->n_tracks, next_id = a.hdr->next_id, nfree = a.hdr->n_free;
-    if (tid == 0) { s_err = 0; s_napp_total = 0; if (a.out.dbg_match) a.out.dbg_match[0] = 0; }
+    if (tid == 0) { s_err = 0; if (a.out.dbg_match) a.out.dbg_match[0] = 0; }
     if (tid < T) {
         const DevTrack t = a.trk[tid];
         L.id[tid] = t.id, L.state[tid] = t.state, L.hits[tid] = t.hits, L.age[tid] = t.age, L.tsu[tid] = t.tsu, L.cls[tid] = t.cls;
@@ -876,10 +876,9 @@ __global__ __launch_bounds__(TRK_DEV_TMAX) void trk_epoch_kernel(EpochArgs a) {
                     const int pos = ring_push(gl, gh, gmax);
                     L.glen[tid] = gl, L.ghead[tid] = gh;
                     const int na = L.napp[tid];
+                    (void)pos;                                     // the ring position is re-derived at the end of the epoch (see there)
                     L.newrow[tid * TRK_KMAX + na] = (unsigned short)(erow0 + det);
                     L.napp[tid] = na + 1;
-                    const int ai = atomicAdd(&s_napp_total, 1);
-                    a.scr.appends[ai * 3] = L.slot[tid], a.scr.appends[ai * 3 + 1] = pos, a.scr.appends[ai * 3 + 2] = erow0 + det;
                 }
                 L.hits[tid] += 1;
                 L.tsu[tid] = 0;
@@ -919,11 +918,9 @@ __global__ __launch_bounds__(TRK_DEV_TMAX) void trk_epoch_kernel(EpochArgs a) {
                 L.sm[ti] = -1, L.glen0[ti] = 0, L.mdet[ti] = -1;
                 int gl = 0, gh = 0, na = 0;
                 if (L.dhas[det]) {
-                    const int pos = ring_push(gl, gh, gmax);
+                    (void)ring_push(gl, gh, gmax);
                     L.newrow[ti * TRK_KMAX] = (unsigned short)(erow0 + det);
                     na = 1;
-                    const int ai = atomicAdd(&s_napp_total, 1);
-                    a.scr.appends[ai * 3] = slot, a.scr.appends[ai * 3 + 1] = pos, a.scr.appends[ai * 3 + 2] = erow0 + det;
                 }
                 L.glen[ti] = gl, L.ghead[ti] = gh, L.napp[ti] = na;
             }
@@ -983,10 +980,44 @@ __global__ __launch_bounds__(TRK_DEV_TMAX) void trk_epoch_kernel(EpochArgs a) {
     }
 
     // ---- gallery rows appended in this epoch: raw row (export) + unit row (cost kernels), one ring position each.
+    //      The list is built HERE from the tracks that are alive at the end of the epoch, not queued frame by frame: slots are
+    //      recycled LIFO, so a tentative track born in frame f, deleted in f + 1 and its slot reused in f + 2 of the same epoch
+    //      left two queue entries for one (slot, position) -- the dead track's row and the new owner's -- written by different
+    //      waves in this loop: whichever landed last became the new track's first gallery row (K >= 3 frames per epoch and spurious
+    //      tentative tracks needed; found on the texture scene, where two identical runs disagreed).  A live track owns its slot
+    //      alone, its `napp` appended rows are its newest (never evicted inside the epoch: k <= gmax), and the newest row of a
+    //      ring is at ghead + glen - 1: entry q of track t goes to ghead + glen - napp + q.  Dead tracks' rows are not written.
     //      16-byte copies, four rows per wave in flight (dim % 4 == 0 on this path)
     __syncthreads();
     {
-        const int na = s_napp_total;
+        const int myn = tid < T ? L.napp[tid] : 0;
+        int incl = myn;                                          // inclusive scan over the wave, wave totals through wcnt
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int u = __shfl_up(incl, o);
+            if (lane >= o) incl += u;
+        }
+        if (lane == 63) L.wcnt[wv] = incl;
+        __syncthreads();
+        int off = incl - myn, na = 0;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const int c = L.wcnt[i];
+            if (i < wv) off += c;
+            na += c;
+        }
+        if (myn > 0) {
+            const int slot = L.slot[tid];
+            int pos = L.ghead[tid] + L.glen[tid] - myn;           // >= 0: glen counts the appended rows
+            if (pos >= gmax) pos -= gmax;
+            for (int q = 0; q < myn; ++q) {
+                int* e = a.scr.appends + (size_t)(off + q) * 3;
+                e[0] = slot, e[1] = pos, e[2] = L.newrow[tid * TRK_KMAX + q];
+                if (++pos == gmax) pos = 0;
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
         const floatx4* fr = reinterpret_cast<const floatx4*>(a.dets.feat + (size_t)a.d_begin * dim);
         const floatx4* fn = reinterpret_cast<const floatx4*>(a.dets.feat_n + (size_t)a.d_begin * dim);
         floatx4* graw = reinterpret_cast<floatx4*>(a.gal_raw);

@@ -254,9 +254,10 @@ def test_fp16_own_detections_vs_fp32_oracle_chain(gpu, engines):
     What the numbers can and cannot say: seeded heads fire on background texture -- dozens of large, mutually overlapping boxes
     whose crops look alike, so appearance costs sit close together and the association is near-degenerate: one near-tie that
     rounds the other way re-labels a cluster of tracks.  The fp32 engine reproduces every detection bit for bit and 95 % of the
-    oracle's track outputs (the rest: near-ties in the appearance cost, 1e-7 apart); the fp16 engine reproduces the DETECTIONS
-    (98.8 %), and its track-level agreement is reported, with a loose floor, as a property of this texture scene -- the planted-person runs (test_bench_shaped_group_fp16, test_configs2_pipeline_ids) are where fp16
-    track ids are required to be identical, and they are."""
+    oracle's track outputs; the fp16 engine reproduces the DETECTIONS (98.9 %), and its track-level agreement is reported with a
+    loose floor as a property of this texture scene -- the planted-person runs (test_bench_shaped_group_fp16,
+    test_configs2_pipeline_ids) are where fp16 track ids are required to be identical, and they are.  Digests of both sides' track
+    outputs are printed: when an agreement figure moves, they say which side moved."""
     n_frames, batch = 320, 32
     sc = syn.Scene(seed=12, n_targets=20)
     frames = sc.render_batch(0, n_frames)
@@ -278,16 +279,18 @@ def test_fp16_own_detections_vs_fp32_oracle_chain(gpu, engines):
         s0 = np.sort(oracle_detect(frames[0])[1])[::-1]
         min_conf = float((s0[24] + s0[25]) / 2)
         TP = pkg("pipeline").TrackingPipeline
-        runs = {}
+        runs, last_emb = {}, {}
         for dtype in ("fp32", "fp16"):
             pipe = TP(engines[0], engines[1], (720, 1280), batch=batch, ring_frames=n_frames, max_persons=64, dtype=dtype, inject=False,
                       min_confidence=min_conf, max_tracks=512)
             pipe.upload(0, frames)
             runs[dtype] = pipe.run(0, n_frames, want_dets=True)
+            last_emb[dtype] = pipe.group_embeddings()
             pipe.close()
         trk = O.OracleTracker()
         stat = {d: dict(id_map={}, switches=0, n_hit=0, n_out=0, det_frac=[], box_dev=0.0, score_dev=0.0) for d in runs}
         n_ref = 0
+        oracle_out = []
         for f in range(n_frames):
             ob, osc, ol = oracle_detect(frames[f])
             keep = [i for i in range(len(ob)) if osc[i] >= min_conf]
@@ -297,6 +300,7 @@ def test_fp16_own_detections_vs_fp32_oracle_chain(gpu, engines):
             trk.predict()
             trk.update(list(tlwh), list(c), [config.class_name(int(k)) for k in ol[keep]], [emb[i] if valid[i] else None for i in range(len(b))])
             exp = trk.output_tuples()
+            oracle_out.append(exp)
             n_ref += len(exp)
             for d, (tracks, dets) in runs.items():
                 st = stat[d]
@@ -322,12 +326,24 @@ def test_fp16_own_detections_vs_fp32_oracle_chain(gpu, engines):
                   f"{np.mean(st['det_frac']):.4f} of the oracle's detections reproduced (IoU > 0.98, same class), max box dev {st['box_dev']:.2f} px, "
                   f"max score dev {st['score_dev']:.4f}; confirmed track outputs oracle {n_ref} / HIP {st['n_out']}, "
                   f"{st['n_hit']} reproduced ({st['n_hit'] / max(n_ref, 1):.4f}), ID switches {st['switches']}")
+        import hashlib
+        digest = lambda v: hashlib.sha1(repr(v).encode()).hexdigest()[:12]
+        for d in runs:     # where a context-dependent run first leaves the other: one digest per 32-frame launch group, + the last group's ReID output
+            print(f"[{d}] per-group track digests " + " ".join(digest(runs[d][0][g:g + batch])[:6] for g in range(0, n_frames, batch))
+                  + f"; last group: embeddings {hashlib.sha1(np.ascontiguousarray(last_emb[d][0]).tobytes()).hexdigest()[:10]}, "
+                  f"crops/frame {digest(last_emb[d][1].tolist())[:6]}, detections {digest([[x.tolist() for x in runs[d][1][f]] for f in range(n_frames - batch, n_frames)])[:6]}")
+        print("track-output digests (which side moves when the agreement moves): "
+              + ", ".join(f"HIP {d} {digest(runs[d][0])}" for d in runs) + f", oracle {digest(oracle_out)}")
         assert n_ref > 150                                      # the chains confirm tracks (static background inside a 16-frame block)
         f32, f16 = stat["fp32"], stat["fp16"]
-        # measured: fp32 1.0000 / 0.00 px / 0.9515 reproduced / 8 switches; fp16 0.9879 / 8.2 px / 0.0013 / 0.3758 reproduced / 36 switches
-        assert np.mean(f32["det_frac"]) > 0.999 and f32["box_dev"] < 0.02 and f32["n_hit"] / n_ref > 0.9 and f32["switches"] <= 0.05 * f32["n_hit"]
+        # Measured (host and device association alike, every run): fp32 1.0000 of the detections, 0.00 px, 330 of 330 track outputs
+        # reproduced, 0 ID switches; fp16 0.989 / 7.2 px / 0.0014, 0.30 of the track outputs, 26 switches (the appearance costs of
+        # this scene sit 1e-7 .. 1e-4 apart: fp16 embeddings re-label clusters of tracks; reported, loose floor).
+        # History: this test is what exposed the gallery-commit race of the device epochs (two dead/reborn tracks sharing a slot
+        # inside one epoch) -- fp32 agreement then wandered between 0.54 and 1.0 from run to run.
+        assert np.mean(f32["det_frac"]) > 0.999 and f32["box_dev"] < 0.02 and f32["n_hit"] / n_ref > 0.95 and f32["switches"] <= 0.02 * n_ref
         assert np.mean(f16["det_frac"]) > 0.97 and f16["box_dev"] < 12.0 and f16["score_dev"] < 0.005
-        assert f16["n_hit"] / n_ref > 0.25                      # reported above; see the docstring for what bounds it
+        assert 0.5 < f16["n_out"] / n_ref < 2.0 and f16["n_hit"] / n_ref > 0.1
     finally:
         config.CLASSES_TO_TRACK.clear()
         config.CLASSES_TO_TRACK.update(old)
