@@ -217,7 +217,8 @@ def test_gallery_exchange_consumer_failure_is_loud_not_a_hang(gpu, engines, monk
     pipe.close()
 
 
-def test_device_epochs_equal_host_on_near_tie_scene(gpu, engines):
+@pytest.mark.parametrize("dtype", ["fp32", "fp16"])
+def test_device_epochs_equal_host_on_near_tie_scene(gpu, engines, dtype):
     """The detector's own boxes on background texture: dozens of look-alike crops, spurious tentative tracks born and deleted every
     few frames, appearance costs 1e-7 .. 1e-4 apart.  The association in 16-frame epochs on the device must give the host
     association's rows on every frame, and give them again on a second run.
@@ -234,7 +235,7 @@ def test_device_epochs_equal_host_on_near_tie_scene(gpu, engines):
         TP = pkg("pipeline").TrackingPipeline
         out = {}
         for name, mode in (("host", 0), ("dev1", 2), ("dev2", 2)):
-            pipe = TP(engines[0], engines[1], (720, 1280), batch=batch, ring_frames=n_frames, max_persons=64, dtype="fp32", inject=False,
+            pipe = TP(engines[0], engines[1], (720, 1280), batch=batch, ring_frames=n_frames, max_persons=64, dtype=dtype, inject=False,
                       min_confidence=0.9441, max_tracks=512)
             pipe.option("device_assoc", mode)
             pipe.upload(0, frames)
