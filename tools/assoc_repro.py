@@ -185,9 +185,48 @@ def pipe_stages(n_frames=96, dtype="fp32", batch=32, mode=2):
         print(f"group {gi} (frames {gi * batch}..{gi * batch + batch - 1}): " + ("; ".join(msgs) if msgs else "identical (detections, embeddings, rows, state)"))
 
 
+def fuzz(seeds=8, n_frames=64, dtype="fp32", batch=32):
+    """Host vs device association (rows of every frame) on several texture scenes: seeds, tracker floors (how many spurious
+    detections get through: up to a few hundred per frame) and gallery budgets."""
+    config, syn, ef = pkg("config"), pkg("synthetic"), pkg("engine_file")
+    TP = pkg("pipeline").TrackingPipeline
+    yp, rp = ef.ensure_seeded_engines(ROOT, scale="n")
+    config.CLASSES_TO_TRACK.clear()
+    config.CLASSES_TO_TRACK.update(config.CLASSES)
+    bad = 0
+    for seed in range(1, seeds + 1):
+        sc = syn.Scene(seed=100 + seed, n_targets=10 + 5 * (seed % 4))
+        frames = sc.render_batch(0, n_frames)
+        floor = (0.97, 0.9441, 0.90, 0.80)[seed % 4]
+        budget = (100, 100, 5, 40)[seed % 4]
+        out, nd = {}, None
+        for name, mode in (("host", 0), ("dev", 2)):
+            pipe = TP(yp, rp, (720, 1280), batch=batch, ring_frames=n_frames, max_persons=256, dtype=dtype, inject=False, min_confidence=floor,
+                      max_tracks=512, nn_budget=budget)
+            pipe.option("device_assoc", mode)
+            pipe.upload(0, frames)
+            try:
+                tr, dets = pipe.run(0, n_frames, want_dets=True)
+            except Exception as e:      # capacity errors are legitimate outcomes at the lowest floors; they must agree between the paths
+                tr, dets = ("error", str(e).split("(")[0][:80]), None
+            out[name] = tr
+            if dets is not None:
+                nd = [int((d[1] >= floor).sum()) for d in dets]
+            pipe.close()
+        same = out["host"] == out["dev"]
+        bad += 0 if same else 1
+        first = "" if same or isinstance(out["host"], tuple) or isinstance(out["dev"], tuple) else f", first differing frame {[f for f in range(n_frames) if out['host'][f] != out['dev'][f]][0]}"
+        rows = sum(len(r) for r in out["host"]) if not isinstance(out["host"], tuple) else out["host"]
+        print(f"seed {seed}: floor {floor}, budget {budget}, tracked detections per frame {min(nd) if nd else '-'}..{max(nd) if nd else '-'}, confirmed rows {rows}: "
+              f"{'identical' if same else 'DIFFERENT'}{first}")
+    print(f"{bad} of {seeds} scenes differ")
+
+
 if __name__ == "__main__":
     a = sys.argv[1:]
-    if a and a[0] == "stages":
+    if a and a[0] == "fuzz":
+        fuzz(int(a[1]) if len(a) > 1 else 8, int(a[2]) if len(a) > 2 else 64, a[3] if len(a) > 3 else "fp32")
+    elif a and a[0] == "stages":
         pipe_stages(int(a[1]) if len(a) > 1 else 96, a[2] if len(a) > 2 else "fp32", mode=int(a[3]) if len(a) > 3 else 2)
     elif a and a[0] == "pipe":
         pipe_modes(int(a[1]) if len(a) > 1 else 96, a[2] if len(a) > 2 else "fp32")
