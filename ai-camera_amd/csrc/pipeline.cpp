@@ -36,6 +36,7 @@ struct FrameDets {
 struct Chunk {
     int frames = 0, first_slot = 0, n_crops = 0;
     bool dev_mode = false;           // this group's association runs on the device (decided when the group is issued)
+    int tracks_after = 0;            // live tracks when this context's last group was released (or at the start of the call)
     PinBuf<float> h_boxes;
     PinBuf<int> h_frame_of, h_valid;
     DevBuf<float> d_boxes, d_emb, d_emb_n;
@@ -76,10 +77,14 @@ struct Pipeline {
     // registers (<= 64 tracks and <= 64 detections: lsap_wave64, cost matrices in LDS), else on the host for that launch group --
     // beyond 64 x 64 the single-wave LSAP is slower than the host's (configs[2], 100 x 100: 290 vs 230 us per frame)
     int dev_assoc = getenv("AICAM_TRK_HOST") ? 0 : (getenv("AICAM_TRK_DEV") ? 2 : 1);
-    std::atomic<int> tracks_seen{0};      // live tracks after the most recent launch group (sizes the next group's choice)
-    bool use_device(int n_max) const {
+    std::atomic<int> tracks_seen{0};      // live tracks after the most recent launch group
+    // `tracks_before`: the track count the decision may use.  It must not depend on timing -- the producer issues group k while the
+    // consumer may or may not have finished group k - 1 -- so it is the count recorded in the group's chunk context when that
+    // context's PREVIOUS group (k - NCK) was released, or the count at the start of the call for the first NCK groups.  The same
+    // frames then always take the same path (both give the same rows; a moving choice made a defect of one of them look random).
+    bool use_device(int n_max, int tracks_before) const {
         if (!dev_assoc || !trk.dev_capable()) return false;
-        return dev_assoc == 2 || (n_max <= 64 && tracks_seen.load() + n_max / 2 <= 64) || x_shard[0] != nullptr;
+        return dev_assoc == 2 || (n_max <= 64 && tracks_before + n_max / 2 <= 64) || x_shard[0] != nullptr;
     }
     bool taper = getenv("AICAM_NO_TAPER") == nullptr;   // aic_pipeline_option("taper")
     // configs[4]: cross-camera gallery exchange. The pipeline packs a shard of the stream's confirmed tracks on
@@ -257,7 +262,7 @@ struct Pipeline {
         }
         int n_max = 0;
         for (int f = 0; f < frames; ++f) n_max = std::max(n_max, c.dets[f].n);
-        const bool dev_mode = use_device(n_max);
+        const bool dev_mode = use_device(n_max, c.tracks_after);
         c.dev_mode = dev_mode;
         if (dev_mode) {   // what the epoch kernels read: frame_n[frames] | frame_d0[frames] | tlwh[nc,4] | conf[nc] | cls[nc]
             c.m_n = 0, c.m_d0 = (size_t)frames * 4, c.m_tlwh = (((size_t)frames * 8 + 15) / 16) * 16;
@@ -386,6 +391,7 @@ struct Pipeline {
         }
         trk.defer_outputs = false;             // direct users of the tracker handle get synchronous outputs
         tracks_seen = (int)trk.tracks.size();
+        c.tracks_after = tracks_seen;
         last_chunk = (int)(&c - &ck[0]);
         t_track += now() - t1;
         n_frames_done += c.frames;
@@ -426,6 +432,7 @@ struct Pipeline {
         HIP_CHECK(hipStreamSynchronize(s));
         trk.check_epochs();
         tracks_seen = reinterpret_cast<const DevTrkHdr*>(trk.h_tbl.p)->n_tracks;
+        c.tracks_after = tracks_seen;
         const double t2 = now();
         t_wait += t2 - t1;
         const int* on = reinterpret_cast<const int*>(c.h_out.p);
@@ -464,6 +471,7 @@ struct Pipeline {
         // the association epoch kernel holds one CU while the next group's convs run: persistent conv grids leave it free
         set_conv_cu_budget(dev_assoc && trk.dev_capable() ? dev->n_cu - 1 : dev->n_cu);
         tracks_seen = trk.on_device ? tracks_seen.load() : (int)trk.tracks.size();
+        for (auto& c : ck) c.tracks_after = tracks_seen;
         // Launch groups: full batches, then the last batch tapered (1/2, 1/4, ... down to 16 frames): stage B of the
         // final group cannot overlap any GPU work, so a short final group shortens the un-overlapped tail of the call.
         std::vector<int> goff, glen;
