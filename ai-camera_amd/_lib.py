@@ -74,12 +74,16 @@ _SIGS = {
     "aic_lsap": (_I, [_P, _I, _I, _P, _P]),
     "aic_min_cost_matching": (_I, [_P, _I, _I, _D, _P, _P, _P]),
     "aic_match_cascade": (_I, [_P, _P, _P, _I, _I, _P, _P, _D, _D, _I, _P, _P, _P, _P, _P, _P, _P]),
-    "aic_match_cascade_device": (_I, [_I, _P, _P, _P, _I, _I, _P, _P, _D, _D, _I, _I, _P]),
+    "aic_match_cascade_device": (_I, [_I, _P, _P, _P, _I, _I, _P, _P, _D, _D, _I, _I, _P, _P]),
     "aic_tracker_option": (_I, [_P, C.c_char_p, _I]),
     "aic_tracker_create": (_I, [_I, _P, _P]),
     "aic_tracker_destroy": (_I, [_P]),
     "aic_tracker_predict": (_I, [_P]),
     "aic_tracker_update": (_I, [_P, _P, _P, _P, _P, _I, _P, _I, _I]),
+    "aic_tracker_update_batch": (_I, [_P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "aic_tracker_import_state": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I]),
+    "aic_tracker_next_track_id": (_I, [_P, _P]),
+    "aic_tracker_assoc_counters": (_I, [_P, _P, _P]),
     "aic_tracker_outputs": (_I, [_P, _P, _P, _I, _P]),
     "aic_tracker_num_tracks": (_I, [_P, _P]),
     "aic_tracker_export": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
@@ -107,6 +111,7 @@ _SIGS = {
     "aic_pipeline_option": (_I, [_P, C.c_char_p, _I]),
     "aic_pipeline_counters": (_I, [_P, _P, _P]),
     "aic_pipeline_assoc_frames": (_I, [_P, _P, _P]),
+    "aic_pipeline_filter_counters": (_I, [_P, _P, _P, _P]),
     "aic_pipeline_group_embeddings": (_I, [_P, _P, _I, _P, _I, _P, _P, _P]),
     "aic_overlay": (_I, [_I, _P, _I, _I, _I, _P, _I, _P, _I]),
     "aic_prof_enable": (_I, [_I, _I]),

@@ -98,6 +98,66 @@ class TrackerCore:
         if dim:
             self._dim = dim
 
+    def update_batch(self, frames, cap_rows=512):
+        """k frames in one call, each a predict() + update() (tracker_core.py:44-81), as epochs of the device association
+        (aic_tracker_update_batch).  frames: list of (tlwh [N,4], conf [N], class ids [N], feats [N,D] or None, has_feat [N] or None).
+        Returns per frame (rows int32 [K,6], conf [K], matches [(track id, detection index)])."""
+        k = len(frames)
+        counts = np.array([len(f[0]) for f in frames], np.int32)
+        tot = int(counts.sum())
+        dim = 0
+        for f in frames:
+            if f[3] is not None and len(f[0]):
+                dim = int(np.asarray(f[3]).shape[1])
+                break
+        tlwh = np.zeros((tot, 4), np.float32)
+        conf, cls = np.zeros(tot, np.float32), np.zeros(tot, np.int32)
+        feats, has = np.zeros((tot, max(dim, 1)), np.float32), np.zeros(tot, np.uint8)
+        o = 0
+        for f in frames:
+            n = len(f[0])
+            if n:
+                tlwh[o:o + n], conf[o:o + n], cls[o:o + n] = np.asarray(f[0]).reshape(-1, 4), f[1], f[2]
+                if f[3] is not None:
+                    feats[o:o + n] = f[3]
+                    has[o:o + n] = 1 if len(f) < 5 or f[4] is None else np.asarray(f[4]).astype(np.uint8)
+            o += n
+        n_out, rows, oc = np.zeros(k, np.int32), np.zeros((k, cap_rows, 6), np.int32), np.zeros((k, cap_rows), np.float32)
+        n_m, m_t, m_d = np.zeros(k, np.int32), np.zeros((k, cap_rows), np.int32), np.zeros((k, cap_rows), np.int32)
+        L.call("aic_tracker_update_batch", self._h, k, L.ptr(counts), L.ptr(tlwh), L.ptr(conf), L.ptr(cls), L.ptr(feats) if dim else None, L.HOST,
+               L.ptr(has), dim, cap_rows, L.ptr(n_out), L.ptr(rows), L.ptr(oc), L.ptr(n_m), L.ptr(m_t), L.ptr(m_d))
+        if dim:
+            self._dim = dim
+        return [(rows[f, :min(n_out[f], cap_rows)], oc[f, :min(n_out[f], cap_rows)],
+                 list(zip(m_t[f, :n_m[f]].tolist(), m_d[f, :n_m[f]].tolist()))) for f in range(k)]
+
+    def export_state(self):
+        """Everything aic_tracker_import_state needs: the arrays of export_arrays(), the galleries in FIFO order, the next track id."""
+        a = self.export_arrays()
+        gal = [self._gallery(i, int(g)) for i, g in enumerate(a["gallery_len"])]
+        nxt = C.c_int32()
+        L.call("aic_tracker_next_track_id", self._h, C.byref(nxt))
+        a["galleries"] = np.concatenate(gal) if gal and self._dim else np.zeros((0, max(self._dim, 1)), np.float32)
+        a["dim"], a["next_track_id"] = self._dim, nxt.value
+        return a
+
+    def import_state(self, st):
+        """aic_tracker_import_state: replace TrackerCore.tracks (tracker_core.py:28) by an exported state."""
+        n = len(st["track_id"])
+        i32 = lambda k: np.ascontiguousarray(st[k], np.int32)
+        gal = L.as_f32(st["galleries"])
+        L.call("aic_tracker_import_state", self._h, n, L.ptr(i32("track_id")), L.ptr(i32("state")), L.ptr(i32("hits")), L.ptr(i32("age")),
+               L.ptr(i32("time_since_update")), L.ptr(i32("cls")), L.ptr(L.as_f32(st["conf"])), L.ptr(i32("gallery_len")),
+               L.ptr(L.as_f32(st["mean"])), L.ptr(L.as_f32(st["cov"])), L.ptr(gal) if gal.size else None, int(st["dim"]), int(st["next_track_id"]))
+        if st["dim"]:
+            self._dim = int(st["dim"])
+
+    def assoc_counters(self):
+        """(assignment problems settled by the unique-optimum check, solved by the wave LSAP) on the device path."""
+        a, b = C.c_int64(), C.c_int64()
+        L.call("aic_tracker_assoc_counters", self._h, C.byref(a), C.byref(b))
+        return a.value, b.value
+
     @property
     def tracks(self):
         return [TrackView(self, i, rec) for i, rec in enumerate(self._export())]

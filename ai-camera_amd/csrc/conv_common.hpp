@@ -427,6 +427,7 @@ inline int conv_impl() {   // AICAM_CONV=v1 selects the register-staged kernel (
 
 // ---- host entry points of the other conv units; each returns false when the layer is not one of its shapes
 bool conv_try_pp_patch(int dtype, const ConvArgs& a, hipStream_t s);   // kernels_conv_pp.hip: v5 ping-pong patch (3x3/s1, Cout 128 / 256k)
+bool conv_pp_patch_shape(int dtype, const ConvArgs& a);                // true when conv_try_pp_patch would take this layer at a large enough batch
 bool conv_try_pp(int dtype, const ConvArgs& a, hipStream_t s);         // kernels_conv_pp.hip: v4 ping-pong im2col (long K, Cout 128 / 256k)
 bool conv_try_patch(int dtype, const ConvArgs& a, hipStream_t s);      // kernels_conv_direct.hip: 4-wave patch kernel (Cout 64 / 32)
 bool conv_try_patch_tail(const ConvArgs& a, hipStream_t s);            // same kernel, Cout 64, with a.w_tail's 1x1 in its epilogue (fp16)

@@ -236,6 +236,7 @@ bool Model::input_pix4_ok() const {
 void Model::run(int n, hipStream_t s) {
     AIC_REQUIRE(n >= 0 && n <= max_items, AIC_ERR_CAPACITY, "batch exceeds the engine's max_items");
     if (n == 0) return;
+    AIC_REQUIRE(!n_items_dev || !(lead_ops > 0 && sub_items > 0), AIC_ERR_INVALID, "a device-side item count cannot be combined with sub-batching");
     if (lead_ops > 0 && sub_items > 0 && n > sub_items + sub_items / 2) {
         // producer -> consumer tensors of the first layers exceed the 256 MiB Infinity Cache at full batch:
         // walk them in sub-batches so each layer reads what the previous one just wrote from cache, not HBM
@@ -299,7 +300,7 @@ void Model::run_range(size_t op0, size_t op1, int i0, int n, hipStream_t s) {
             const double fl = 2.0 * n * sb.h * sb.w * 64.0 * 27.0;
             Prof pr(*dev, PROF_CONV_DIRECT, s, fl, (double)n * (sb.h * sb.w * 16.0 + pb.h * pb.w * 128.0));
             launch_reid_stem_pool(sb.p, w.w.p, w.bias.p, pb.p, n, sb.h, sb.w, w.Kp, pb.c, pv[5], in_pix4 ? 4 : 8, s,
-                                  (crop_src.frames && in_pix4 && i0 == 0) ? &crop_src : nullptr);
+                                  (crop_src.frames && in_pix4 && i0 == 0) ? &crop_src : nullptr, n_items_dev);
             continue;
         }
         if (v[0] == OP_CONV) {
@@ -318,6 +319,7 @@ void Model::run_range(size_t op0, size_t op1, int i0, int n, hipStream_t s) {
                 a.KH = w.kh, a.KW = w.kw, a.stride = u[9], a.pad = u[10];
                 a.Kp = w.Kp, a.M = n * yb.h * yb.w, a.out_f32 = yb.f32, a.cout_pad = w.cout_pad, a.zero = d_zero.p;
                 a.tap_rows = 0;
+                a.n_dev = n_items_dev;
                 for (int kh = 0; kh < w.kh; ++kh) a.tap_rows |= 1u << (kh * w.kw);
                 AIC_REQUIRE(w.kh * w.kw <= 25, AIC_ERR_FORMAT, "kernel window larger than 5x5");
                 fl += 2.0 * a.M * (double)w.cout * w.cin * w.kh * w.kw;
@@ -379,6 +381,7 @@ void Model::run_range(size_t op0, size_t op1, int i0, int n, hipStream_t s) {
             EltArgs a{};
             a.src = sb.p, a.dst = db.p, a.n = n, a.h = sb.h, a.w = sb.w, a.c = v[3];
             a.s_cs = sb.c, a.s_coff = v[2], a.d_cs = db.c, a.d_coff = v[5];
+            a.n_dev = n_items_dev;
             Prof pr(*dev, PROF_MISC, s, 0, 0);
             switch (v[0]) {
                 case OP_SPPF_POOL: launch_sppf_pool(dtype, a, s); break;

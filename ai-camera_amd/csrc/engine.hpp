@@ -42,6 +42,9 @@ struct Model {
     bool in_pix4 = false;
     // set around run(): the fused stem takes its crops straight from these frames / boxes (pipeline; no crop tensor in HBM)
     CropSrc crop_src{nullptr, 0, 0, nullptr, nullptr, nullptr};
+    // set around run(): the number of items is only known on the device (ReID behind the on-device detection filter): run(n) then
+    // sizes every launch for the bound n and the kernels leave past n_items_dev[0] (ConvArgs::n_dev)
+    const int* n_items_dev = nullptr;
     bool input_pix4_ok() const;
     void run(int n_items, hipStream_t s);
     // u8 BGR frames -> letterbox -> the whole graph; fp16 YOLO engines fuse the letterbox into the stem conv

@@ -24,6 +24,12 @@ struct ConvArgs {
     unsigned tap_rows;  // bit kh*KW set for kh < KH (replication pattern of the tap-validity mask)
     const void* zero;   // 64 bytes of zeros in HBM: LDS-DMA source for padded / out-of-range chunks
     int xcd_map;        // 1: blocks take tiles through xcd_tile() (set by launch_conv_igemm)
+    const int* n_dev;   // optional DEVICE-side item count (images / crops of this launch): M then is only an upper bound the grid was sized
+                        // for, and tiles past n_dev[0] * Ho * Wo leave at once (ReID behind the on-device detection filter, where the
+                        // host does not know the count when it launches).  NULL: M is exact
+    int k_chunk_major;  // 1: K is walked (channel chunk, tap) instead of (tap, channel chunk): the order of the ping-pong patch kernel.
+                        // Set by launch_conv_igemm for every layer SHAPE that kernel can take, so that such a layer accumulates in
+                        // the same order whichever kernel its batch size selects (embeddings do not depend on the batch)
     // ---- optional 1x1 "tail" conv run in this conv's epilogue (fp16 only; conv_tail_supported()).  This conv's own output
     // (SiLU(acc + bias) rounded to fp16, exactly what it would have stored) never leaves the registers: it is the B operand of
     // the tail's MFMAs.  y / y_cs / y_coff of THIS conv are then unused.  w_tail == NULL: no tail.
@@ -53,14 +59,16 @@ bool launch_yolo_stem_fused(const uint8_t* frames, int n, const LetterboxGeom& g
 // in_stride: halves per input pixel, 8 (NHWC8) or 4 (NHWC4 = RGB0; only where reid_stem2_usable(H, W))
 // frames != NULL: the fused fp16 ReID stem resamples every crop from the u8 frames itself (boxes [n,4] xyxy, frame_of[n] or NULL, valid[n] written)
 struct CropSrc { const uint8_t* frames; int fh, fw; const float* boxes; const int* frame_of; int* valid; };
+// n_dev: optional device-side crop count (see ConvArgs::n_dev)
 void launch_reid_stem_pool(const void* x, const void* w, const float* bias, void* y, int n, int H, int W, int Kp, int y_cs,
-                           int y_coff, int in_stride, hipStream_t s, const CropSrc* crop = nullptr);
+                           int y_coff, int in_stride, hipStream_t s, const CropSrc* crop = nullptr, const int* n_dev = nullptr);
 bool reid_stem2_usable(int H, int W);
 
 struct EltArgs {
     const void* src; void* dst;
     int n, h, w, c;            // source extent, channels processed
     int s_cs, s_coff, d_cs, d_coff;
+    const int* n_dev;          // optional device-side item count (n is then the bound the grid was sized for); NULL: n is exact
 };
 void launch_sppf_pool(int dtype, const EltArgs& a, hipStream_t s);     // writes 3 pooled copies at d_coff + k*c
 void launch_upsample2x(int dtype, const EltArgs& a, hipStream_t s);
@@ -110,6 +118,20 @@ struct DetArgs {
     int* out_labels;   // [B,max_det]
 };
 void launch_decode(const DetArgs& a, hipStream_t s);
+// deepsort_tracker.py:88-101 on the device: order-preserving confidence / class filter of a launch group's NMS outputs, compacted
+// into the arrays crop + ReID + the association epochs read (kernels_det.hip)
+struct DetFilterArgs {
+    const int* num_dets; const float* boxes; const float* scores; const int* labels;   // [B], [B,max_det,4] original-frame xyxy, [B,max_det] x 2
+    int batch, max_det;
+    float min_conf;
+    unsigned long long mask[2];     // bit c = class c is tracked
+    int cap;                        // rows the compact arrays hold (batch * max_det never overflows)
+    int* rank;                      // scratch [B, max_det]
+    int* frame_n; int* frame_d0;    // [B] kept detections of the frame, first row of the frame
+    int* total;                     // [2]: rows present (<= cap), rows the filter passed
+    float* xyxy; float* tlwh; float* conf; int* cls; int* frame_of;   // [cap, 4] x 2, [cap] x 3
+};
+void launch_det_filter(const DetFilterArgs& a, hipStream_t s);
 void launch_select_sort_nms(const DetArgs& a, hipStream_t s);
 
 // ------------------------------------------------------------------ tracker (kernels_trk.hip)
@@ -124,7 +146,7 @@ void launch_kf_gating(const float* mean, const float* cov, const int* slots, int
 void launch_iou_cost(const float* trk_tlwh, const float* mean, const int* slots, int t, const float* det_tlwh,
                      int n, float* cost, hipStream_t s);
 void launch_fill(float* p, float v, size_t n, hipStream_t s);
-void launch_normalize_rows(const float* src, float* dst, int n, int dim, hipStream_t s);
+void launch_normalize_rows(const float* src, float* dst, int n, int dim, hipStream_t s, const int* n_dev = nullptr);
 // galleries: base [slots][gmax][dim]; per row t: slot index + valid length; det_n normalised rows.
 void launch_cosine_min(const float* gal, const int* slots, const int* glen, int t, int gmax, int dim,
                        const float* det_n, const unsigned char* has_feat, int n, float* cost, hipStream_t s);

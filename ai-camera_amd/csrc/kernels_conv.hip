@@ -44,6 +44,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     const int r0 = t >> 2;       // first tile row this thread stages
     const int m0 = blockIdx.x * BM;
     const int n0 = blockIdx.y * BN;
+    const int M = a.n_dev ? min(a.M, a.n_dev[0] * (a.Ho * a.Wo)) : a.M;
+    if (m0 >= M) return;
 
     const T* __restrict__ xg = reinterpret_cast<const T*>(a.x);
     const T* __restrict__ wg = reinterpret_cast<const T*>(a.w);
@@ -55,7 +57,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < A_PER; ++i) {
         const int m = m0 + r0 + 64 * i;
-        if (m < a.M) {
+        if (m < M) {
             const int img = m / HoWo;
             const int rem = m - img * HoWo;
             const int oh = rem / a.Wo;
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         const int m = m0 + (wm * MT + i) * 16 + r;
-        if (m >= a.M) continue;
+        if (m >= M) continue;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const int n = n0 + (wn * NT + j) * 16 + 4 * q;
@@ -244,6 +246,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const Conv
     xcd_tile_xy(a.xcd_map, tbx, tby);
     const int m0 = tbx * BM;
     const int n0 = tby * BN;
+    const int M = a.n_dev ? min(a.M, a.n_dev[0] * (a.Ho * a.Wo)) : a.M;     // device-side item count: the grid was sized for a bound
+    if (m0 >= M) return;
 
     const T* __restrict__ xg = reinterpret_cast<const T*>(a.x);
     const T* __restrict__ wg = reinterpret_cast<const T*>(a.w);
@@ -259,7 +263,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const Conv
         const int m = m0 + r0 + RP * i;
         unsigned mk = 0;
         const T* rp = zero;
-        if (m < a.M) {
+        if (m < M) {
             int img, rem, oh, ow;
             fast_divmod(m, HoWo, inv_howo, img, rem);
             fast_divmod(rem, a.Wo, inv_wo, oh, ow);
@@ -320,13 +324,14 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const Conv
             winc[j] = okr ? BKE : 0;
         }
         int tap = 0, kh = 0, kw = 0, cc = 0;
+        const bool cmaj = a.k_chunk_major != 0;    // K walked (channel chunk, tap): the source pointers are rebuilt every step
         auto set_tap = [&] {
-            const long toff = ((long)kh * a.W + kw) * a.x_cs + kc * CH;
+            const long toff = ((long)kh * a.W + kw) * a.x_cs + kc * CH + (cmaj ? cc * BKE : 0);
 #pragma unroll
             for (int i = 0; i < A_PER; ++i) {
-                const bool ok = tap < ntap && ((vmask[i] >> (tap & 31)) & 1u);
+                const bool ok = tap < ntap && cc < csteps && ((vmask[i] >> (tap & 31)) & 1u);
                 aptr[i] = ok ? rowp[i] + toff : zero;
-                ainc[i] = ok ? BKE : 0;
+                ainc[i] = (ok && !cmaj) ? BKE : 0;
             }
         };
         set_tap();
@@ -336,6 +341,20 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const Conv
             for (int i = 0; i < A_PER; ++i) {
                 __builtin_amdgcn_global_load_lds((gptr_t)aptr[i], (lptr_t)(sbase + i * (RP * 64)), 16, 0, 0);
                 aptr[i] += ainc[i];
+            }
+            if (cmaj) {
+                const int koff = tap * a.Cin + cc * BKE;
+#pragma unroll
+                for (int j = 0; j < B_PER; ++j) {
+                    const T* src = (winc[j] && cc < csteps) ? wptr[j] + koff : zero;
+                    asm volatile("" : "+v"(src));
+                    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sbase + BM * 64 + j * (RP * 64)), 16, 0, 0);
+                }
+                ++tap;
+                if (++kw == a.KW) { kw = 0; ++kh; }
+                if (tap == ntap) { tap = 0, kh = 0, kw = 0; ++cc; }
+                set_tap();
+                return;
             }
 #pragma unroll
             for (int j = 0; j < B_PER; ++j) {
@@ -420,7 +439,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const Conv
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         const int m = m0 + (wm * MT + i) * 16 + r;
-        mrow[i] = m < a.M ? m : -1;
+        mrow[i] = m < M ? m : -1;
     }
     if constexpr (TAIL) {
         static_assert(sizeof(T) == 2 && WN == 1, "the tail needs fp16 and a wave that owns every channel of its pixels");
@@ -520,6 +539,8 @@ void launch_conv_igemm(int dtype, const ConvArgs& a0, hipStream_t s) {
     if (a0.M <= 0) return;
     ConvArgs a = a0;
     a.xcd_map = xcd_map_on();
+    static const bool tap_major_everywhere = getenv("AICAM_K_TAP_MAJOR") != nullptr;   // A/B: the pre-round-3 behaviour (batch-dependent bits)
+    a.k_chunk_major = (conv_impl() == 2 && !tap_major_everywhere && conv_pp_patch_shape(dtype, a)) ? 1 : 0;
     if (a.w_tail) {
         AIC_REQUIRE(dtype == AIC_F16 && (a.Cout == 64 || a.Cout == 80) && a.act == 1 && a.res_mode == 0, AIC_ERR_INVALID,
                     "conv with a 1x1 tail: unsupported lead (check conv_tail_supported before setting w_tail)");

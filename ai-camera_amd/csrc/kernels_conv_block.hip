@@ -25,6 +25,7 @@ struct BlockArgs {
     const void* w2; const float* b2;
     const void* zero;
     int x_cs, x_coff, y_cs, y_coff, H, n_img, ipb;
+    const int* n_dev;                       // optional device-side image count (n_img is then the bound the grid was sized for)
 };
 
 __global__ __launch_bounds__(512) void conv3x3_c64_block_kernel(const BlockArgs a) {
@@ -60,7 +61,7 @@ __global__ __launch_bounds__(512) void conv3x3_c64_block_kernel(const BlockArgs 
 
     const int gpi = a.H / 4 + 1;                        // row groups per image: H/4 real ones and the separator
     const int img0 = blockIdx.x * a.ipb;
-    const int n_loc = max(0, min(a.ipb, a.n_img - img0));
+    const int n_loc = max(0, min(a.ipb, (a.n_dev ? min(a.n_img, a.n_dev[0]) : a.n_img) - img0));
     const int S_tot = gpi * n_loc;
 
     // ---- LDS-DMA of row group g (rows 4g .. 4g+3 of this block's stream) into ring slot g mod 5: 17 wave-instructions of
@@ -229,6 +230,7 @@ bool conv_try_c64_block(const ConvArgs& c1, const ConvArgs& c2, hipStream_t s) {
     a.x = c1.x, a.y = c2.y, a.w1 = c1.w, a.b1 = c1.bias, a.w2 = c2.w, a.b2 = c2.bias, a.zero = c1.zero;
     a.x_cs = c1.x_cs, a.x_coff = c1.x_coff, a.y_cs = c2.y_cs, a.y_coff = c2.y_coff, a.H = c1.H;
     a.n_img = c1.M / (c1.H * c1.W);
+    a.n_dev = c1.n_dev;
     // images per block: n_img / 256 = one persistent block per CU, or AICAM_BLK_IPB for shorter-lived blocks (each pays 3 steps
     // of pipeline fill and a weight reload; in exchange the CU takes other streams' waiting blocks in between)
     static const int ipb_env = [] { const char* e = getenv("AICAM_BLK_IPB"); return e ? atoi(e) : 0; }();

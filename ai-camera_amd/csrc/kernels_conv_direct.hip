@@ -146,7 +146,8 @@ static bool try_c16(const ConvArgs& a, hipStream_t s) {
 // Measured (tools/conv_bench.py, 7680 crops): 859 TFLOP/s without / 774 with residual; without stores 1150, with
 // L2-resident input and no stores 1275 -- the remaining gap is the 2 GB of output writes, which do not overlap.
 template <int ACT, int RES>
-__global__ __launch_bounds__(512) void conv3x3_c64_resident_kernel(const ConvArgs a, int n_tiles, int tiles_x, int tiles_y, int nblk) {
+__global__ __launch_bounds__(512) void conv3x3_c64_resident_kernel(const ConvArgs a, int n_tiles_bound, int tiles_x, int tiles_y, int nblk) {
+    const int n_tiles = a.n_dev ? min(n_tiles_bound, a.n_dev[0] * tiles_x * tiles_y) : n_tiles_bound;   // device-side item count
     // nblk = gridDim.x as an argument: read through the dispatch packet it is a scalar load inside the tile loop, and a
     // scalar load in flight makes every compiler-made LDS wait an lgkmcnt(0)
     constexpr int TH = 8, TW = 32, PW = TW + 2, PH = TH + 2, NPIX = PW * PH, NPASS = (NPIX + 63) / 64, NPIXP = NPASS * 64;
@@ -434,6 +435,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(const ConvA
     const int img = bx / tiles_y;
     const int oy0 = ty * TH, ox0 = tx * TW;
     const int n0 = tby * BN;
+    if (a.n_dev && img >= a.n_dev[0]) return;               // device-side item count: the grid was sized for a bound
 
     const T* __restrict__ wg = reinterpret_cast<const T*>(a.w);
     const T* zero = reinterpret_cast<const T*>(a.zero);
@@ -611,6 +613,7 @@ struct StemArgs {
     // fused crop (second stem form only): frames != NULL = the block resamples its crop from the u8 frame itself
     // (_extract_image_crops + preprocess_reid_input, deepsort_tracker.py:143-159 / image_processing.py:105-138) instead of reading x
     const uint8_t* frames; int fh, fw; const float* boxes; const int* frame_of; int* valid;
+    const int* n_dev;                // optional device-side crop count (n is then the bound the grid was sized for)
 };
 
 __global__ __launch_bounds__(256) void reid_stem_pool_kernel(const StemArgs a) {
@@ -624,6 +627,7 @@ __global__ __launch_bounds__(256) void reid_stem_pool_kernel(const StemArgs a) {
     const int Hp = a.H / 2, Wp = a.W / 2;
     const int groups = Hp / PT;
     const int img = blockIdx.x / groups, rg = blockIdx.x - img * groups;
+    if (a.n_dev && img >= a.n_dev[0]) return;
     const int oy0 = rg * PT, cr0 = 2 * oy0 - 1, ir0 = cr0 - 1;
     const half_t* xg = reinterpret_cast<const half_t*>(a.x) + (size_t)img * a.H * a.W * 8;
 
@@ -731,6 +735,7 @@ __global__ __launch_bounds__(512) void reid_stem_pool2_kernel(const StemArgs a) 
     const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6), r = lane & 15, q = lane >> 4;
     const int H = a.H, Hp = H / 2, Wp = CW / 2, rows_per_wave = Hp / 8;
     const int img = blockIdx.x;
+    if (a.n_dev && img >= a.n_dev[0]) return;               // device-side crop count: the grid was sized for a bound
     const half_t* xg = reinterpret_cast<const half_t*>(a.x) + (size_t)img * H * CW * a.in_stride;
 
     if (a.frames == nullptr) {
@@ -896,9 +901,9 @@ bool reid_stem2_usable(int H, int W) {
 }
 
 void launch_reid_stem_pool(const void* x, const void* w, const float* bias, void* y, int n, int H, int W, int Kp, int y_cs,
-                           int y_coff, int in_stride, hipStream_t s, const CropSrc* crop) {
+                           int y_coff, int in_stride, hipStream_t s, const CropSrc* crop, const int* n_dev) {
     if (n <= 0) return;
-    StemArgs a{x, w, bias, y, n, H, W, Kp, y_cs, y_coff, in_stride, nullptr, 0, 0, nullptr, nullptr, nullptr};
+    StemArgs a{x, w, bias, y, n, H, W, Kp, y_cs, y_coff, in_stride, nullptr, 0, 0, nullptr, nullptr, nullptr, n_dev};
     if (crop && crop->frames) {
         AIC_REQUIRE(reid_stem2_usable(H, W) && H <= 256 - 64, AIC_ERR_INVALID, "fused crop needs the second stem form");
         a.frames = crop->frames, a.fh = crop->fh, a.fw = crop->fw, a.boxes = crop->boxes, a.frame_of = crop->frame_of, a.valid = crop->valid;

@@ -50,6 +50,8 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(const ConvArgs a) {
     const int m0 = tbx * BM;
     const int n0 = tby * BN;
     const bool late = wv >= 4;
+    const int M = a.n_dev ? min(a.M, a.n_dev[0] * (a.Ho * a.Wo)) : a.M;     // device-side item count: the grid was sized for a bound
+    if (m0 >= M) return;
 
     const T* __restrict__ xg = reinterpret_cast<const T*>(a.x);
     const T* __restrict__ wg = reinterpret_cast<const T*>(a.w);
@@ -65,7 +67,7 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(const ConvArgs a) {
         const int m = m0 + r0 + RP * i;
         unsigned mk = 0;
         const T* rp = zero;
-        if (m < a.M) {
+        if (m < M) {
             int img, rem, oh, ow;
             fast_divmod(m, HoWo, inv_howo, img, rem);
             fast_divmod(rem, a.Wo, inv_wo, oh, ow);
@@ -112,13 +114,14 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(const ConvArgs a) {
         winc[j] = okr ? BKE : 0;
     }
     int tap = 0, kh = 0, kw = 0, cc = 0;
+    const bool cmaj = a.k_chunk_major != 0;    // K walked (channel chunk, tap): the source pointers are rebuilt every step
     auto set_tap = [&] {
-        const long toff = ((long)kh * a.W + kw) * a.x_cs + kc * CH;
+        const long toff = ((long)kh * a.W + kw) * a.x_cs + kc * CH + (cmaj ? cc * BKE : 0);
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
-            const bool ok = tap < ntap && ((vmask[i] >> (tap & 31)) & 1u);
+            const bool ok = tap < ntap && cc < csteps && ((vmask[i] >> (tap & 31)) & 1u);
             aptr[i] = ok ? rowp[i] + toff : zero;
-            ainc[i] = ok ? BKE : 0;
+            ainc[i] = (ok && !cmaj) ? BKE : 0;
         }
     };
     set_tap();
@@ -128,6 +131,20 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(const ConvArgs a) {
         for (int i = 0; i < A_PER; ++i) {
             __builtin_amdgcn_global_load_lds((gptr_t)aptr[i], (lptr_t)(sbase + i * (RP * 64)), 16, 0, 0);
             aptr[i] += ainc[i];
+        }
+        if (cmaj) {
+            const int koff = tap * a.Cin + cc * BKE;
+#pragma unroll
+            for (int j = 0; j < B_PER; ++j) {
+                const T* src = (winc[j] && cc < csteps) ? wptr[j] + koff : zero;
+                asm volatile("" : "+v"(src));
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sbase + BM * 64 + j * (RP * 64)), 16, 0, 0);
+            }
+            ++tap;
+            if (++kw == a.KW) { kw = 0; ++kh; }
+            if (tap == ntap) { tap = 0, kh = 0, kw = 0; ++cc; }
+            set_tap();
+            return;
         }
 #pragma unroll
         for (int j = 0; j < B_PER; ++j) {
@@ -181,7 +198,7 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(const ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         const int m = m0 + (wm * MT + i) * 16 + r;
-        mrow[i] = m < a.M ? m : -1;
+        mrow[i] = m < M ? m : -1;
     }
     epilogue_dispatch<T, MT, NT, true>(a, acc, mrow, n0 + wn * NT * 16, q);
     if (g_pp_times_on) { wait_vmcnt<0>(); PP_STAMP(3); }
@@ -291,7 +308,8 @@ __global__ __launch_bounds__(512) void conv3x3_pp_patch_kernel(const ConvArgs a,
     const int img0 = (bx / tiles_y) * NI;
     const int oy0 = ty * TH, ox0 = tx * TW;
     const int n0 = tby * BN;
-    const int n_img = a.M / (a.Ho * a.Wo);
+    const int n_img = a.n_dev ? min(a.M / (a.Ho * a.Wo), a.n_dev[0]) : a.M / (a.Ho * a.Wo);     // device-side item count: the grid was sized for a bound
+    if (img0 >= n_img) return;
 
     const T* __restrict__ xg = reinterpret_cast<const T*>(a.x);
     const T* __restrict__ wg = reinterpret_cast<const T*>(a.w);
@@ -469,20 +487,37 @@ static bool launch_pp_patch(const ConvArgs& a, hipStream_t s) {
 }
 
 // 3x3/s1/p1 layers whose map tiles exactly: pick the tile by map shape and Cout (ReID layer1..4 shapes and their multiples).
+// bit 0: Cout 64 (slower than the 4-wave patch kernel: 16 MFMAs per segment), 1: Cout 128, 2: Cout % 256, 3: deeper ring (no gain)
+static int ppp_mode() {
+    static const int mode = [] { const char* e = getenv("AICAM_PPP"); return e ? atoi(e) : 6; }();
+    return mode;
+}
+// The layer SHAPES this kernel takes (a property of the graph, not of the batch): 1 = Cout 64 tile, 2 = Cout 128, 3 = Cout % 256 on
+// 16 x 8 tiles, 4 = on 8 x 4 tiles; 0 = not one of them.  Such a layer is walked chunk-major by EVERY conv kernel (ConvArgs::k_chunk_major).
+template <typename T>
+static int pp_patch_shape(const ConvArgs& a) {
+    constexpr int BKE = 64 / (int)sizeof(T);
+    const int mode = ppp_mode();
+    if (!mode || a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.Cin % (2 * BKE) || a.Ho != a.H || a.Wo != a.W) return 0;
+    const int c = a.Cout;
+    if (c == 64 && (mode & 1)) return (a.H % 16 == 0 && a.W % 32 == 0) ? 1 : 0;
+    if (c == 128 && (mode & 2)) return (a.H % 32 == 0 && a.W % 16 == 0) ? 2 : 0;
+    if (c % 256 == 0 && (mode & 4)) return (a.H % 16 == 0 && a.W % 8 == 0) ? 3 : ((a.H % 8 == 0 && a.W % 4 == 0) ? 4 : 0);
+    return 0;
+}
+
 template <typename T>
 static bool try_pp_patch(const ConvArgs& a, hipStream_t s) {
-    // bit 0: Cout 64 (slower than the 4-wave patch kernel: 16 MFMAs per segment), 1: Cout 128, 2: Cout % 256, 3: deeper ring (no gain)
-    static const int mode = [] { const char* e = getenv("AICAM_PPP"); return e ? atoi(e) : 6; }();
     static const int pp_min = [] { const char* e = getenv("AICAM_PP_MIN"); return e ? atoi(e) : 200; }();
-    constexpr int BKE = 64 / (int)sizeof(T);
-    if (!mode || a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.Cin % (2 * BKE)) return false;
+    const int shape = pp_patch_shape<T>(a);
+    if (!shape) return false;
     if ((long)a.M * a.x_cs >= (1l << 31)) return false;                       // 32-bit element offsets inside the kernel
     const int c = a.Cout;
-    const bool deep = mode & 8;
-    if (c == 64 && (mode & 1) && a.M / 512 >= pp_min) return deep ? launch_pp_patch<T, 4, 4, 8, 1, 16, 32, 6>(a, s) : launch_pp_patch<T, 4, 4, 8, 1, 16, 32, 4>(a, s);
-    if (c == 128 && (mode & 2) && a.M / 512 >= pp_min) return deep ? launch_pp_patch<T, 8, 4, 4, 2, 32, 16, 6>(a, s) : launch_pp_patch<T, 8, 4, 4, 2, 32, 16, 4>(a, s);
-    if (c % 256 == 0 && (mode & 4) && (long)(a.M / 256) * (c / 256) >= pp_min) {
-        if (a.H % 16 == 0 && a.W % 8 == 0) return deep ? launch_pp_patch<T, 8, 4, 2, 4, 16, 8, 6>(a, s) : launch_pp_patch<T, 8, 4, 2, 4, 16, 8, 4>(a, s);
+    const bool deep = ppp_mode() & 8;
+    if (shape == 1 && a.M / 512 >= pp_min) return deep ? launch_pp_patch<T, 4, 4, 8, 1, 16, 32, 6>(a, s) : launch_pp_patch<T, 4, 4, 8, 1, 16, 32, 4>(a, s);
+    if (shape == 2 && a.M / 512 >= pp_min) return deep ? launch_pp_patch<T, 8, 4, 4, 2, 32, 16, 6>(a, s) : launch_pp_patch<T, 8, 4, 4, 2, 32, 16, 4>(a, s);
+    if (shape >= 3 && (long)(a.M / 256) * (c / 256) >= pp_min) {
+        if (shape == 3) return deep ? launch_pp_patch<T, 8, 4, 2, 4, 16, 8, 6>(a, s) : launch_pp_patch<T, 8, 4, 2, 4, 16, 8, 4>(a, s);
         return deep ? launch_pp_patch<T, 8, 4, 2, 4, 8, 4, 5>(a, s) : launch_pp_patch<T, 8, 4, 2, 4, 8, 4, 4>(a, s);
     }
     return false;
@@ -491,6 +526,10 @@ static bool try_pp_patch(const ConvArgs& a, hipStream_t s) {
 
 bool conv_try_pp_patch(int dtype, const ConvArgs& a, hipStream_t s) {
     return dtype == AIC_F16 ? try_pp_patch<half_t>(a, s) : try_pp_patch<float>(a, s);
+}
+
+bool conv_pp_patch_shape(int dtype, const ConvArgs& a) {
+    return (dtype == AIC_F16 ? pp_patch_shape<half_t>(a) : pp_patch_shape<float>(a)) != 0;
 }
 
 // Ping-pong kernels (one block per CU) where the K loop is long enough to amortise the tile's prologue/epilogue:

@@ -226,6 +226,64 @@ __global__ __launch_bounds__(NMS_THREADS) void select_sort_nms_kernel(const DetA
     if (t == 0) a.num_dets[img] = min(nk, a.max_det);
 }
 
+// ---- the tracker's detection filter on the device (deepsort_tracker.py:88-101): keep detections with conf >= min_confidence
+// whose class is tracked, IN ORDER, and lay the survivors of a launch group out as the arrays crop + ReID + the association
+// epochs consume -- all in HBM, nothing crosses to the host between NMS and ReID.
+//   pass 1 (one wave per frame): rank of every kept detection inside its frame (ballot prefix), count per frame;
+//   pass 2 (one wave per frame): first row of the frame = sum of the counts before it (a wave reduction over <= 512 values),
+//          then one thread per kept detection writes xyxy (the crop box, :148), tlwh (:185-186), conf, class, frame index.
+__global__ __launch_bounds__(64) void det_filter_rank_kernel(const DetFilterArgs a) {
+    const int f = blockIdx.x, lane = threadIdx.x;
+    const int nd = min(a.num_dets[f], a.max_det);
+    int cnt = 0;
+    for (int i0 = 0; i0 < nd; i0 += 64) {
+        const int i = i0 + lane;
+        bool keep = false;
+        if (i < nd) {
+            const float sc = a.scores[(size_t)f * a.max_det + i];
+            const int c = a.labels[(size_t)f * a.max_det + i];
+            keep = sc >= a.min_conf && c >= 0 && c < 128 && ((a.mask[c >> 6] >> (c & 63)) & 1ull);
+        }
+        const unsigned long long bal = __ballot(keep);
+        if (i < nd) a.rank[(size_t)f * a.max_det + i] = keep ? cnt + __popcll(bal & ((1ull << lane) - 1ull)) : -1;
+        cnt += __popcll(bal);
+    }
+    if (lane == 0) a.frame_n[f] = cnt;
+}
+
+__global__ __launch_bounds__(64) void det_filter_scatter_kernel(const DetFilterArgs a) {
+    const int f = blockIdx.x, lane = threadIdx.x;
+    int before = 0;
+    for (int g = lane; g < f; g += 64) before += a.frame_n[g];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o);
+    const int mine = a.frame_n[f];
+    if (lane == 0) {
+        a.frame_d0[f] = before;
+        if (f == a.batch - 1) { a.total[0] = min(before + mine, a.cap); a.total[1] = before + mine; }   // [0]: rows present, [1]: rows the filter passed
+    }
+    const int nd = min(a.num_dets[f], a.max_det);
+    for (int i = lane; i < nd; i += 64) {
+        const int rk = a.rank[(size_t)f * a.max_det + i];
+        const int row = before + rk;
+        if (rk < 0 || row >= a.cap) continue;
+        const float4 b = *reinterpret_cast<const float4*>(a.boxes + ((size_t)f * a.max_det + i) * 4);
+        *reinterpret_cast<float4*>(a.xyxy + (size_t)row * 4) = b;
+        *reinterpret_cast<float4*>(a.tlwh + (size_t)row * 4) = make_float4(b.x, b.y, b.z - b.x, b.w - b.y);
+        a.conf[row] = a.scores[(size_t)f * a.max_det + i];
+        a.cls[row] = a.labels[(size_t)f * a.max_det + i];
+        a.frame_of[row] = f;
+    }
+}
+
+void launch_det_filter(const DetFilterArgs& a, hipStream_t s) {
+    if (a.batch <= 0) return;
+    hipLaunchKernelGGL(det_filter_rank_kernel, dim3(a.batch), dim3(64), 0, s, a);
+    KCHECK();
+    hipLaunchKernelGGL(det_filter_scatter_kernel, dim3(a.batch), dim3(64), 0, s, a);
+    KCHECK();
+}
+
 void launch_decode(const DetArgs& a, hipStream_t s) {
     const long tot = (long)a.batch * a.n_anchors;
     if (tot <= 0) return;

@@ -144,7 +144,7 @@ __global__ void maxpool3s2_kernel(const EltArgs a) {
     constexpr int VN = Vec<T>::N;
     const int cv = a.c / VN;
     const int oh = (a.h + 2 - 3) / 2 + 1, ow = (a.w + 2 - 3) / 2 + 1;
-    const long total = (long)a.n * oh * ow * cv;
+    const long total = (long)(a.n_dev ? min(a.n, a.n_dev[0]) : a.n) * oh * ow * cv;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
     const int cc = (int)(idx % cv);
@@ -173,7 +173,7 @@ __global__ void maxpool3s2_kernel(const EltArgs a) {
 template <typename T>
 __global__ void avgpool_kernel(const EltArgs a) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long)a.n * a.c) return;
+    if (idx >= (long)(a.n_dev ? min(a.n, a.n_dev[0]) : a.n) * a.c) return;
     const int ch = (int)(idx % a.c);
     const int img = (int)(idx / a.c);
     const T* src = reinterpret_cast<const T*>(a.src) + (size_t)img * a.h * a.w * a.s_cs + a.s_coff + ch;
@@ -188,7 +188,7 @@ template <typename T>
 __global__ void l2norm_kernel(const EltArgs a) {
     const int lane = threadIdx.x & 63;
     const int item = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (item >= a.n) return;
+    if (item >= (a.n_dev ? min(a.n, a.n_dev[0]) : a.n)) return;
     const T* src = reinterpret_cast<const T*>(a.src) + (size_t)item * a.s_cs + a.s_coff;
     float ss = 0.f;
     for (int c = lane; c < a.c; c += 64) { const float v = (float)src[c]; ss += v * v; }

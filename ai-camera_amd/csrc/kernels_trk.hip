@@ -186,9 +186,9 @@ __global__ void fill_kernel(float* p, float v, size_t n) {
 }
 
 // rows / max(||row||, 1e-7)  (matching.py:126-130); one wavefront per row.
-__global__ void normalize_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int n, int dim) {
+__global__ void normalize_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int n, int dim, const int* __restrict__ n_dev) {
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (row >= n) return;
+    if (row >= (n_dev ? min(n, n_dev[0]) : n)) return;
     const int lane = threadIdx.x & 63;
     const float* s = src + (size_t)row * dim;
     float ss = 0.f;
@@ -779,9 +779,9 @@ void launch_fill(float* p, float v, size_t n, hipStream_t s) {
     hipLaunchKernelGGL(fill_kernel, dim3(ceil_div((long)n, 256)), dim3(256), 0, s, p, v, n);
     KCHECK();
 }
-void launch_normalize_rows(const float* src, float* dst, int n, int dim, hipStream_t s) {
+void launch_normalize_rows(const float* src, float* dst, int n, int dim, hipStream_t s, const int* n_dev) {
     if (n <= 0) return;
-    hipLaunchKernelGGL(normalize_rows_kernel, dim3(ceil_div(n, 4)), dim3(256), 0, s, src, dst, n, dim);
+    hipLaunchKernelGGL(normalize_rows_kernel, dim3(ceil_div(n, 4)), dim3(256), 0, s, src, dst, n, dim, n_dev);
     KCHECK();
 }
 void launch_cosine_min(const float* gal, const int* slots, const int* glen, int t, int gmax, int dim, const float* det_n,

@@ -652,6 +652,52 @@ namespace {
 // Matched pairs are entered into mdet / mtrk. *err != 0 on an LSAP failure.
 struct FrameCosts { const float* app; const float* maha; const float* iou; float* sub_lds; int sub_floats; };
 
+// The assignment read off the sub-matrix when it is the ONLY optimum (block-wide; true = matches entered, nothing left to do).
+// Take the short side's lines (rows when nr <= nc, else columns): R lines of C entries, every line must be assigned, to distinct
+// entries.  A line whose minimum is above the threshold holds the clamp value everywhere (linear_assignment.py:58): whatever it
+// gets is rejected at :76 and any free entry costs it the same.  If every OTHER line has a strict minimum (below its runner-up)
+// and those minima sit in distinct places, then sum-of-line-minima is attained, and only by assignments that put each such line
+// on its minimum: SciPy's answer restricted to the accepted pairs is exactly this, its tie rules never come into play.  (The
+// solver's arithmetic is exact here: entries are fp32 values below 1 on a 2^-27 grid, sums of <= 512 of them fit a double.)
+// One ordered scan per line instead of ~R augmenting paths on one wavefront; anything else falls through to the LSAP.
+__device__ bool unique_optimum(const Lds& L, const float* sub, const int* cols, int nr, int nc, float maxd) {
+    const int tid = threadIdx.x;
+    const bool tall = nr > nc;
+    const int R = tall ? nc : nr, C = tall ? nr : nc;
+    int* cnt = L.pred;                                          // scratch of the LSAP, free here
+    for (int c = tid; c < C; c += BT) cnt[c] = 0;
+    float m1 = __builtin_inff(), m2 = __builtin_inff();
+    int arg = -1;
+    if (tid < R) {
+        const float* p = tall ? sub + tid : sub + (size_t)tid * nc;
+        const int step = tall ? nc : 1;
+        for (int c0 = 0; c0 < C; c0 += 8) {                     // eight independent LDS reads in flight, then the ordered compare chain
+            float x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = p[(size_t)min(c0 + u, C - 1) * step];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float xv = c0 + u < C ? x[u] : __builtin_inff();
+                if (xv < m1) { m2 = m1; m1 = xv; arg = c0 + u; }
+                else if (xv < m2) m2 = xv;
+            }
+        }
+    }
+    __syncthreads();
+    const bool live = tid < R && m1 <= maxd;
+    if (live) atomicAdd(&cnt[arg], 1);
+    __syncthreads();
+    const int ok = !live || (m1 < m2 && cnt[arg] == 1);
+    if (!__syncthreads_and(ok)) return false;
+    if (live) {
+        const int r = tall ? arg : tid, c = tall ? tid : arg;
+        L.mdet[L.rows[r]] = cols[c];
+        L.mtrk[cols[c]] = L.rows[r];
+    }
+    __syncthreads();
+    return true;
+}
+
 __device__ void match_block(const Lds& L, const EpochArgs& a, const FrameCosts& fc, const int* cols, int nr, int nc, int n, bool stage2, int* err) {
     const float* app = fc.app;
     const float* maha = fc.maha;
@@ -667,6 +713,11 @@ __device__ void match_block(const Lds& L, const EpochArgs& a, const FrameCosts& 
     }
     __threadfence_block();
     __syncthreads();
+    if (!a.prm.no_fast && unique_optimum(L, sub, cols, nr, nc, maxd)) {
+        if (threadIdx.x == 0) L.wcnt[NW + 1] += 1;
+        return;
+    }
+    if (threadIdx.x == 0) L.wcnt[NW + 2] += 1;
     if (threadIdx.x < 64) {
         const int side = max(nr, nc);
         const bool ok = side <= 64 ? lsap_wave64(sub, nr, nc, L, threadIdx.x)
@@ -723,7 +774,7 @@ __global__ __launch_bounds__(TRK_DEV_TMAX) void trk_epoch_kernel(EpochArgs a) {
 
     // ---- load the track table (uniform copies of the scalars in registers)
     int T = a.hdr->n_tracks, next_id = a.hdr->next_id, nfree = a.hdr->n_free;
-    if (tid == 0) { s_err = 0; if (a.out.dbg_match) a.out.dbg_match[0] = 0; }
+    if (tid == 0) { s_err = 0; L.wcnt[NW + 1] = 0; L.wcnt[NW + 2] = 0; if (a.out.dbg_match && !a.out.dbg_stride) a.out.dbg_match[0] = 0; }
     if (tid < T) {
         const DevTrack t = a.trk[tid];
         L.id[tid] = t.id, L.state[tid] = t.state, L.hits[tid] = t.hits, L.age[tid] = t.age, L.tsu[tid] = t.tsu, L.cls[tid] = t.cls;
@@ -757,6 +808,7 @@ __global__ __launch_bounds__(TRK_DEV_TMAX) void trk_epoch_kernel(EpochArgs a) {
             L.mtrk[tid] = -1;
             L.und[tid] = tid;
         }
+        if (tid == 0 && a.out.dbg_match && a.out.dbg_stride) a.out.dbg_match[(size_t)f * a.out.dbg_stride] = 0;
         if (tid < T) { L.age[tid] += 1; L.tsu[tid] += 1; L.mdet[tid] = -1; }
         for (int t = wv; t < T; t += NW) {
             const int slot = L.slot[t];
@@ -885,9 +937,10 @@ __global__ __launch_bounds__(TRK_DEV_TMAX) void trk_epoch_kernel(EpochArgs a) {
                 L.conf[tid] = L.dconf[det];
                 L.cls[tid] = L.dcls[det];
                 if (L.state[tid] == 1 && L.hits[tid] >= a.prm.n_init) L.state[tid] = 2;
-                if (a.out.dbg_match && fi == a.k - 1) {
-                    const int mi = atomicAdd(&a.out.dbg_match[0], 1);
-                    a.out.dbg_match[1 + 2 * mi] = L.id[tid], a.out.dbg_match[2 + 2 * mi] = det;
+                if (a.out.dbg_match && (a.out.dbg_stride || fi == a.k - 1)) {
+                    int* dm = a.out.dbg_match + (size_t)f * a.out.dbg_stride;
+                    const int mi = atomicAdd(&dm[0], 1);
+                    dm[1 + 2 * mi] = L.id[tid], dm[2 + 2 * mi] = det;
                 }
             } else {                                               // Track.mark_missed, track.py:106-119
                 if (L.state[tid] == 1) L.state[tid] = 3;
@@ -1057,6 +1110,7 @@ __global__ __launch_bounds__(TRK_DEV_TMAX) void trk_epoch_kernel(EpochArgs a) {
     if (tid == 0) {
         a.hdr->n_tracks = T, a.hdr->next_id = next_id, a.hdr->n_free = nfree;
         a.hdr->err = s_err, a.hdr->err_frame = err_frame, a.hdr->frames_done = fi;
+        a.hdr->n_fast += L.wcnt[NW + 1], a.hdr->n_lsap += L.wcnt[NW + 2];
     }
 }
 
@@ -1069,7 +1123,7 @@ __global__ __launch_bounds__(TRK_DEV_TMAX) void trk_cascade_test_kernel(EpochArg
     __shared__ int s_err;
     const Lds L = lds_carve(smem, a.prm.cap, a.nmax, lds_bytes);
     const int tid = threadIdx.x;
-    if (tid == 0) s_err = 0;
+    if (tid == 0) { s_err = 0; L.wcnt[NW + 1] = 0; L.wcnt[NW + 2] = 0; }
     const size_t stride = (size_t)TRK_DEV_TMAX * TRK_DEV_NMAX;
     const FrameCosts fc{a.scr.cost, a.scr.cost + stride, a.scr.cost + 2 * stride, L.arena, L.arena_floats};
     if (tid < T) { L.state[tid] = state[tid]; L.tsu[tid] = tsu[tid]; L.mdet[tid] = -1; }
@@ -1099,7 +1153,7 @@ __global__ __launch_bounds__(TRK_DEV_TMAX) void trk_cascade_test_kernel(EpochArg
     }
     __syncthreads();
     if (tid < T) out_mdet[tid] = L.mdet[tid];
-    if (tid == 0) *out_err = s_err;
+    if (tid == 0) { out_err[0] = s_err; out_err[1] = L.wcnt[NW + 1]; out_err[2] = L.wcnt[NW + 2]; }
 }
 
 // ------------------------------------------------------------------------------------------------ cross-camera gallery shard

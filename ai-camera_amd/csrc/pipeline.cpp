@@ -47,8 +47,16 @@ struct Chunk {
     size_t m_n = 0, m_d0 = 0, m_tlwh = 0, m_conf = 0, m_cls = 0, m_bytes = 0;   // offsets into h_meta / d_meta
     PinBuf<int> h_numdets, h_labels;
     PinBuf<float> h_detboxes, h_scores;
+    // detection filter on the device (inject = 0): the group's surviving detections are compacted in HBM by det_filter_*_kernel,
+    // the host only ever sees the per-frame counts (for planning the association epochs), behind ev_det, on the consumer thread
+    bool filt_dev = false;           // this group went through the device filter
+    int f_cap = 0;                   // rows the arrays below hold (batch * max_det: the filter cannot overflow them)
+    int reid_rows = 0;               // rows the producer's (bounded) ReID round covered
+    DevBuf<int> d_rank, d_fn, d_fd0, d_total, d_fcls;
+    DevBuf<float> d_ftlwh, d_fconf;
+    PinBuf<int> h_fn, h_fd0, h_total;
     std::vector<FrameDets> dets;
-    hipEvent_t done = nullptr, ev_yolo = nullptr, ev_det = nullptr, ev_reid = nullptr;
+    hipEvent_t done = nullptr, ev_yolo = nullptr, ev_det = nullptr, ev_reid = nullptr, ev_extra = nullptr;
     hipEvent_t t_begin = nullptr, t_end = nullptr, t_yolo = nullptr;   // AICAM_PIPE_TIMES: GPU timeline of the group on the main stream
 };
 
@@ -83,10 +91,36 @@ struct Pipeline {
     // context's PREVIOUS group (k - NCK) was released, or the count at the start of the call for the first NCK groups.  The same
     // frames then always take the same path (both give the same rows; a moving choice made a defect of one of them look random).
     bool use_device(int n_max, int tracks_before) const {
-        if (!dev_assoc || !trk.dev_capable()) return false;
+        if (!dev_assoc || !trk.dev_capable() || n_max > TRK_DEV_NMAX) return false;   // beyond 512 detections in a frame only the host chain applies (it takes 1536)
         return dev_assoc == 2 || (n_max <= 64 && tracks_before + n_max / 2 <= 64) || x_shard[0] != nullptr;
     }
+    // configs[4]: gallery shard of this stream on the tracker stream, ordered behind the group's association; every launch group
+    // counts, whichever path associated it (the ranks' exchange counts must agree).  Double-buffered: the stream's association only
+    // waits when the consumer is TWO exchanges behind, and then with a bound -- a stuck peer ends the run loudly instead of hanging it.
+    void pack_shard_if_due(hipStream_t s) {
+        if (!x_shard[0] || (x_groups++ % x_every) != 0) return;
+        std::unique_lock<std::mutex> lk(x_mu);
+        static const int wait_s = [] { const char* e = getenv("AICAM_XCHG_WAIT_S"); return e ? std::max(1, atoi(e)) : 60; }();
+        const bool ok = x_cv.wait_for(lk, std::chrono::seconds(wait_s), [&] { return x_done >= x_packed - 1; });   // the buffer's previous exchange has been consumed
+        AIC_REQUIRE(ok, AIC_ERR_RUNTIME, "gallery exchange: the consumer has not released a shard buffer for " + std::to_string(wait_s) +
+                                             " s (a peer rank is stuck or gone)");
+        trk.to_device();                                       // (a group associated on the host: the table goes up for the pack)
+        const int b = (int)(x_packed & 1);
+        launch_gallery_shard(trk.tbl_hdr(), trk.tbl_trk(), trk.d_gal_n.p, trk.gmax, trk.dim, x_shard[b], x_tmax, s);
+        HIP_CHECK(hipEventRecord(ev_shard[b], s));
+        x_packed += 1;
+        lk.unlock();
+        x_cv.notify_all();
+    }
     bool taper = getenv("AICAM_NO_TAPER") == nullptr;   // aic_pipeline_option("taper")
+    // inject = 0: the tracker's confidence / class filter (deepsort_tracker.py:88-101) runs on the device behind NMS and ReID is
+    // launched for a bound with the count read on the device -- no host synchronisation between YOLO and ReID.  0 = the filter on
+    // the host (one hipEventSynchronize per launch group on the producer thread).  aic_pipeline_option("device_filter").
+    // Needs the fp16 engine's fused crop + stem (the crop list is read where it was written, in HBM); other engines use the host filter.
+    int dev_filter = getenv("AICAM_HOST_FILTER") ? 0 : 1;
+    std::mutex reid_mu;              // the ReID engine's host-side launch state: producer (stage A) and consumer (overflow rounds)
+    long n_overflow_rounds = 0;      // extra ReID rounds the consumer launched: groups whose crops outnumbered the engine's max_items
+    long n_filter_dev_groups = 0, n_filter_host_groups = 0;
     // configs[4]: cross-camera gallery exchange. The pipeline packs a shard of the stream's confirmed tracks on
     // the tracker stream every x_every launch groups; a consumer thread (ai-camera_amd/distributed.py) all-gathers it over
     // RCCL on the exchange stream. Double-buffered: the pipeline only ever waits if the consumer is two exchanges behind.
@@ -148,6 +182,7 @@ struct Pipeline {
             HIP_CHECK(hipEventCreateWithFlags(&c.ev_yolo, hipEventDisableTiming));
             HIP_CHECK(hipEventCreateWithFlags(&c.ev_det, hipEventDisableTiming));
             HIP_CHECK(hipEventCreateWithFlags(&c.ev_reid, hipEventDisableTiming));
+            HIP_CHECK(hipEventCreateWithFlags(&c.ev_extra, hipEventDisableTiming));
         }
     }
     ~Pipeline() {
@@ -158,6 +193,7 @@ struct Pipeline {
             if (c.ev_yolo) (void)hipEventDestroy(c.ev_yolo);
             if (c.ev_det) (void)hipEventDestroy(c.ev_det);
             if (c.ev_reid) (void)hipEventDestroy(c.ev_reid);
+            if (c.ev_extra) (void)hipEventDestroy(c.ev_extra);
         }
     }
 
@@ -227,8 +263,18 @@ struct Pipeline {
         HIP_CHECK(hipMemcpyAsync(c.h_detboxes.p, yolo->d_out_boxes_orig.p, (size_t)frames * prm.max_det * 16, hipMemcpyDeviceToHost, sd));
         HIP_CHECK(hipMemcpyAsync(c.h_scores.p, yolo->d_out_scores.p, (size_t)frames * prm.max_det * 4, hipMemcpyDeviceToHost, sd));
         HIP_CHECK(hipMemcpyAsync(c.h_labels.p, yolo->d_out_labels.p, (size_t)frames * prm.max_det * 4, hipMemcpyDeviceToHost, sd));
+        c.filt_dev = false;
+        if (!prm.inject && dev_filter && !split_streams && reid->dtype == AIC_F16 && getenv("AICAM_NO_FUSE_CROP") == nullptr) {
+            reid->in_pix4 = reid->input_pix4_ok();
+            c.filt_dev = reid->in_pix4;
+        }
+        if (c.filt_dev) {
+            stage_a_device_filter(c, f0, frames, s, sd);
+            t_issue += now() - t0;
+            return;
+        }
         HIP_CHECK(hipEventRecord(c.ev_det, sd));
-        if (!prm.inject) HIP_CHECK(hipEventSynchronize(c.ev_det));
+        if (!prm.inject) { HIP_CHECK(hipEventSynchronize(c.ev_det)); n_filter_host_groups += 1; }
         // detection set handed to ReID + association
         int nc = 0;
         for (int f = 0; f < frames; ++f) {
@@ -322,6 +368,106 @@ struct Pipeline {
         t_issue += now() - t0;
     }
 
+    // inject = 0 with the filter on the device: NMS -> det_filter kernels -> crop + ReID, stream-ordered, no host round trip.
+    // The ReID round is launched for a BOUND (the engine's max_items, at most frames * max_det) and reads the crop count on the
+    // device (Model::n_items_dev); a group with more crops than that gets its remaining rounds from the consumer thread, which
+    // is where the counts first reach the host (prepare_b).
+    void stage_a_device_filter(Chunk& c, const uint8_t* f0, int frames, hipStream_t s, hipStream_t sd) {
+        const int cap = prm.batch * prm.max_det;
+        if (c.f_cap < cap) {                  // first use of this context (it is idle: stage B released it)
+            HIP_CHECK(hipStreamSynchronize(s));
+            c.d_rank.alloc((size_t)cap), c.d_fn.alloc(prm.batch), c.d_fd0.alloc(prm.batch), c.d_total.alloc(4), c.d_fcls.alloc(cap);
+            c.d_ftlwh.alloc((size_t)cap * 4), c.d_fconf.alloc(cap);
+            c.h_fn.alloc(prm.batch), c.h_fd0.alloc(prm.batch), c.h_total.alloc(4);
+            c.h_boxes.alloc((size_t)cap * 4), c.h_frame_of.alloc(cap), c.h_valid.alloc(cap);
+            c.d_boxes.alloc((size_t)cap * 4), c.d_frame_of.alloc(cap), c.d_valid.alloc(cap), c.d_emb.alloc((size_t)cap * dim), c.d_emb_n.alloc((size_t)cap * dim);
+            c.f_cap = cap;
+        }
+        DetFilterArgs fa{};
+        fa.num_dets = yolo->d_numdets.p, fa.boxes = yolo->d_out_boxes_orig.p, fa.scores = yolo->d_out_scores.p, fa.labels = yolo->d_out_labels.p;
+        fa.batch = frames, fa.max_det = prm.max_det, fa.min_conf = prm.min_confidence;
+        fa.mask[0] = prm.track_class_mask[0], fa.mask[1] = prm.track_class_mask[1];
+        fa.cap = c.f_cap, fa.rank = c.d_rank.p, fa.frame_n = c.d_fn.p, fa.frame_d0 = c.d_fd0.p, fa.total = c.d_total.p;
+        fa.xyxy = c.d_boxes.p, fa.tlwh = c.d_ftlwh.p, fa.conf = c.d_fconf.p, fa.cls = c.d_fcls.p, fa.frame_of = c.d_frame_of.p;
+        {
+            Prof pr(*dev, PROF_DET, sd, 0, (double)frames * prm.max_det * 24);
+            launch_det_filter(fa, sd);
+        }
+        HIP_CHECK(hipMemcpyAsync(c.h_fn.p, c.d_fn.p, (size_t)frames * 4, hipMemcpyDeviceToHost, sd));
+        HIP_CHECK(hipMemcpyAsync(c.h_fd0.p, c.d_fd0.p, (size_t)frames * 4, hipMemcpyDeviceToHost, sd));
+        HIP_CHECK(hipMemcpyAsync(c.h_total.p, c.d_total.p, 8, hipMemcpyDeviceToHost, sd));
+        HIP_CHECK(hipEventRecord(c.ev_det, sd));
+        HIP_CHECK(hipStreamWaitEvent(s, c.ev_det, 0));     // the crop list is in HBM: a stream dependency, not a host wait
+        const int bound = std::min(reid->max_items, frames * prm.max_det);
+        c.reid_rows = bound;
+        {
+            std::lock_guard<std::mutex> lk(reid_mu);
+            reid->in_pix4 = true;
+            reid->crop_src = CropSrc{f0, prm.frame_h, prm.frame_w, c.d_boxes.p, c.d_frame_of.p, c.d_valid.p};
+            reid->n_items_dev = c.d_total.p;
+            reid->run(bound, s);
+            reid->crop_src.frames = nullptr;
+            reid->n_items_dev = nullptr;
+            HIP_CHECK(hipMemcpyAsync(c.d_emb.p, reid->embeddings(), (size_t)bound * dim * 4, hipMemcpyDeviceToDevice, s));
+        }
+        {
+            Prof pr(*dev, PROF_TRK, s, 0, (double)bound * dim * 8);
+            launch_normalize_rows(c.d_emb.p, c.d_emb_n.p, bound, dim, s, c.d_total.p);
+        }
+        if (pipe_times) HIP_CHECK(hipEventRecord(c.t_end, s));
+        HIP_CHECK(hipEventRecord(c.done, s));
+        n_filter_dev_groups += 1;
+    }
+
+    // Consumer side of a device-filtered group: the per-frame counts are on the host behind ev_det (recorded right after NMS, long
+    // before the group's ReID ends).  Plans the association (device / host, deepsort_tracker.py:88-101 redone on the host only for
+    // the host path), and launches the ReID rounds the producer's bounded one did not cover.
+    void prepare_b(Chunk& c) {
+        const double t0 = now();
+        HIP_CHECK(hipEventSynchronize(c.ev_det));
+        const int total = c.h_total.p[1];
+        AIC_REQUIRE(total <= c.f_cap, AIC_ERR_RUNTIME, "detection filter: more rows than batch * max_det");
+        c.n_crops = total;
+        int n_max = 0;
+        for (int f = 0; f < c.frames; ++f) {
+            FrameDets& fd = c.dets[f];
+            fd.n = c.h_fn.p[f], fd.crop0 = c.h_fd0.p[f];
+            n_max = std::max(n_max, fd.n);
+        }
+        c.dev_mode = use_device(n_max, c.tracks_after);
+        if (total > c.reid_rows) {             // a crowded group: every surviving detection is embedded (deepsort_tracker.py:104-113), in further rounds
+            hipStream_t s = dev->s_main;
+            const uint8_t* f0 = ring.p + (size_t)c.first_slot * frame_bytes;
+            std::lock_guard<std::mutex> lk(reid_mu);
+            dev->use();
+            for (int c0 = c.reid_rows; c0 < total; c0 += reid->max_items) {
+                const int k = std::min(reid->max_items, total - c0);
+                reid->in_pix4 = true;
+                reid->crop_src = CropSrc{f0, prm.frame_h, prm.frame_w, c.d_boxes.p + (size_t)c0 * 4, c.d_frame_of.p + c0, c.d_valid.p + c0};
+                reid->run(k, s);
+                reid->crop_src.frames = nullptr;
+                HIP_CHECK(hipMemcpyAsync(c.d_emb.p + (size_t)c0 * dim, reid->embeddings(), (size_t)k * dim * 4, hipMemcpyDeviceToDevice, s));
+                launch_normalize_rows(c.d_emb.p + (size_t)c0 * dim, c.d_emb_n.p + (size_t)c0 * dim, k, dim, s);
+                n_overflow_rounds += 1;
+            }
+            HIP_CHECK(hipEventRecord(c.ev_extra, s));
+            HIP_CHECK(hipEventRecord(c.done, s));          // `done` now covers the extra rounds too
+        }
+        if (!c.dev_mode) {                      // association on the host: it needs the detection lists and the crop validity there
+            HIP_CHECK(hipEventSynchronize(c.done));
+            for (int f = 0; f < c.frames; ++f) {
+                FrameDets& fd = c.dets[f];
+                const int crop0 = fd.crop0, n_dev = fd.n;
+                const int nd = std::min(c.h_numdets.p[f], prm.max_det);
+                collect(fd, nd, c.h_detboxes.p + (size_t)f * prm.max_det * 4, c.h_scores.p + (size_t)f * prm.max_det, c.h_labels.p + (size_t)f * prm.max_det);
+                fd.crop0 = crop0;
+                AIC_REQUIRE(fd.n == n_dev, AIC_ERR_RUNTIME, "detection filter: device and host counts differ");
+            }
+            if (total) HIP_CHECK(hipMemcpy(c.h_valid.p, c.d_valid.p, (size_t)total * 4, hipMemcpyDeviceToHost));
+        }
+        t_wait += now() - t0;
+    }
+
     void stage_b(Chunk& c, int out_base, int32_t* n_tracks, int32_t* tracks6, float* track_conf, int32_t* n_dets,
                  float* det_boxes, float* det_scores, int32_t* det_labels) {
         const double t0 = now();
@@ -390,6 +536,7 @@ struct Pipeline {
             }
         }
         trk.defer_outputs = false;             // direct users of the tracker handle get synchronous outputs
+        if (x_shard[0]) { pack_shard_if_due(dev->s_trk); HIP_CHECK(hipStreamSynchronize(dev->s_trk)); }
         tracks_seen = (int)trk.tracks.size();
         c.tracks_after = tracks_seen;
         last_chunk = (int)(&c - &ck[0]);
@@ -413,20 +560,17 @@ struct Pipeline {
         EpochDets dets{reinterpret_cast<const int*>(c.d_meta.p + c.m_n), reinterpret_cast<const int*>(c.d_meta.p + c.m_d0),
                        reinterpret_cast<const float*>(c.d_meta.p + c.m_tlwh), reinterpret_cast<const float*>(c.d_meta.p + c.m_conf),
                        reinterpret_cast<const int*>(c.d_meta.p + c.m_cls), c.d_valid.p, c.d_emb.p, c.d_emb_n.p};
-        EpochOut out{reinterpret_cast<int*>(c.d_out.p), reinterpret_cast<int*>(c.d_out.p + o_rows), reinterpret_cast<float*>(c.d_out.p + o_conf),
-                     mp, nullptr, nullptr};
-        trk.run_epochs(dets, reinterpret_cast<const int*>(c.h_meta.p + c.m_n), reinterpret_cast<const int*>(c.h_meta.p + c.m_d0), c.frames, out, s);
-        HIP_CHECK(hipMemcpyAsync(c.h_out.p, c.d_out.p, obytes, hipMemcpyDeviceToHost, s));
-        if (x_shard[0] && (x_groups++ % x_every) == 0) {       // gallery shard of this stream, ordered behind the group's epochs
-            std::unique_lock<std::mutex> lk(x_mu);
-            x_cv.wait(lk, [&] { return x_done >= x_packed - 1; });   // the buffer's previous exchange has been consumed
-            const int b = (int)(x_packed & 1);
-            launch_gallery_shard(trk.tbl_hdr(), trk.tbl_trk(), trk.d_gal_n.p, trk.gmax, trk.dim, x_shard[b], x_tmax, s);
-            HIP_CHECK(hipEventRecord(ev_shard[b], s));
-            x_packed += 1;
-            lk.unlock();
-            x_cv.notify_all();
+        const int* h_n = reinterpret_cast<const int*>(c.h_meta.p + c.m_n);
+        const int* h_d0 = reinterpret_cast<const int*>(c.h_meta.p + c.m_d0);
+        if (c.filt_dev) {                                      // the arrays the device filter wrote; counts came back behind ev_det (prepare_b)
+            dets = EpochDets{c.d_fn.p, c.d_fd0.p, c.d_ftlwh.p, c.d_fconf.p, c.d_fcls.p, c.d_valid.p, c.d_emb.p, c.d_emb_n.p};
+            h_n = c.h_fn.p, h_d0 = c.h_fd0.p;
         }
+        EpochOut out{reinterpret_cast<int*>(c.d_out.p), reinterpret_cast<int*>(c.d_out.p + o_rows), reinterpret_cast<float*>(c.d_out.p + o_conf),
+                     mp, nullptr, nullptr, 0};
+        trk.run_epochs(dets, h_n, h_d0, c.frames, out, s);
+        HIP_CHECK(hipMemcpyAsync(c.h_out.p, c.d_out.p, obytes, hipMemcpyDeviceToHost, s));
+        pack_shard_if_due(s);
         const double t1 = now();
         t_track += t1 - t0;                                    // host time of the association: planning + launches
         HIP_CHECK(hipStreamSynchronize(s));
@@ -532,6 +676,7 @@ struct Pipeline {
                     cv.wait(lk, [&] { return issued > k; });
                     if (perr) break;
                 }
+                if (ck[k % NCK].filt_dev) prepare_b(ck[k % NCK]);
                 if (ck[k % NCK].dev_mode) {
                     trk.dev_assoc = true;
                     stage_b_device(ck[k % NCK], goff[k], n_tracks, tracks6, track_conf, n_dets, det_boxes, det_scores, det_labels);
@@ -751,6 +896,10 @@ int aic_pipeline_option(aic_pipeline* p, const char* key, int value) {
             AIC_REQUIRE(value >= 0 && value <= 2, AIC_ERR_INVALID, "device_assoc: 0 host, 1 auto, 2 always on the device");
             p->p.dev_assoc = value;
         }
+        else if (k == "device_filter") {
+            AIC_REQUIRE(value == 0 || value == 1, AIC_ERR_INVALID, "device_filter: 0 host filter, 1 on the device");
+            p->p.dev_filter = value;
+        }
         else if (k == "group_frames") {
             AIC_REQUIRE(value >= 0 && value <= p->p.prm.batch, AIC_ERR_INVALID, "group_frames must be in 0..batch");
             p->p.group_frames = value;
@@ -764,6 +913,15 @@ int aic_pipeline_counters(aic_pipeline* p, int64_t* grown_groups, int64_t* clipp
         AIC_REQUIRE(p, AIC_ERR_INVALID, "NULL pipeline");
         if (grown_groups) *grown_groups = p->p.n_grow;
         if (clipped_frames) *clipped_frames = p->p.n_rows_clipped;
+    });
+}
+
+int aic_pipeline_filter_counters(aic_pipeline* p, int64_t* device_groups, int64_t* host_groups, int64_t* overflow_rounds) {
+    return guarded([&] {
+        AIC_REQUIRE(p, AIC_ERR_INVALID, "NULL pipeline");
+        if (device_groups) *device_groups = p->p.n_filter_dev_groups;
+        if (host_groups) *host_groups = p->p.n_filter_host_groups;
+        if (overflow_rounds) *overflow_rounds = p->p.n_overflow_rounds;
     });
 }
 

@@ -504,6 +504,7 @@ void Tracker::to_host() {
     }
     free_slots.assign(hf, hf + hh->n_free);
     next_id = hh->next_id;
+    acc_fast += hh->n_fast, acc_lsap += hh->n_lsap;       // the header's counters restart when the table next goes up
     on_device = false;
     for (int i = 0; i < dev_predicts; ++i)                // predicts announced but not yet consumed by an epoch
         for (auto& t : tracks) { t.age += 1; t.tsu += 1; }
@@ -521,12 +522,13 @@ void Tracker::run_epochs(const EpochDets& dets, const int* h_n, const int* h_d0,
     prm.max_cos = (float)this->prm.max_cosine_distance, prm.clamp_cos = (float)(this->prm.max_cosine_distance + 1e-5);   // lsap.cpp:133-134
     prm.max_iou = (float)this->prm.max_iou_distance, prm.clamp_iou = (float)(this->prm.max_iou_distance + 1e-5);
     prm.max_age = this->prm.max_age, prm.n_init = this->prm.n_init, prm.gmax = gmax, prm.dim = dim, prm.cap = cap;
+    prm.no_fast = lsap_fast ? 0 : 1;
     d_costs.ensure((size_t)3 * TRK_DEV_TMAX * TRK_DEV_NMAX);
     d_sub.ensure((size_t)TRK_DEV_TMAX * TRK_DEV_NMAX);
     d_appends.ensure((size_t)3 * TRK_DEV_DNMAX);
     d_dbg.ensure(16 + 2 * TRK_DEV_TMAX);
     static const int k_env = [] { const char* e = getenv("AICAM_TRK_K"); return e ? atoi(e) : 16; }();   // frames per epoch (measured: 8 / 16 / 32)
-    const int kmax = std::max(1, std::min(std::min(TRK_KMAX, k_env), gmax));
+    const int kmax = std::max(1, std::min(std::min(TRK_KMAX, epoch_frames > 0 ? epoch_frames : k_env), gmax));
     int f = 0;
     while (f < frames) {
         int k = 0, dn = 0, nmax = 0;
@@ -551,7 +553,7 @@ void Tracker::run_epochs(const EpochDets& dets, const int* h_n, const int* h_d0,
         }
         EpochOut o = out;
         const bool last = f + k >= frames;
-        if (!(debug && last)) o.dbg_match = nullptr, o.dbg_tn = nullptr;
+        if (!(debug && last)) { o.dbg_tn = nullptr; if (!o.dbg_stride) o.dbg_match = nullptr; }
         {
             Prof pr(*dev, PROF_TRK, s, 0, 0);
             launch_trk_epoch(tbl_hdr(), tbl_trk(), tbl_free(), d_mean.p, d_cov.p, d_gal_raw.p, d_gal_n.p, prm, dets, f, k, d_begin, dn_pad, nmax,
@@ -564,6 +566,7 @@ void Tracker::run_epochs(const EpochDets& dets, const int* h_n, const int* h_d0,
 
 void Tracker::check_epochs() {
     const DevTrkHdr* hh = reinterpret_cast<const DevTrkHdr*>(h_tbl.p);
+    n_fast = acc_fast + hh->n_fast, n_lsap = acc_lsap + hh->n_lsap;
     if (hh->err == 0) return;
     const std::string at = " (frame " + std::to_string(hh->err_frame) + " of the launch group; the tracker state is the frame before it)";
     AIC_REQUIRE(hh->err != 1, AIC_ERR_CAPACITY, "track capacity exhausted (raise max_tracks)" + at);
@@ -613,7 +616,7 @@ void Tracker::update_device(const float* det_tlwh, const float* conf, const int3
                    reinterpret_cast<const int*>(d_api.p + o_cls), reinterpret_cast<const int*>(d_api.p + o_valid), d_featp, d_featn};
     d_dbg.ensure(16 + 2 * TRK_DEV_TMAX);
     EpochOut out{reinterpret_cast<int*>(d_api.p + o_out), reinterpret_cast<int*>(d_api.p + o_rows), reinterpret_cast<float*>(d_api.p + o_oconf),
-                 max_rows, d_dbg.p + 8, d_dbg.p};
+                 max_rows, d_dbg.p + 8, d_dbg.p, 0};
     const int zero = 0;
     run_epochs(dets, &n, &zero, 1, out, s, true);
     HIP_CHECK(hipMemcpyAsync(h_api.p + o_out, d_api.p + o_out, bytes - o_out, hipMemcpyDeviceToHost, s));
@@ -641,6 +644,147 @@ void Tracker::update_device(const float* det_tlwh, const float* conf, const int3
         HIP_CHECK(hipMemcpyAsync(last_iou.data(), d_costs.p + 2 * stride, tn * 4, hipMemcpyDeviceToHost, s));
         HIP_CHECK(hipStreamSynchronize(s));
     }
+}
+
+// aic_tracker_update_batch: k frames, each TrackerCore.predict() + update() (tracker_core.py:44-81), as epochs of the device
+// association -- what the pipeline does per launch group, with the embeddings supplied by the caller.
+void Tracker::update_batch(int k, const int32_t* counts, const float* det_tlwh, const float* conf, const int32_t* cls, const float* feat,
+                           int feat_mem, const uint8_t* has_feat, int dim_in, int cap_rows, int32_t* n_out, int32_t* out6, float* out_conf,
+                           int32_t* n_match, int32_t* match_tid, int32_t* match_det) {
+    dev->use();
+    AIC_REQUIRE(k >= 0 && cap_rows >= 0, AIC_ERR_INVALID, "negative frame count / row capacity");
+    if (k == 0) return;
+    AIC_REQUIRE(dev_predicts == 0 && !pending_predict, AIC_ERR_INVALID, "update_batch: a predict() without its update() is still open");
+    long total = 0;
+    for (int f = 0; f < k; ++f) {
+        AIC_REQUIRE(counts[f] >= 0 && counts[f] <= TRK_DEV_NMAX, AIC_ERR_CAPACITY, "device association: more than 512 detections in one frame");
+        total += counts[f];
+    }
+    const bool any_feat = feat != nullptr && total > 0;
+    if (any_feat) ensure_dim(dim_in);
+    AIC_REQUIRE(dev_capable(), AIC_ERR_INVALID, "update_batch runs on the device: needs nn_budget > 0, max_tracks <= 512 and a feature dimension divisible by 4");
+    hipStream_t s = dev->s_trk;
+    const int n = (int)total, stride = 2 * TRK_DEV_TMAX + 8;
+    // staging (host == device layout): frame_n[k] | frame_d0[k] | tlwh[n*4] | conf[n] | cls[n] | valid[n] || n_tracks[k] | rows[k*cap*6] | conf[k*cap] | matches[k*stride]
+    const size_t o_d0 = (size_t)k * 4, o_tlwh = (((size_t)k * 8 + 15) / 16) * 16, o_conf = o_tlwh + (size_t)n * 16, o_cls = o_conf + (size_t)n * 4;
+    const size_t o_valid = o_cls + (size_t)n * 4, o_out = ((o_valid + (size_t)n * 4 + 15) / 16) * 16;
+    const size_t o_rows = o_out + (((size_t)k * 4 + 15) / 16) * 16, o_oconf = o_rows + (size_t)k * cap_rows * 24;
+    const size_t o_dbg = ((o_oconf + (size_t)k * cap_rows * 4 + 15) / 16) * 16, bytes = o_dbg + (size_t)k * stride * 4;
+    HIP_CHECK(hipStreamSynchronize(s));
+    h_api.ensure(bytes);
+    d_api.ensure(bytes);
+    int* hn = reinterpret_cast<int*>(h_api.p);
+    int* hd = reinterpret_cast<int*>(h_api.p + o_d0);
+    int d0 = 0;
+    for (int f = 0; f < k; ++f) { hn[f] = counts[f]; hd[f] = d0; d0 += counts[f]; }
+    if (n) {
+        std::memcpy(h_api.p + o_tlwh, det_tlwh, (size_t)n * 16);
+        std::memcpy(h_api.p + o_conf, conf, (size_t)n * 4);
+        std::memcpy(h_api.p + o_cls, cls, (size_t)n * 4);
+        int* hv = reinterpret_cast<int*>(h_api.p + o_valid);
+        for (int j = 0; j < n; ++j) hv[j] = (any_feat && (!has_feat || has_feat[j])) ? 1 : 0;
+    }
+    HIP_CHECK(hipMemcpyAsync(d_api.p, h_api.p, o_out, hipMemcpyHostToDevice, s));
+    const float* d_featp = nullptr;
+    const float* d_featn = nullptr;
+    if (any_feat) {
+        if (feat_mem == AIC_DEVICE) d_featp = feat;
+        else {
+            d_feat.ensure((size_t)n * dim);
+            HIP_CHECK(hipMemcpyAsync(d_feat.p, feat, (size_t)n * dim * 4, hipMemcpyHostToDevice, s));
+            d_featp = d_feat.p;
+        }
+        d_detn.ensure((size_t)n * dim);
+        launch_normalize_rows(d_featp, d_detn.p, n, dim, s);
+        d_featn = d_detn.p;
+    }
+    EpochDets dets{reinterpret_cast<const int*>(d_api.p), reinterpret_cast<const int*>(d_api.p + o_d0),
+                   reinterpret_cast<const float*>(d_api.p + o_tlwh), reinterpret_cast<const float*>(d_api.p + o_conf),
+                   reinterpret_cast<const int*>(d_api.p + o_cls), reinterpret_cast<const int*>(d_api.p + o_valid), d_featp, d_featn};
+    EpochOut out{reinterpret_cast<int*>(d_api.p + o_out), reinterpret_cast<int*>(d_api.p + o_rows), reinterpret_cast<float*>(d_api.p + o_oconf),
+                 cap_rows, reinterpret_cast<int*>(d_api.p + o_dbg), nullptr, stride};
+    run_epochs(dets, hn, hd, k, out, s, false);
+    HIP_CHECK(hipMemcpyAsync(h_api.p + o_out, d_api.p + o_out, bytes - o_out, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    check_epochs();
+    const int* on = reinterpret_cast<const int*>(h_api.p + o_out);
+    const int* rows = reinterpret_cast<const int*>(h_api.p + o_rows);
+    const float* oc = reinterpret_cast<const float*>(h_api.p + o_oconf);
+    const int* dbg = reinterpret_cast<const int*>(h_api.p + o_dbg);
+    for (int f = 0; f < k; ++f) {
+        const int kk = std::min(on[f], cap_rows);
+        if (n_out) n_out[f] = on[f];                       // the true count: rows beyond cap_rows are not stored
+        if (out6) std::copy(rows + (size_t)f * cap_rows * 6, rows + ((size_t)f * cap_rows + kk) * 6, out6 + (size_t)f * cap_rows * 6);
+        if (out_conf) std::copy(oc + (size_t)f * cap_rows, oc + (size_t)f * cap_rows + kk, out_conf + (size_t)f * cap_rows);
+        const int* dm = dbg + (size_t)f * stride;
+        if (n_match) n_match[f] = dm[0];
+        for (int m = 0; m < dm[0] && m < cap_rows; ++m) {
+            if (match_tid) match_tid[(size_t)f * cap_rows + m] = dm[1 + 2 * m];
+            if (match_det) match_det[(size_t)f * cap_rows + m] = dm[2 + 2 * m];
+        }
+    }
+    outputs.clear();
+    const int kl = std::min(on[k - 1], cap_rows);
+    for (int r = 0; r < kl; ++r) {
+        const int* q = rows + ((size_t)(k - 1) * cap_rows + r) * 6;
+        outputs.push_back(TrackOut{q[0], q[1], q[2], q[3], q[4], q[5], oc[(size_t)(k - 1) * cap_rows + r]});
+    }
+}
+
+// aic_tracker_import_state: the inverse of aic_tracker_export + aic_tracker_export_gallery.
+void Tracker::import_state(int n, const int32_t* track_id, const int32_t* state, const int32_t* hits, const int32_t* age, const int32_t* tsu,
+                           const int32_t* cls, const float* conf, const int32_t* gallery_len, const float* mean, const float* cov,
+                           const float* galleries, int dim_in, int next_track_id) {
+    dev->use();
+    AIC_REQUIRE(n >= 0 && n <= cap, AIC_ERR_CAPACITY, "more tracks than the tracker's capacity (max_tracks)");
+    AIC_REQUIRE(n == 0 || (track_id && state && hits && age && tsu && cls && conf && gallery_len && mean && cov), AIC_ERR_INVALID, "NULL state array");
+    long rows = 0;
+    int longest = 0;
+    for (int i = 0; i < n; ++i) {
+        AIC_REQUIRE(state[i] == TRK_TENTATIVE || state[i] == TRK_CONFIRMED, AIC_ERR_INVALID, "track state must be Tentative or Confirmed (deleted tracks are pruned, tracker_core.py:75)");
+        AIC_REQUIRE(gallery_len[i] >= 0, AIC_ERR_INVALID, "negative gallery length");
+        AIC_REQUIRE(track_id[i] < next_track_id, AIC_ERR_INVALID, "next_track_id must be above every imported id (track.py:21)");
+        rows += gallery_len[i];
+        longest = std::max(longest, gallery_len[i]);
+    }
+    AIC_REQUIRE(rows == 0 || (galleries && dim_in > 0), AIC_ERR_INVALID, "galleries need their rows and a feature dimension");
+    if (rows) ensure_dim(dim_in);
+    if (!unlimited) AIC_REQUIRE(longest <= gmax, AIC_ERR_CAPACITY, "a gallery is longer than nn_budget");
+    while (unlimited && dim > 0 && longest + 1 > gmax) grow_galleries();
+    hipStream_t s = dev->s_trk;
+    HIP_CHECK(hipStreamSynchronize(s));
+    // every check passed: from here on the old state is gone
+    on_device = false, dev_predicts = 0, pending_predict = false, pre_rows = false, pre_predicted = false;
+    pend.active = false;
+    tracks.clear();
+    free_slots.clear();
+    for (int sl = cap - 1; sl >= n; --sl) free_slots.push_back(sl);     // the constructor's order: the lowest free slot is handed out first
+    next_id = next_track_id;
+    DevBuf<float> stage;
+    if (rows) {
+        stage.alloc((size_t)rows * dim);
+        HIP_CHECK(hipMemcpyAsync(stage.p, galleries, (size_t)rows * dim * 4, hipMemcpyHostToDevice, s));
+    }
+    size_t r0 = 0;
+    for (int i = 0; i < n; ++i) {
+        TrackRec r{};
+        r.id = track_id[i], r.state = state[i], r.hits = hits[i], r.age = age[i], r.tsu = tsu[i], r.cls = cls[i], r.conf = conf[i];
+        r.slot = i, r.glen = gallery_len[i], r.ghead = 0;
+        tracks.push_back(r);
+        if (r.glen) {
+            float* raw = d_gal_raw.p + (size_t)r.slot * gmax * dim;
+            HIP_CHECK(hipMemcpyAsync(raw, stage.p + r0 * dim, (size_t)r.glen * dim * 4, hipMemcpyDeviceToDevice, s));
+            launch_normalize_rows(raw, d_gal_n.p + (size_t)r.slot * gmax * dim, r.glen, dim, s);    // matching.py:126-130, as at append time
+            r0 += r.glen;
+        }
+    }
+    if (n) {
+        HIP_CHECK(hipMemcpyAsync(d_mean.p, mean, (size_t)n * 8 * 4, hipMemcpyHostToDevice, s));
+        HIP_CHECK(hipMemcpyAsync(d_cov.p, cov, (size_t)n * 64 * 4, hipMemcpyHostToDevice, s));
+    }
+    HIP_CHECK(hipStreamSynchronize(s));
+    outputs.clear(), resolved.clear(), last_matches.clear();
+    last_t = last_n = 0;
 }
 
 }  // namespace aic
@@ -817,23 +961,29 @@ int aic_tracker_option(aic_tracker* t, const char* key, int value) {
                         "device association needs nn_budget > 0, max_tracks <= 512 and a feature dimension divisible by 4");
             if (!value) t->t.to_host();
             t->t.dev_assoc = value != 0;
+        } else if (k == "lsap_fast") {
+            t->t.lsap_fast = value != 0;
+        } else if (k == "epoch_frames") {
+            AIC_REQUIRE(value >= 0 && value <= TRK_KMAX, AIC_ERR_INVALID, "epoch_frames must be in 0..32 (0 = default)");
+            t->t.epoch_frames = value;
         } else AIC_REQUIRE(false, AIC_ERR_INVALID, "unknown tracker option: " + k);
     });
 }
 
 // The device cascade + LSAP of kernels_trk_dev.hip on caller-provided matrices of one frame (parity tests).
 int aic_match_cascade_device(int device_id, const float* app, const float* maha, const float* iou, int t, int n, const int32_t* state,
-                             const int32_t* tsu, double max_cosine_distance, double max_iou_distance, int max_age, int stage1_only,
-                             int32_t* match_det_of_track) {
+                             const int32_t* tsu, double max_cosine_distance, double max_iou_distance, int max_age, int flags,
+                             int32_t* match_det_of_track, int32_t* n_fast_lsap) {
     return guarded([&] {
         AIC_REQUIRE(t >= 0 && n >= 0 && t <= TRK_DEV_TMAX && n <= TRK_DEV_NMAX, AIC_ERR_CAPACITY, "at most 512 tracks x 512 detections");
         if (t == 0) return;
         AIC_REQUIRE(state && tsu && match_det_of_track && (n == 0 || (app && maha && iou)), AIC_ERR_INVALID, "NULL argument");
         Device& d = device(device_id);
+        d.use();
         hipStream_t s = d.s_trk;
         const size_t stride = (size_t)TRK_DEV_TMAX * TRK_DEV_NMAX, tn = (size_t)t * n;
         DevBuf<float> costs(3 * stride), sub(stride);
-        DevBuf<int> st(t), ts(t), md(t + 1);
+        DevBuf<int> st(t), ts(t), md(t + 3);
         if (tn) {
             HIP_CHECK(hipMemcpyAsync(costs.p, app, tn * 4, hipMemcpyHostToDevice, s));
             HIP_CHECK(hipMemcpyAsync(costs.p + stride, maha, tn * 4, hipMemcpyHostToDevice, s));
@@ -845,13 +995,15 @@ int aic_match_cascade_device(int device_id, const float* app, const float* maha,
         prm.max_cos = (float)max_cosine_distance, prm.clamp_cos = (float)(max_cosine_distance + 1e-5);
         prm.max_iou = (float)max_iou_distance, prm.clamp_iou = (float)(max_iou_distance + 1e-5);
         prm.max_age = max_age, prm.n_init = 3, prm.gmax = 1, prm.dim = 0, prm.cap = TRK_DEV_TMAX;
+        prm.no_fast = (flags & 2) ? 1 : 0;
         EpochScratch scr{nullptr, nullptr, costs.p, sub.p, nullptr};
-        launch_trk_cascade_test(prm, scr, t, n, st.p, ts.p, md.p, md.p + t, stage1_only, s);
-        std::vector<int> out(t + 1);
-        HIP_CHECK(hipMemcpyAsync(out.data(), md.p, (size_t)(t + 1) * 4, hipMemcpyDeviceToHost, s));
+        launch_trk_cascade_test(prm, scr, t, n, st.p, ts.p, md.p, md.p + t, flags & 1, s);
+        std::vector<int> out(t + 3);
+        HIP_CHECK(hipMemcpyAsync(out.data(), md.p, (size_t)(t + 3) * 4, hipMemcpyDeviceToHost, s));
         HIP_CHECK(hipStreamSynchronize(s));
         AIC_REQUIRE(out[t] == 0, AIC_ERR_INVALID, "cost matrix contains NaN/-inf or is infeasible");
         std::copy(out.begin(), out.begin() + t, match_det_of_track);
+        if (n_fast_lsap) { n_fast_lsap[0] = out[t + 1]; n_fast_lsap[1] = out[t + 2]; }
     });
 }
 
@@ -868,6 +1020,43 @@ int aic_tracker_update(aic_tracker* t, const float* det_tlwh, const float* conf,
         AIC_REQUIRE(t, AIC_ERR_INVALID, "NULL tracker");
         AIC_REQUIRE(n == 0 || (det_tlwh && conf && cls), AIC_ERR_INVALID, "NULL detection arrays");
         t->t.update(det_tlwh, conf, cls, feat, feat_mem, has_feat, n, dim);
+    });
+}
+
+int aic_tracker_update_batch(aic_tracker* t, int k, const int32_t* counts, const float* det_tlwh, const float* conf, const int32_t* cls,
+                             const float* feat, int feat_mem, const uint8_t* has_feat, int dim, int cap_rows, int32_t* n_out, int32_t* out6,
+                             float* out_conf, int32_t* n_match, int32_t* match_track_id, int32_t* match_det) {
+    return guarded([&] {
+        AIC_REQUIRE(t && (k == 0 || counts), AIC_ERR_INVALID, "NULL argument");
+        long total = 0;
+        for (int f = 0; f < k; ++f) total += counts[f];
+        AIC_REQUIRE(total == 0 || (det_tlwh && conf && cls), AIC_ERR_INVALID, "NULL detection arrays");
+        t->t.update_batch(k, counts, det_tlwh, conf, cls, feat, feat_mem, has_feat, dim, cap_rows, n_out, out6, out_conf, n_match, match_track_id, match_det);
+    });
+}
+
+int aic_tracker_import_state(aic_tracker* t, int n, const int32_t* track_id, const int32_t* state, const int32_t* hits, const int32_t* age,
+                             const int32_t* time_since_update, const int32_t* cls, const float* conf, const int32_t* gallery_len,
+                             const float* mean, const float* cov, const float* galleries, int dim, int next_track_id) {
+    return guarded([&] {
+        AIC_REQUIRE(t, AIC_ERR_INVALID, "NULL tracker");
+        t->t.import_state(n, track_id, state, hits, age, time_since_update, cls, conf, gallery_len, mean, cov, galleries, dim, next_track_id);
+    });
+}
+
+int aic_tracker_next_track_id(aic_tracker* t, int32_t* next_id) {
+    return guarded([&] {
+        AIC_REQUIRE(t && next_id, AIC_ERR_INVALID, "NULL argument");
+        t->t.to_host();
+        *next_id = t->t.next_id;
+    });
+}
+
+int aic_tracker_assoc_counters(aic_tracker* t, int64_t* n_fast, int64_t* n_lsap) {
+    return guarded([&] {
+        AIC_REQUIRE(t, AIC_ERR_INVALID, "NULL tracker");
+        if (n_fast) *n_fast = t->t.n_fast;
+        if (n_lsap) *n_lsap = t->t.n_lsap;
     });
 }
 

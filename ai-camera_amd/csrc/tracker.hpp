@@ -1,5 +1,7 @@
 // tracker.hpp -- DeepSORT core with Kalman state and galleries in HBM, lifecycle + cascade on host.
 #pragma once
+#include <cstdlib>
+
 #include "kernels.hpp"
 #include "trk_dev.hpp"
 
@@ -59,6 +61,7 @@ struct Tracker {
     // ---- association on the device, k frames per launch (kernels_trk_dev.hip): the track table lives in HBM between launches
     bool dev_assoc = false;            // aic_tracker_option("device_assoc"); the pipeline turns it on when dev_capable()
     bool on_device = false;            // the HBM table is the current one; `tracks` / `free_slots` / `next_id` are stale
+    bool lsap_fast = getenv("AICAM_TRK_NOFAST") == nullptr;   // aic_tracker_option("lsap_fast"): unique optima skip the LSAP (kernels_trk_dev.hip::unique_optimum)
     int dev_predicts = 0;              // predict() calls not yet consumed by an update (device path: the epoch kernel predicts)
     DevBuf<char> d_tbl;                // DevTrkHdr | DevTrack[cap] | int free_slots[cap]
     PinBuf<char> h_tbl;
@@ -66,6 +69,9 @@ struct Tracker {
     DevBuf<int> d_appends, d_dbg;
     PinBuf<char> h_api;                // single-frame API staging (aic_tracker_update through the device path)
     DevBuf<char> d_api;
+    long acc_fast = 0, acc_lsap = 0;
+    long n_fast = 0, n_lsap = 0;       // assignment problems settled by the unique-optimum check / the LSAP (device path, since the table last went up)
+    int epoch_frames = 0;              // frames per epoch launch; 0 = AICAM_TRK_K / 16 (aic_tracker_option("epoch_frames"), aic_tracker_update_batch)
     bool dev_capable() const { return !unlimited && cap <= TRK_DEV_TMAX && (dim == 0 || dim % 4 == 0); }
     bool use_device() const { return dev_assoc && dev_capable(); }
     DevTrkHdr* tbl_hdr() { return reinterpret_cast<DevTrkHdr*>(d_tbl.p); }
@@ -78,6 +84,14 @@ struct Tracker {
     // no host synchronisation; the header copy lands in h_tbl behind them (check_epochs() after the caller's sync)
     void run_epochs(const EpochDets& dets, const int* h_n, const int* h_d0, int frames, const EpochOut& out, hipStream_t s, bool debug = false);
     void check_epochs();
+    // k frames (predict + update each) as epochs on the device; features given by the caller (aic_tracker_update_batch)
+    void update_batch(int k, const int32_t* counts, const float* det_tlwh, const float* conf, const int32_t* cls, const float* feat, int feat_mem,
+                      const uint8_t* has_feat, int dim_in, int cap_rows, int32_t* n_out, int32_t* out6, float* out_conf, int32_t* n_match,
+                      int32_t* match_tid, int32_t* match_det);
+    // replace the whole state (aic_tracker_import_state): tracks in list order, galleries concatenated in FIFO order
+    void import_state(int n, const int32_t* track_id, const int32_t* state, const int32_t* hits, const int32_t* age, const int32_t* tsu,
+                      const int32_t* cls, const float* conf, const int32_t* gallery_len, const float* mean, const float* cov,
+                      const float* galleries, int dim_in, int next_track_id);
     void update_device(const float* det_tlwh, const float* conf, const int32_t* cls, const float* feat, int feat_mem,
                        const uint8_t* has_feat, int n, int dim_in);
 

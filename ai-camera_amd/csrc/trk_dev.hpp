@@ -33,12 +33,13 @@ struct DevTrkHdr {
     int32_t err;                    // 0 ok; 1 track slots exhausted; 2 LSAP infeasible / invalid cost; 3 capacity of the kernel exceeded
     int32_t err_frame;              // group frame index the error was raised at (state = the frame before it)
     int32_t frames_done;            // frames processed by the last epoch launch
-    int32_t pad[2];
+    int32_t n_fast, n_lsap;         // assignment problems settled by the unique-optimum check / by the LSAP, since the table went to the device
 };
 
 struct TrkDevParams {
     float max_cos, clamp_cos, max_iou, clamp_iou;   // fp32 thresholds and clamp values of linear_assignment.py:55-58,76
     int32_t max_age, n_init, gmax, dim, cap;
+    int32_t no_fast;                // 1: every assignment problem goes through the LSAP (tests / A-B); 0: unique optima are read off directly
 };
 
 struct EpochDets {                  // detection arrays of one launch group, device memory, rows = crops in frame order
@@ -60,6 +61,7 @@ struct EpochOut {                   // per frame of the launch group, device mem
     // debug of the LAST frame of the launch (tracker-level API: aic_tracker_last_matches / _last_costs); may be NULL
     int32_t* dbg_match;             // [0] = count, then (track id, det) pairs
     int32_t* dbg_tn;                // T, N of that frame
+    int32_t dbg_stride;             // > 0: dbg_match holds EVERY frame of the launch group, frame f at dbg_match + f * dbg_stride (aic_tracker_update_batch)
 };
 
 struct EpochScratch {

@@ -156,12 +156,15 @@ int aic_match_cascade(const float* app, const float* maha, const float* iou, int
                       int32_t* unmatched_tracks, int32_t* n_unmatched_tracks, int32_t* unmatched_dets,
                       int32_t* n_unmatched_dets);
 
-/* The same cascade (stage1_only = 0) or its appearance stage alone (1) run by the DEVICE association kernels
- * (csrc/kernels_trk_dev.hip: wave-parallel restatement of the same SciPy LSAP) on one frame's matrices; at most 512 x 512.
- * match_det_of_track[T]: the detection each track got, or -1.  Parity-test entry point of SURVEY.md §8(f)-4. */
+/* The same cascade run by the DEVICE association kernels (csrc/kernels_trk_dev.hip: wave-parallel restatement of the same
+ * SciPy LSAP, preceded by a unique-optimum check that reads the answer off the matrix when it is the only optimum) on one
+ * frame's matrices; at most 512 x 512.  flags: bit 0 = appearance stage alone, bit 1 = every problem through the LSAP (no
+ * unique-optimum check).  match_det_of_track[T]: the detection each track got, or -1.  n_fast_lsap (may be NULL): [0] =
+ * assignment problems settled by the check, [1] = by the LSAP.  Parity-test entry point of SURVEY.md §8(f)-4. */
 int aic_match_cascade_device(int device, const float* app, const float* maha, const float* iou, int t, int n,
                              const int32_t* state, const int32_t* time_since_update, double max_cosine_distance,
-                             double max_iou_distance, int max_age, int stage1_only, int32_t* match_det_of_track);
+                             double max_iou_distance, int max_age, int flags, int32_t* match_det_of_track,
+                             int32_t* n_fast_lsap);
 
 /* ------------------------------------------------------------------ tracker
  * TrackerCore (src/tracker/core/tracker_core.py:11-198) + Track lifecycle
@@ -182,7 +185,9 @@ int aic_tracker_create(int device, const aic_tracker_params* p, aic_tracker** ou
 int aic_tracker_destroy(aic_tracker* t);
 /* "device_assoc" = 1: predict/update run the whole frame (gating, cascade, LSAP, lifecycle, Kalman update) on the device,
  * the track table stays in HBM between calls (what the pipeline does k frames per launch); 0 (default for this entry
- * point): cost matrices on the device, cascade/LSAP/lifecycle in host C++.  Same results either way. */
+ * point): cost matrices on the device, cascade/LSAP/lifecycle in host C++.  Same results either way.
+ * "lsap_fast" = 0: every assignment problem of the device path goes through the wave LSAP (default 1: unique optima are read
+ * off the matrix).  "epoch_frames" = 1..32: frames per epoch launch of the device path (0 = default 16). */
 int aic_tracker_option(aic_tracker* t, const char* key, int value);
 /* TrackerCore.predict (tracker_core.py:44-49). */
 int aic_tracker_predict(aic_tracker* t);
@@ -190,6 +195,17 @@ int aic_tracker_predict(aic_tracker* t);
  * feat[N,dim] (host or device), has_feat[N] (NULL = all). */
 int aic_tracker_update(aic_tracker* t, const float* det_tlwh, const float* conf, const int32_t* cls,
                        const float* feat, int feat_mem, const uint8_t* has_feat, int n, int dim);
+/* k consecutive frames in ONE call, each a TrackerCore.predict() + TrackerCore.update() (tracker_core.py:44-49, 51-81), run
+ * as epochs of the device association (csrc/kernels_trk_dev.hip; frames per epoch: aic_tracker_option "epoch_frames", default
+ * 16) -- the pipeline's per-launch-group association with the embeddings supplied by the caller.  counts[k]; the rows of all
+ * frames concatenated: det_tlwh[sum,4], conf[sum], class id[sum], feat[sum,dim] (host or device), has_feat[sum] (NULL = all).
+ * Per frame (any may be NULL): n_out[k] confirmed tracks updated in the frame (true count), out6[k,cap_rows,6] + out_conf[k,
+ * cap_rows] as aic_tracker_outputs; n_match[k], match_track_id / match_det [k,cap_rows] as aic_tracker_last_matches.  Device
+ * path only (nn_budget > 0, max_tracks <= 512, dim % 4 == 0): AIC_ERR_INVALID otherwise.  Same results as k predict/update calls. */
+int aic_tracker_update_batch(aic_tracker* t, int k, const int32_t* counts, const float* det_tlwh, const float* conf,
+                             const int32_t* cls, const float* feat, int feat_mem, const uint8_t* has_feat, int dim,
+                             int cap_rows, int32_t* n_out, int32_t* out6, float* out_conf, int32_t* n_match,
+                             int32_t* match_track_id, int32_t* match_det);
 /* Confirmed tracks updated this frame, formatted as deepsort_tracker.py:126-141:
  * out[k] = {x1,y1,x2,y2 (round-half-even ints), track_id, class_id}, conf[k]. */
 int aic_tracker_outputs(aic_tracker* t, int32_t* out6, float* conf, int cap, int32_t* n_out);
@@ -201,6 +217,20 @@ int aic_tracker_export(aic_tracker* t, int cap, int32_t* track_id, int32_t* stat
                        int32_t* gallery_len, float* mean, float* cov);
 /* Gallery of live track `index` in FIFO order (track.py:70-74): out[gallery_len, dim]. */
 int aic_tracker_export_gallery(aic_tracker* t, int index, float* out, int cap_rows);
+/* The id the next new track will get (Track._next_id, track.py:21; per tracker here). */
+int aic_tracker_next_track_id(aic_tracker* t, int32_t* next_id);
+/* Inverse of aic_tracker_export + aic_tracker_export_gallery ("export / import of tracker state"): replaces the
+ * whole state of TrackerCore.tracks (tracker_core.py:28) by n tracks in list order -- the arrays of aic_tracker_export, the
+ * galleries of all tracks concatenated in FIFO order [sum(gallery_len), dim], and the next track id.  A tracker that
+ * imports another's export continues exactly as the exporter would have (checkpoint / resume, moving a stream between GPUs).
+ * Every argument is checked before the old state is touched. */
+int aic_tracker_import_state(aic_tracker* t, int n, const int32_t* track_id, const int32_t* state, const int32_t* hits,
+                             const int32_t* age, const int32_t* time_since_update, const int32_t* cls, const float* conf,
+                             const int32_t* gallery_len, const float* mean, const float* cov, const float* galleries,
+                             int dim, int next_track_id);
+/* Device association: assignment problems (one per cascade level + the IoU stage) settled by the unique-optimum check /
+ * solved by the wave LSAP since the tracker was created.  Either pointer may be NULL. */
+int aic_tracker_assoc_counters(aic_tracker* t, int64_t* n_unique, int64_t* n_lsap);
 /* (track_id, detection index) pairs of the last update, and its full cost matrices [T,N]
  * (appearance, squared Mahalanobis, 1-IoU), T = tracks alive before the update. */
 int aic_tracker_last_matches(aic_tracker* t, int32_t* track_id, int32_t* det, int cap, int32_t* n);
@@ -266,7 +296,9 @@ int aic_pipeline_group_times(aic_pipeline* p, int32_t* frames, double* submit_s,
  * confirmed tracks into the caller's device buffers (two, alternating).  A consumer thread then calls wait(seq) -- blocks
  * until shard `seq` is packed, returns its buffer index and makes the exchange stream (exchange_stream: a hipStream_t the
  * caller runs its RCCL all-gather on, e.g. through torch.cuda.ExternalStream) wait for the pack kernel -- and done(seq) once
- * the collective has consumed the buffer.  shard0_dev = NULL disables.  The association of the stream never waits for it. */
+ * the collective has consumed the buffer.  shard0_dev = NULL disables.  Two buffers alternate: the stream's association waits
+ * only when the consumer is two exchanges behind, and then for at most 60 s (AICAM_XCHG_WAIT_S) before the call fails with
+ * AIC_ERR_RUNTIME -- a stuck peer ends the run loudly, it does not hang it. */
 int aic_pipeline_exchange_enable(aic_pipeline* p, float* shard0_dev, float* shard1_dev, int t_max, int every_groups);
 int aic_pipeline_exchange_stream(aic_pipeline* p, void** stream);
 int aic_pipeline_exchange_wait(aic_pipeline* p, int64_t seq, int timeout_ms, int32_t* buffer, int32_t* ready);
@@ -282,12 +314,18 @@ int aic_pipeline_stats(aic_pipeline* p, double* issue_s, double* wait_s, double*
  * (<= batch; 0 = batch).  "device_assoc": 2 = association on the device, k frames per launch (cascade, LSAP and
  * lifecycle in csrc/kernels_trk_dev.hip, no host round trip per frame); 0 = cost matrices on the device, cascade / LSAP /
  * lifecycle in host C++ (csrc/assoc_host.cpp, lsap.cpp), one launch + one sync per frame; 1 (default) = per launch group, on
- * the device while the assignment problems fit one wavefront's registers (<= 64 tracks x 64 detections), else on the host.
+ * the device while the assignment problems fit one wavefront's registers (<= 64 tracks x 64 detections), else on the host;
+ * a group with a frame of more than 512 detections always takes the host chain.  "device_filter" (inject = 0): 1 (default) = the
+ * tracker's confidence / class filter runs on the device and ReID is sized from a device-side count, 0 = filter on the host.
  * Same results in every mode. */
 int aic_pipeline_option(aic_pipeline* p, const char* key, int value);
 /* Launch groups whose crop count outgrew the buffers sized from max_persons (handled, not dropped), and frames
  * whose confirmed tracks outnumbered the caller's max_persons rows (n_tracks reports the true count). */
 int aic_pipeline_counters(aic_pipeline* p, int64_t* grown_groups, int64_t* clipped_frames);
+/* inject = 0: launch groups whose detection filter (src/tracker/deepsort_tracker.py:88-101) ran on the device behind NMS (no host
+ * synchronisation between YOLO and ReID) / on the host (one event wait per group), and the extra ReID rounds launched for groups
+ * whose surviving detections outnumbered the ReID engine's max_items.  Any pointer may be NULL. */
+int aic_pipeline_filter_counters(aic_pipeline* p, int64_t* device_groups, int64_t* host_groups, int64_t* overflow_rounds);
 /* Frames, since creation, whose association (src/tracker/core/tracker_core.py:83-177) ran on the device in the epoch
  * kernels / on the host in C++: what the "device_assoc" auto mode actually chose. Either pointer may be NULL. */
 int aic_pipeline_assoc_frames(aic_pipeline* p, int64_t* device_frames, int64_t* host_frames);

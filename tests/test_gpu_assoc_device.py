@@ -13,12 +13,17 @@ from oracle import deepsort_oracle as O
 pytestmark = pytest.mark.gpu
 
 
-def device_cascade(lib, app, maha, iou, state, tsu, max_cos, max_iou, max_age, stage1_only=0):
+def device_cascade(lib, app, maha, iou, state, tsu, max_cos, max_iou, max_age, stage1_only=0, no_fast=0, counts=None):
+    """counts: int32[2] accumulating (problems settled by the unique-optimum check, problems solved by the LSAP)."""
     t, n = app.shape
     out = np.full(max(t, 1), -2, np.int32)
+    c = np.zeros(2, np.int32)
     lib.call("aic_match_cascade_device", 0, lib.ptr(np.ascontiguousarray(app, np.float32)), lib.ptr(np.ascontiguousarray(maha, np.float32)),
              lib.ptr(np.ascontiguousarray(iou, np.float32)), t, n, lib.ptr(np.ascontiguousarray(state, np.int32)),
-             lib.ptr(np.ascontiguousarray(tsu, np.int32)), float(max_cos), float(max_iou), int(max_age), int(stage1_only), lib.ptr(out))
+             lib.ptr(np.ascontiguousarray(tsu, np.int32)), float(max_cos), float(max_iou), int(max_age),
+             int(stage1_only) | (2 if no_fast else 0), lib.ptr(out), lib.ptr(c))
+    if counts is not None:
+        counts += c
     return out[:t]
 
 
@@ -36,6 +41,47 @@ def test_device_lsap_matches_scipy(gpu, lib):
         exp = np.full(r, -1, np.int32)
         exp[sr] = sc
         assert np.array_equal(got, exp), (it, m.shape)
+
+
+def test_device_unique_optimum_path_and_lsap_agree(gpu, lib, golden):
+    """Both branches of match_block on the same matrices: with the unique-optimum check (default) and with every problem
+    forced through the wave LSAP (flag bit 1).  Random matrices almost always have a unique optimum, tied / quantised /
+    constant ones do not: both kinds must reach SciPy's answer, and each branch must actually have been taken."""
+    rng = np.random.default_rng(21)
+    fast, slow = np.zeros(2, np.int64), np.zeros(2, np.int64)
+    for it in range(600):
+        r, c = (int(v) for v in rng.integers(1, 64, 2))
+        if it % 50 == 0:
+            r, c = int(rng.integers(65, 180)), int(rng.integers(65, 180))
+        if it % 2:                                             # what tracking produces: one small entry per matched line, the rest large
+            m = rng.uniform(0.5, 1.0, (r, c)).astype(np.float32)
+            k = int(rng.integers(0, min(r, c) + 1))
+            m[rng.permutation(r)[:k], rng.permutation(c)[:k]] = rng.uniform(0, 0.1, k).astype(np.float32)
+        else:
+            m = random_cost(rng, it, r, c).astype(np.float32)
+        thr = 1e30 if it % 3 else float(np.quantile(m[np.isfinite(m)], 0.6))   # a threshold inside the value range: clamped rows / columns
+        sr, sc = scipy_lsa(np.where(m > thr, np.float32(thr + 1e-5), m).astype(np.float64))
+        exp = np.full(r, -1, np.int32)
+        for a, b in zip(sr, sc):
+            if m[a, b] <= np.float32(thr):
+                exp[a] = b
+        got_f = device_cascade(lib, m, np.zeros_like(m), np.zeros_like(m), np.full(r, 2), np.ones(r), thr, thr, 1, stage1_only=1, counts=fast)
+        got_s = device_cascade(lib, m, np.zeros_like(m), np.zeros_like(m), np.full(r, 2), np.ones(r), thr, thr, 1, stage1_only=1, no_fast=1, counts=slow)
+        assert np.array_equal(got_f, exp) and np.array_equal(got_s, exp), (it, m.shape, thr)
+    assert slow[0] == 0 and slow[1] == 600, slow
+    assert fast[0] > 100 and fast[1] > 100, fast               # both branches exercised by the default path
+    # the reference's own thresholded-assignment fixtures, both ways
+    g = golden("assign")
+    for k in range(int(g["n_cases"])):
+        m = np.ascontiguousarray(g[f"c{k}_cost"], np.float32)
+        nr = m.shape[0]
+        for name, thr in (("cos", 0.2), ("iou", 0.7)):
+            exp = np.full(nr, -1, np.int32)
+            for a, b in g[f"c{k}_{name}_m"].reshape(-1, 2):
+                exp[a // 2] = b - 100
+            for nf in (0, 1):
+                got = device_cascade(lib, m, np.zeros_like(m), np.zeros_like(m), np.full(nr, 2), np.ones(nr), thr, thr, 1, stage1_only=1, no_fast=nf)
+                assert np.array_equal(got, exp), (k, name, nf)
 
 
 def test_device_min_cost_matching_reference_fixtures(gpu, lib, golden):
@@ -103,6 +149,108 @@ def test_device_tracker_trajectories_identical_to_reference(gpu, golden, name):
     assert worst_mean < 1e-3, worst_mean
     v = trk.tracks[0]
     assert len(v.features) == a["gallery_len"][0] and v.features[0].shape == (dim,)
+
+
+@pytest.mark.parametrize("K", [3, 8, 16])
+@pytest.mark.parametrize("name", ["traj8", "traj30", "traj100"])
+def test_reference_trajectories_through_multi_frame_epochs(gpu, golden, name, K):
+    """The reference trajectories (tests/golden/traj*.npz, generated by the imported reference: >70-frame gaps, max-age deletions,
+    births, budget-4 galleries that wrap) through REAL multi-frame epochs: aic_tracker_update_batch hands the device K frames per
+    epoch launch (calls of 2K + 1 frames: two full epochs and a ragged one), costs in LDS as in the pipeline.  Matches and output
+    rows of every frame, the whole table after every call."""
+    from golden.traj_config import TRAJ, scene_inputs
+    TC = pkg("core.tracker_core").TrackerCore
+    g = golden(name)
+    _, tk, frames, dim, _ = TRAJ[name]
+    trk = TC(**tk)
+    trk.option("epoch_frames", K)
+    nofast = K == 8                                             # one epoch length with every problem forced through the wave LSAP
+    trk.option("lsap_fast", 0 if nofast else 1)
+    worst_mean, f0 = 0.0, 0
+    while f0 < frames:
+        kk = min(2 * K + 1, frames - f0)
+        batch = []
+        for f in range(f0, f0 + kk):
+            tlwh, conf, ids, feats, has = scene_inputs(name, f)
+            batch.append((tlwh, conf, np.zeros(len(ids), np.int32), feats, has.astype(np.uint8)))
+        res = trk.update_batch(batch)
+        for i, (rows, _, matches) in enumerate(res):
+            f = f0 + i
+            k = int((g["match_tid"][f] >= 0).sum())
+            assert sorted(matches) == sorted(zip(g["match_tid"][f, :k].tolist(), g["match_det"][f, :k].tolist())), f
+            no = int(g["n_out"][f])
+            assert len(rows) == no, f
+            if no:
+                assert np.array_equal(rows[:, 4], g["out"][f, :no, 4]), f
+                assert np.abs(rows[:, :4] - g["out"][f, :no, :4]).max() <= 1, f
+        f = f0 + kk - 1
+        a = trk.export_arrays()
+        nt = int(g["n_tracks"][f])
+        assert a["track_id"].tolist() == g["tid"][f, :nt].tolist(), f
+        assert a["state"].tolist() == g["state"][f, :nt].tolist(), f
+        assert a["hits"].tolist() == g["hits"][f, :nt].tolist() and a["age"].tolist() == g["age"][f, :nt].tolist(), f
+        assert a["time_since_update"].tolist() == g["tsu"][f, :nt].tolist(), f
+        assert a["gallery_len"].tolist() == g["glen"][f, :nt].tolist(), f
+        if nt:
+            worst_mean = max(worst_mean, float(np.abs(a["mean"] - g["mean"][f, :nt]).max()))
+        f0 += kk
+    assert worst_mean < 1e-3, worst_mean
+    fast, slow = trk.assoc_counters()
+    assert (fast == 0 and slow > 0) if nofast else fast > 0, (fast, slow)   # the branch asked for is the one that decided
+
+
+@pytest.mark.parametrize("mode", ["host", "device", "batch"])
+def test_export_import_continue_equals_uninterrupted(gpu, golden, mode):
+    """aic_tracker_import_state: a fresh tracker that imports another's export at frame 40 of traj8 (galleries
+    wrapped, a featureless detection period, tracks in every state) continues exactly as the exporter: same rows, matches and
+    table on every later frame -- bit-identical Kalman state included -- and both equal the reference fixture."""
+    from golden.traj_config import TRAJ, scene_inputs
+    TC = pkg("core.tracker_core").TrackerCore
+    name = "traj8"
+    g = golden(name)
+    _, tk, frames, dim, _ = TRAJ[name]
+
+    def step(trk, f):
+        tlwh, conf, ids, feats, has = scene_inputs(name, f)
+        if mode == "batch":
+            rows, _, m = trk.update_batch([(tlwh, conf, np.zeros(len(ids), np.int32), feats, has.astype(np.uint8))])[0]
+            return rows, sorted(m)
+        trk.predict()
+        trk.update_arrays(tlwh, conf, np.zeros(len(ids), np.int32), feats, has.astype(np.uint8))
+        return trk.outputs()[0], sorted(trk.last_matches())
+
+    a = TC(**tk)
+    if mode == "device":
+        a.option("device_assoc", 1)
+    for f in range(40):
+        step(a, f)
+    st = a.export_state()
+    assert st["next_track_id"] > int(st["track_id"].max()) and st["galleries"].shape == (int(st["gallery_len"].sum()), dim)
+    b = TC(**tk)
+    if mode == "device":
+        b.option("device_assoc", 1)
+    b.import_state(st)
+    sb = b.export_state()
+    for key in ("track_id", "state", "hits", "age", "time_since_update", "cls", "gallery_len", "conf", "mean", "cov", "galleries"):
+        assert np.array_equal(st[key], sb[key]), key
+    assert sb["next_track_id"] == st["next_track_id"]
+    for f in range(40, frames):
+        ra, ma = step(a, f)
+        rb, mb = step(b, f)
+        assert np.array_equal(ra, rb) and ma == mb, f
+        k = int((g["match_tid"][f] >= 0).sum())
+        assert mb == sorted(zip(g["match_tid"][f, :k].tolist(), g["match_det"][f, :k].tolist())), f
+    ea, eb = a.export_state(), b.export_state()
+    for key in ("track_id", "state", "hits", "age", "time_since_update", "gallery_len", "mean", "cov", "galleries"):
+        assert np.array_equal(ea[key], eb[key]), key
+    nt = int(g["n_tracks"][frames - 1])
+    assert eb["track_id"].tolist() == g["tid"][frames - 1, :nt].tolist()
+    # refused imports leave the tracker as it was
+    bad = dict(st)
+    bad["next_track_id"] = 1
+    with pytest.raises(pkg("_lib").AicError):
+        b.import_state(bad)
+    assert b.export_arrays()["track_id"].tolist() == eb["track_id"].tolist()
 
 
 def test_device_and_host_association_same_costs(gpu):

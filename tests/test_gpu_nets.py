@@ -240,6 +240,23 @@ def test_reid_large_batch_kernels(gpu, engines, dtype, tol_split, tol, n_crops):
     big.close(), small.close()
 
 
+@pytest.mark.parametrize("dtype", ["fp16", "fp32"])
+def test_reid_embeddings_do_not_depend_on_the_batch(gpu, engines, dtype):
+    """A crop's embedding must not depend on how many crops shared its launch: kernel variants are chosen by batch size (ping-pong
+    patch kernels at 832 and 256, the LDS-DMA implicit GEMMs below), and every variant a layer can get walks K in the same order --
+    (channel chunk, tap) for the layer shapes the patch kernel takes (ConvArgs::k_chunk_major), (tap, channel chunk) for the rest.
+    Bit-identical rows, not a tolerance: a track's gallery must not change with the group size its frames were batched in."""
+    x = np.random.default_rng(3).standard_normal((832, 3, 128, 64)).astype(np.float32)
+    big = HipEngine(engines[1], dtype=dtype, max_items=832, warm_up=False)
+    e_big = big.reid_infer_np(x)
+    big.close()
+    for n in (256, 64, 8):
+        eng = HipEngine(engines[1], dtype=dtype, max_items=n, warm_up=False)
+        e = eng.reid_infer_np(x[:n])
+        eng.close()
+        assert np.array_equal(e, e_big[:n]), (dtype, n, float(np.abs(e - e_big[:n]).max()))
+
+
 @pytest.mark.parametrize("env", [{"AICAM_C64_BLOCK": "0"}, {"AICAM_PP_MIN": "0"}], ids=["unfused_layer1", "pp_everywhere"])
 def test_reid_large_batch_kernel_switches(gpu, engines, env):
     """Kernel choices that are read once per process, hence a child process: with the fused BasicBlock kernel off layer1 runs on

@@ -13,6 +13,7 @@ from oracle import nets_oracle as N
 pytestmark = pytest.mark.gpu
 syn = pkg("synthetic")
 config = pkg("config")
+HipEngine = pkg("hip_engine").HipEngine
 
 
 def oracle_tracks(sc, reid_eo, frames, n_frames, **trk_kw):
@@ -249,6 +250,88 @@ def test_device_epochs_equal_host_on_near_tie_scene(gpu, engines, dtype):
         for f in range(n_frames):
             assert out["dev1"][f] == out["host"][f], f
             assert out["dev2"][f] == out["host"][f], f
+    finally:
+        config.CLASSES_TO_TRACK.clear()
+        config.CLASSES_TO_TRACK.update(old)
+
+
+@pytest.mark.parametrize("assoc", [2, 0], ids=["assoc_device", "assoc_host"])
+def test_device_filter_equals_host_filter(gpu, engines, assoc):
+    """inject = 0, the detector's own boxes (texture scene, all classes tracked, a tracker floor inside the score range so that the
+    confidence AND the class filter both cut): the filter of deepsort_tracker.py:88-101 on the device behind NMS, ReID sized from a
+    device-side count, no host round trip (device_filter = 1, the default) must give the rows, the true track counts, the
+    detector outputs and the very embeddings of the filter on the host (device_filter = 0: event wait + host loop + H2D of the
+    crop list) on every frame; batch invariance of the ReID kernels (test_gpu_nets) is what makes the embeddings comparable bit
+    for bit although one path launches for the exact crop count and the other for a bound."""
+    old = set(config.CLASSES_TO_TRACK)
+    config.CLASSES_TO_TRACK.clear()
+    config.CLASSES_TO_TRACK.update(c for i, c in enumerate(config.CLASSES) if i % 3)     # a third of the classes is NOT tracked
+    try:
+        n_frames, batch = 72, 32                                  # groups of 32, 32 and a tapered tail
+        sc = syn.Scene(seed=12, n_targets=20)
+        frames = sc.render_batch(0, n_frames)
+        TP = pkg("pipeline").TrackingPipeline
+        out = {}
+        for filt in (1, 0):
+            pipe = TP(engines[0], engines[1], (720, 1280), batch=batch, ring_frames=n_frames, max_persons=64, dtype="fp16", inject=False,
+                      min_confidence=0.93, max_tracks=512)
+            pipe.option("device_assoc", assoc)
+            pipe.option("device_filter", filt)
+            pipe.upload(0, frames)
+            tracks, dets = pipe.run(0, n_frames, want_dets=True)
+            emb, cpf = pipe.group_embeddings()
+            c = pipe.counters()
+            out[filt] = (tracks, dets, emb.copy(), cpf.copy(), pipe.tracker_core.export_arrays())
+            if filt:
+                assert c["filter_device_groups"] >= 3 and c["filter_host_groups"] == 0 and c["reid_overflow_rounds"] == 0, c
+            else:
+                assert c["filter_host_groups"] >= 3 and c["filter_device_groups"] == 0, c
+            pipe.close()
+        (ta, da, ea, ca, xa), (tb, db, eb, cb, xb) = out[1], out[0]
+        assert sum(len(r) for r in tb) >= 3 and int(cb.sum()) > 0            # the scene confirms tracks and the last group has crops
+        for f in range(n_frames):
+            assert ta[f] == tb[f], f
+            for u, v in zip(da[f], db[f]):
+                assert np.array_equal(u, v), f
+        assert np.array_equal(ca, cb) and np.array_equal(ea, eb)
+        for key in ("track_id", "state", "hits", "age", "time_since_update", "gallery_len", "mean", "cov"):
+            assert np.array_equal(xa[key], xb[key]), key
+    finally:
+        config.CLASSES_TO_TRACK.clear()
+        config.CLASSES_TO_TRACK.update(old)
+
+
+def test_device_filter_crowded_groups_take_extra_reid_rounds(gpu, engines):
+    """A ReID engine whose arena (max_items 48) is far below a launch group's surviving detections (69-300 per frame, 4 frames per
+    group): the producer's bounded round covers the first 48 crops, the consumer thread -- where the counts first reach the host --
+    launches the remaining rounds; nothing is dropped (deepsort_tracker.py:104-113) and the rows are those of the host filter."""
+    old = set(config.CLASSES_TO_TRACK)
+    config.CLASSES_TO_TRACK.clear()
+    config.CLASSES_TO_TRACK.update(config.CLASSES)
+    try:
+        n_frames = 8
+        sc = syn.Scene(seed=33, n_targets=8)
+        frames = sc.render_batch(0, n_frames)
+        TP = pkg("pipeline").TrackingPipeline
+        out = {}
+        for filt in (1, 0):
+            reid = HipEngine(engines[1], dtype="fp16", max_items=48, warm_up=False)
+            pipe = TP(engines[0], reid, (720, 1280), batch=4, ring_frames=n_frames, max_persons=16, dtype="fp16", inject=False, n_init=2, max_tracks=2048)
+            pipe.option("device_filter", filt)
+            pipe.upload(0, frames)
+            nt, rows, nd = (x.copy() for x in pipe.run_raw(0, n_frames))
+            c = pipe.counters()
+            out[filt] = (nt, rows, nd, pipe.tracker_core.export_arrays())
+            if filt:
+                assert c["filter_device_groups"] == 2 and c["reid_overflow_rounds"] >= 4, c
+            pipe.close()
+            reid.close()
+        (na, ra, da, xa), (nb, rb, db, xb) = out[1], out[0]
+        assert da.min() > 50 and np.array_equal(da, db) and np.array_equal(na, nb) and nb.max() > 16
+        for f in range(n_frames):
+            assert np.array_equal(ra[f][:min(na[f], 16)], rb[f][:min(nb[f], 16)]), f
+        for key in ("track_id", "state", "hits", "age", "time_since_update", "gallery_len", "mean"):
+            assert np.array_equal(xa[key], xb[key]), key
     finally:
         config.CLASSES_TO_TRACK.clear()
         config.CLASSES_TO_TRACK.update(old)
