@@ -103,6 +103,12 @@ _SIGS = {
     "aic_pipeline_exchange_stream": (_I, [_P, _P]),
     "aic_pipeline_exchange_wait": (_I, [_P, C.c_int64, _I, _P, _P]),
     "aic_pipeline_exchange_done": (_I, [_P, C.c_int64]),
+    "aic_gallery_annotate": (_I, [_I, _P, _P, _I, _I, _I, _I, _D, _P, _P, _P, _P]),
+    "aic_gid_create": (_I, [_I, _P]),
+    "aic_gid_destroy": (_I, [_P]),
+    "aic_gid_update": (_I, [_P, _I, _I, _P, _P, _P, _D, _P]),
+    "aic_gid_lookup": (_I, [_P, _I, _I, _P]),
+    "aic_gid_size": (_I, [_P, _P, _P, _P]),
     "aic_host_register": (_I, [_P, C.c_size_t]),
     "aic_host_unregister": (_I, [_P]),
     "aic_pipeline_tracker": (_I, [_P, _P]),

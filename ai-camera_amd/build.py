@@ -14,7 +14,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libaicam.so")
-SOURCES = ["runtime.cpp", "lsap.cpp", "assoc_host.cpp", "tracker.cpp", "engine.cpp", "pipeline.cpp",
+SOURCES = ["runtime.cpp", "lsap.cpp", "assoc_host.cpp", "global_id.cpp", "tracker.cpp", "engine.cpp", "pipeline.cpp",
            "kernels_conv.hip", "kernels_conv_pp.hip", "kernels_conv_direct.hip", "kernels_conv_block.hip", "kernels_conv_c2f.hip", "kernels_elt.hip",
            "kernels_pre.hip", "kernels_det.hip", "kernels_trk.hip", "kernels_trk_dev.hip", "kernels_overlay.hip"]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-Wall",
@@ -26,6 +26,18 @@ def hipcc():
         if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
             return c
     raise RuntimeError("hipcc not found")
+
+
+def sources_digest():
+    """sha256 over the kernel / host sources the library is built from (names + bytes, sorted).  A measurement that is committed
+    as a file (profiles/pmc_traffic.json) records it; bench.py quotes that measurement only while the digest still matches."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp", ".hpp")))
+    for f in files + ["../../include/aicam.h"]:
+        h.update(f.encode())
+        h.update(open(os.path.join(CSRC, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def _stale(target, deps):

@@ -153,8 +153,13 @@ def main(argv=None):
     try:
         if args.batch > 1:
             from .pipeline import TrackingPipeline
-            pipe = TrackingPipeline(args.yolo_engine, args.reid_engine, (size[1], size[0]), batch=args.batch, ring_frames=args.batch,
-                                    max_persons=64, device=config.resolve_device(args.device), dtype=args.dtype, conf_thresh=args.conf_thresh)
+            # rows per frame = the tracker's slot capacity: a frame cannot emit more confirmed tracks than that, so nothing is ever
+            # clipped (the per-frame path and the reference, deepsort_tracker.py:126-141, emit every confirmed track)
+            from .hip_engine import HipEngine
+            dev_id = config.resolve_device(args.device)
+            reid = HipEngine(args.reid_engine, device=dev_id, dtype=args.dtype, max_items=args.batch * 64, warm_up=False)   # arena for 64 crops per frame; busier groups take more ReID rounds
+            pipe = TrackingPipeline(args.yolo_engine, reid, (size[1], size[0]), batch=args.batch, ring_frames=args.batch,
+                                    max_persons=512, max_tracks=512, device=dev_id, dtype=args.dtype, conf_thresh=args.conf_thresh)
         else:
             detector = YOLODetector(engine_path=args.yolo_engine, conf_threshold=args.conf_thresh, device=args.device, dtype=args.dtype)
     except Exception as e:   # aicamera_tracker.py:94-97
@@ -231,6 +236,9 @@ def main(argv=None):
         if writer is not None:
             writer.close()
         if pipe is not None:
+            clipped = pipe.counters()["clipped_frames"]
+            if clipped:
+                print(f"Warning: {clipped} frames had more confirmed tracks than the {pipe.max_persons} rows stored per frame.")
             pipe.close()
         if cv2 is not None and args.show_display:
             cv2.destroyAllWindows()

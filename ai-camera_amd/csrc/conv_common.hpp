@@ -394,6 +394,17 @@ __device__ __forceinline__ void xcd_tile_xy(int on, int& bx, int& by) {
     const int t = xcd_tile(lin, nbx * (int)gridDim.y, on);
     by = t / nbx, bx = t - by * nbx;
 }
+// The same when only the first nbx_live <= gridDim.x tile columns hold items (the grid was sized for a bound and the count is
+// read on the device, ConvArgs::n_dev): the live tiles are dealt to the first nbx_live * gridDim.y blocks -- XCD-contiguous runs
+// of LIVE tiles, all eight XCDs busy -- and the other blocks leave (false).  nbx_live == gridDim.x: exactly xcd_tile_xy above.
+__device__ __forceinline__ bool xcd_tile_xy_live(int on, int nbx_live, int& bx, int& by) {
+    const int lin = (int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x;
+    const int nlive = nbx_live * (int)gridDim.y;
+    if (lin >= nlive) return false;
+    const int t = xcd_tile(lin, nlive, on);
+    by = t / nbx_live, bx = t - by * nbx_live;
+    return true;
+}
 inline int xcd_map_on() {
     static const int v = getenv("AICAM_NO_XCD_MAP") == nullptr;
     return v;
@@ -412,6 +423,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
     else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
     else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
     else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if constexpr (N == 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
     else if constexpr (N == 15) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
     else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     else if constexpr (N == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");

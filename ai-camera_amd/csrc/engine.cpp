@@ -103,36 +103,47 @@ Model::Model(Device& d, const void* blob, size_t nbytes, int dtype_, int max_ite
     // ---- weights: OIHW fp32 -> [cout_pad][Kp] (kh, kw, cin) in the activation dtype
     weights.resize(nw);
     const int bke = 4 * vec;
-    for (int i = 0; i < nw; ++i) {
-        ConvWeights& w = weights[i];
-        w.cout = (int)wtab[i * 6], w.cin = (int)wtab[i * 6 + 1], w.kh = (int)wtab[i * 6 + 2], w.kw = (int)wtab[i * 6 + 3];
-        const size_t woff = (size_t)wtab[i * 6 + 4], boff = (size_t)wtab[i * 6 + 5];
-        const size_t wn = (size_t)w.cout * w.cin * w.kh * w.kw;
-        AIC_REQUIRE(woff + wn <= payload_n && boff + w.cout <= payload_n, AIC_ERR_FORMAT, "weight offsets out of range");
+    // one device weight = the output channels of one or more engine-file weights stacked (a merged conv, below)
+    struct WSrc { const float* w; const float* b; int cout; };
+    auto pack_weights = [&](ConvWeights& w, const std::vector<WSrc>& parts, int cin, int kh, int kw) {
+        w.cout = 0;
+        for (const WSrc& p : parts) w.cout += p.cout;
+        w.cin = cin, w.kh = kh, w.kw = kw;
         w.cin_eff = w.cin == 3 ? 8 : w.cin;
         AIC_REQUIRE(w.cin_eff % vec == 0, AIC_ERR_FORMAT, "conv input channels must be a multiple of 16 bytes");
         w.K = w.kh * w.kw * w.cin_eff;
         w.Kp = round_up(w.K, bke);
         w.cout_pad = round_up(w.cout, 128) + 128;
-        const float* src = payload + woff;
         // + 8 K-steps of zero slack: the conv kernel's drain iterations step the weight pointer past the last row
         std::vector<char> packed(((size_t)w.cout_pad * w.Kp + 8 * bke) * esz, 0);
-        for (int co = 0; co < w.cout; ++co)
-            for (int ci = 0; ci < w.cin; ++ci)
-                for (int ky = 0; ky < w.kh; ++ky)
-                    for (int kx = 0; kx < w.kw; ++kx) {
-                        const float v = src[(((size_t)co * w.cin + ci) * w.kh + ky) * w.kw + kx];
-                        const size_t k = (size_t)co * w.Kp + (size_t)(ky * w.kw + kx) * w.cin_eff + ci;
-                        if (dtype == AIC_F16) reinterpret_cast<uint16_t*>(packed.data())[k] = f32_to_f16_bits(v);
-                        else reinterpret_cast<float*>(packed.data())[k] = v;
-                    }
+        std::vector<float> bias(w.cout_pad, 0.f);
+        int co0 = 0;
+        for (const WSrc& p : parts) {
+            for (int co = 0; co < p.cout; ++co)
+                for (int ci = 0; ci < w.cin; ++ci)
+                    for (int ky = 0; ky < w.kh; ++ky)
+                        for (int kx = 0; kx < w.kw; ++kx) {
+                            const float v = p.w[(((size_t)co * w.cin + ci) * w.kh + ky) * w.kw + kx];
+                            const size_t k = (size_t)(co0 + co) * w.Kp + (size_t)(ky * w.kw + kx) * w.cin_eff + ci;
+                            if (dtype == AIC_F16) reinterpret_cast<uint16_t*>(packed.data())[k] = f32_to_f16_bits(v);
+                            else reinterpret_cast<float*>(packed.data())[k] = v;
+                        }
+            std::copy(p.b, p.b + p.cout, bias.begin() + co0);
+            co0 += p.cout;
+        }
         w.w.alloc(packed.size());
         HIP_CHECK(hipMemcpy(w.w.p, packed.data(), packed.size(), hipMemcpyHostToDevice));
-        std::vector<float> bias(w.cout_pad, 0.f);
-        std::copy(payload + boff, payload + boff + w.cout, bias.begin());
         w.bias.alloc(w.cout_pad);
         HIP_CHECK(hipMemcpy(w.bias.p, bias.data(), bias.size() * 4, hipMemcpyHostToDevice));
-    }
+    };
+    auto wsrc_of = [&](int i) {
+        const int cout = (int)wtab[i * 6], cin = (int)wtab[i * 6 + 1], kh = (int)wtab[i * 6 + 2], kw = (int)wtab[i * 6 + 3];
+        const size_t woff = (size_t)wtab[i * 6 + 4], boff = (size_t)wtab[i * 6 + 5];
+        AIC_REQUIRE(woff + (size_t)cout * cin * kh * kw <= payload_n && boff + cout <= payload_n, AIC_ERR_FORMAT, "weight offsets out of range");
+        return WSrc{payload + woff, payload + boff, cout};
+    };
+    for (int i = 0; i < nw; ++i)
+        pack_weights(weights[i], {wsrc_of(i)}, (int)wtab[i * 6 + 1], (int)wtab[i * 6 + 2], (int)wtab[i * 6 + 3]);
     // ---- validate ops against buffers, count FLOPs
     for (const OpDesc& o : ops) {
         const int* v = o.v;
@@ -156,6 +167,63 @@ Model::Model(Device& d, const void* blob, size_t nbytes, int dtype_, int max_ite
             }
             flops_per_item += 2.0 * db.h * db.w * (double)v[6] * v[3] * v[7] * v[8];
             ++n_convs;
+        }
+    }
+    // ---- merge: two convs that read the SAME tensor slice with the same window, stride, padding and activation and no residual
+    // (YOLOv8's detect branches: 22.box{l}.0 and 22.cls{l}.0 both start from the level's feature map) become ONE conv whose output
+    // channels are the two sets side by side in one new buffer; their readers take channel slices of it.  The map is read once
+    // instead of twice and the GEMM is 144 wide instead of 64 and 80.  Per output channel nothing changes (same K order, same
+    // epilogue): the head is bit-identical (tests/test_gpu_nets.py::test_merged_detect_branch_heads).  AICAM_NO_MERGE=1: off.
+    if (dtype == AIC_F16 && !getenv("AICAM_NO_MERGE") && !getenv("AICAM_NO_FUSE")) {
+        for (size_t i = 0; i < ops.size(); ++i) {
+            int* c = ops[i].v;
+            if (c[0] != OP_CONV || c[14] != 0 || ops[i].fuse || c[15] >= nw) continue;
+            for (size_t j = i + 1; j < ops.size() && j <= i + 8; ++j) {
+                int* p = ops[j].v;
+                if (p[0] != OP_CONV || p[14] != 0 || ops[j].fuse || p[15] >= nw) continue;
+                bool same = p[1] == c[1] && p[2] == c[2] && p[3] == c[3];
+                for (int k = 7; k <= 11; ++k) same = same && p[k] == c[k];
+                const int di = c[4], dj = p[4];
+                if (!same || di == dj || c[5] != 0 || p[5] != 0 || c[7] != 3) continue;
+                const BufDesc bi = bufs[di], bj = bufs[dj];
+                if (bi.f32 || bj.f32 || bi.c != c[6] || bj.c != p[6] || bi.h != bj.h || bi.w != bj.w || (c[6] % vec) || (p[6] % vec)) continue;
+                bool clash = false;                     // the second conv now runs at the first one's place: nobody may touch its output in between,
+                for (size_t k = 0; k < ops.size(); ++k) {   // and nobody else may write either buffer
+                    const int* u = ops[k].v;
+                    if (k != i && k != j && (u[4] == di || u[4] == dj)) clash = true;
+                    if (k > i && k < j && (u[1] == dj || (u[0] == OP_CONV && u[14] && u[12] == dj))) clash = true;
+                }
+                for (auto& o : outs)
+                    if (o.v[0] == di || o.v[0] == dj || (kind == KIND_YOLO && (o.v[1] == di || o.v[1] == dj))) clash = true;
+                if (clash) continue;
+                // new buffer and weight
+                BufDesc nb = bi;
+                nb.c = c[6] + p[6];
+                nb.per_item = (size_t)nb.h * nb.w * nb.c * nb.esize;
+                storage.emplace_back();
+                storage.back().alloc(nb.per_item * max_items + 256);
+                HIP_CHECK(hipMemsetAsync(storage.back().p, 0, storage.back().n, d.s_main));
+                nb.p = storage.back().p;
+                bufs.push_back(nb);
+                const int m = (int)bufs.size() - 1;
+                weights.emplace_back();
+                pack_weights(weights.back(), {wsrc_of(c[15]), wsrc_of(p[15])}, c[3], c[7], c[8]);
+                const int ci_out = c[6];
+                for (auto& o : ops) {                   // readers of either output: slices of the merged buffer
+                    int* u = o.v;
+                    if (u[1] == di) u[1] = m;
+                    else if (u[1] == dj) { u[1] = m; u[2] += ci_out; }
+                    if (u[0] == OP_CONV && u[14]) {
+                        if (u[12] == di) u[12] = m;
+                        else if (u[12] == dj) { u[12] = m; u[13] += ci_out; }
+                    }
+                }
+                c[4] = m, c[5] = 0, c[6] = nb.c, c[15] = (int)weights.size() - 1;
+                ops[j].fuse = 2;                        // absorbed: run_range skips it
+                storage[di].release(), storage[dj].release();      // (nobody reads the two old buffers any more)
+                bufs[di].p = bufs[dj].p = nullptr;
+                break;
+            }
         }
     }
     // ---- fusion: conv3x3/1 (3->64)+ReLU followed by max-pool 3x3/2 of exactly that tensor (ReID stem)

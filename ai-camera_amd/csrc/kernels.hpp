@@ -24,12 +24,17 @@ struct ConvArgs {
     unsigned tap_rows;  // bit kh*KW set for kh < KH (replication pattern of the tap-validity mask)
     const void* zero;   // 64 bytes of zeros in HBM: LDS-DMA source for padded / out-of-range chunks
     int xcd_map;        // 1: blocks take tiles through xcd_tile() (set by launch_conv_igemm)
+    const float* bias_init;   // non-NULL (k_order 2 only): the accumulators START from this bias and `bias` points at zeros -- the
+                              // weights-resident kernels add their products onto the bias, (bias + sum) and (sum + bias) round differently
     const int* n_dev;   // optional DEVICE-side item count (images / crops of this launch): M then is only an upper bound the grid was sized
                         // for, and tiles past n_dev[0] * Ho * Wo leave at once (ReID behind the on-device detection filter, where the
                         // host does not know the count when it launches).  NULL: M is exact
-    int k_chunk_major;  // 1: K is walked (channel chunk, tap) instead of (tap, channel chunk): the order of the ping-pong patch kernel.
-                        // Set by launch_conv_igemm for every layer SHAPE that kernel can take, so that such a layer accumulates in
-                        // the same order whichever kernel its batch size selects (embeddings do not depend on the batch)
+    int k_order;        // order in which the K-steps (tap row kh, tap column kw, channel chunk cc) are accumulated:
+                        //   0 = (kh, kw, cc)  tap-major, the memory order of the packed weights (default);
+                        //   1 = (cc, kh, kw)  the order of the ping-pong patch kernel (conv3x3_pp_patch_kernel);
+                        //   2 = (kw, cc, kh)  the order of the weights-resident 64-channel kernels (conv3x3_c64_resident / _block).
+                        // Set by launch_conv_igemm from the layer SHAPE: a layer one of those kernels can take is accumulated in that
+                        // kernel's order by EVERY kernel its batch size may select, so embeddings do not depend on the batch
     // ---- optional 1x1 "tail" conv run in this conv's epilogue (fp16 only; conv_tail_supported()).  This conv's own output
     // (SiLU(acc + bias) rounded to fp16, exactly what it would have stored) never leaves the registers: it is the B operand of
     // the tail's MFMAs.  y / y_cs / y_coff of THIS conv are then unused.  w_tail == NULL: no tail.
@@ -179,6 +184,8 @@ void launch_trk_epoch(DevTrkHdr* hdr, DevTrack* trk, int* free_slots, float* mea
                       const TrkDevParams& prm, const EpochDets& dets, int f0, int k, int d_begin, int dn_pad, int nmax, int has_sm,
                       const EpochScratch& scr, const EpochOut& out, hipStream_t s);
 void launch_gallery_shard(const DevTrkHdr* hdr, const DevTrack* trk, const float* gal_n, int gmax, int dim, float* out, int t_max, hipStream_t s);
+// configs[4] annotation pass: gathered [world, t_max, 2 + dim] -> per row (all ranks) track id or -1, nearest valid row of another rank or -1, its cosine distance
+void launch_gallery_nearest(const float* gathered, int world, int t_max, int dim, int* ids, int* near_row, float* near_dist, hipStream_t s);
 void launch_trk_cascade_test(const TrkDevParams& prm, const EpochScratch& scr, int T, int n, const int* state, const int* tsu,
                              int* out_mdet, int* out_err, int stage1_only, hipStream_t s);
 

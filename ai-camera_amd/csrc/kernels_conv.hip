@@ -242,12 +242,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const Conv
     const int lane = t & 63, wv = t >> 6;
     const int slot = t & 3, r0 = t >> 2;
     const int kc = slot ^ lds_swz(r0);         // K-chunk this thread fetches (source-side swizzle)
+    const int M = a.n_dev ? min(a.M, a.n_dev[0] * (a.Ho * a.Wo)) : a.M;     // device-side item count: the grid was sized for a bound
     int tbx, tby;
-    xcd_tile_xy(a.xcd_map, tbx, tby);
+    if (!xcd_tile_xy_live(a.xcd_map, (M + BM - 1) / BM, tbx, tby)) return;
     const int m0 = tbx * BM;
     const int n0 = tby * BN;
-    const int M = a.n_dev ? min(a.M, a.n_dev[0] * (a.Ho * a.Wo)) : a.M;     // device-side item count: the grid was sized for a bound
-    if (m0 >= M) return;
 
     const T* __restrict__ xg = reinterpret_cast<const T*>(a.x);
     const T* __restrict__ wg = reinterpret_cast<const T*>(a.w);
@@ -290,6 +289,16 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const Conv
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+    if (a.bias_init) {                         // bias first (ConvArgs::bias_init): the epilogue's `bias` is a page of zeros
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            floatx4 b;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) b[e] = a.bias_init[n0 + wn * NT * 16 + perm_ch<NT>(j, q, e)];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) acc[i][j] = b;
+        }
+    }
 
     // LDS offsets of this lane's operand chunks inside a stage (stage base added as an immediate below)
     int xoff[MT], woff[NT];
@@ -324,7 +333,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const Conv
             winc[j] = okr ? BKE : 0;
         }
         int tap = 0, kh = 0, kw = 0, cc = 0;
-        const bool cmaj = a.k_chunk_major != 0;    // K walked (channel chunk, tap): the source pointers are rebuilt every step
+        const int kord = a.k_order;                 // != 0: K-steps in another order than memory's, source pointers rebuilt every step
+        const bool cmaj = kord != 0;
         auto set_tap = [&] {
             const long toff = ((long)kh * a.W + kw) * a.x_cs + kc * CH + (cmaj ? cc * BKE : 0);
 #pragma unroll
@@ -350,9 +360,13 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const Conv
                     asm volatile("" : "+v"(src));
                     __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sbase + BM * 64 + j * (RP * 64)), 16, 0, 0);
                 }
-                ++tap;
-                if (++kw == a.KW) { kw = 0; ++kh; }
-                if (tap == ntap) { tap = 0, kh = 0, kw = 0; ++cc; }
+                if (kord == 1) {                        // (cc, kh, kw)
+                    if (++kw == a.KW) { kw = 0; if (++kh == a.KH) { kh = 0; ++cc; } }
+                } else {                                // (kw, cc, kh)
+                    if (++kh == a.KH) { kh = 0; if (++cc == csteps) { cc = 0; ++kw; } }
+                    if (kw == a.KW) { kw = 0; cc = csteps; }          // past the last step: zero page from here on
+                }
+                tap = kh * a.KW + kw;
                 set_tap();
                 return;
             }
@@ -479,7 +493,12 @@ static void launch_variant(const ConvArgs& a, hipStream_t s) {
 }
 
 template <typename T>
-static void launch_conv_t(const ConvArgs& a, hipStream_t s) {
+static void launch_conv_t(const ConvArgs& a_in, hipStream_t s) {
+    ConvArgs a = a_in;
+    if (a.k_order == 2) {                      // the order AND the bias placement of the weights-resident kernels (Cout = 64: one 256-byte zero page covers the epilogue's reads)
+        a.bias_init = a.bias;
+        a.bias = reinterpret_cast<const float*>(a.zero);
+    }
     const int c = a.Cout;
     constexpr int DT = sizeof(T) == 2 ? AIC_F16 : AIC_F32;
     if (conv_impl() == 2 && conv_try_pp_patch(DT, a, s)) return;
@@ -492,6 +511,13 @@ static void launch_conv_t(const ConvArgs& a, hipStream_t s) {
         else if (conv_impl() == 2 && (blocks128 / 2) * ceil_div(c, 128) >= 384) launch_dma<T, 4, 4, 4, 2, 3>(a, s);   // 8 waves: 256 px x 128 ch
         else if (blocks128 * ceil_div(c, 128) >= 128) launch_variant<T, 4, 4, 2, 2>(a, s);   // 128 px x 128 ch
         else launch_variant<T, 2, 2, 2, 2>(a, s);                                       // 64 px x 64 ch (small maps)
+    } else if (c == 144 && conv_impl() == 2 && sizeof(T) == 2) {
+        // the merged first convs of a YOLOv8 detect level (64 box + 80 class channels, Model::Model; fp16 only): one 144-wide tile,
+        // the map is read once.  4 waves, one per SIMD: 36 accumulator tiles per wave on the 256-pixel tile need the whole register file
+        if constexpr (sizeof(T) == 2) {
+            if (ceil_div(a.M, 256) >= 512) launch_dma<T, 4, 9, 4, 1, 4>(a, s);          // 256 px x 144 ch
+            else launch_dma<T, 2, 9, 4, 1, 4>(a, s);                                    // 128 px x 144 ch
+        }
     } else if (c % 80 == 0) {
         // YOLOv8's class branches (Cout = nc = 80).  512 px x 80 ch on 8 waves once there are tiles for every CU:
         // 428 -> 499 TFLOP/s on cls0.1 (80 -> 80, 3x3 at 80 x 80), +7..16 % on the others (tools/conv_bench.py); AICAM_C80=0: off
@@ -540,7 +566,15 @@ void launch_conv_igemm(int dtype, const ConvArgs& a0, hipStream_t s) {
     ConvArgs a = a0;
     a.xcd_map = xcd_map_on();
     static const bool tap_major_everywhere = getenv("AICAM_K_TAP_MAJOR") != nullptr;   // A/B: the pre-round-3 behaviour (batch-dependent bits)
-    a.k_chunk_major = (conv_impl() == 2 && !tap_major_everywhere && conv_pp_patch_shape(dtype, a)) ? 1 : 0;
+    a.k_order = 0;
+    if (conv_impl() == 2 && !tap_major_everywhere) {
+        // the 64-channel weights-resident kernels (fp16): any 3x3 / 1 / 1 layer with Cin = Cout = 64 whose map they tile
+        // (ReLU, with or without the BasicBlock's residual: the only forms those kernels have)
+        const bool c64 = dtype == AIC_F16 && a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.Cin == 64 && a.Cout == 64 && a.Kp == 576 &&
+                         a.act == 2 && a.res_mode <= 1 && !a.out_f32 && !a.w_tail &&
+                         a.Ho == a.H && a.Wo == a.W && ((a.W % 32 == 0 && a.H % 8 == 0) || (a.W == 32 && a.H % 4 == 0));
+        a.k_order = conv_pp_patch_shape(dtype, a) ? 1 : (c64 ? 2 : 0);
+    }
     if (a.w_tail) {
         AIC_REQUIRE(dtype == AIC_F16 && (a.Cout == 64 || a.Cout == 80) && a.act == 1 && a.res_mode == 0, AIC_ERR_INVALID,
                     "conv with a 1x1 tail: unsupported lead (check conv_tail_supported before setting w_tail)");

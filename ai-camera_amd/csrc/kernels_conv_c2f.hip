@@ -28,7 +28,28 @@ namespace {
 constexpr int TH = 8, TW = 32;
 constexpr int XR = TH + 4, XC = TW + 4;          // 12 x 36: cv1 region
 constexpr int TR = TH + 2, TC = TW + 2;          // 10 x 34: m.cv1 region
-constexpr int PX = XR * XC * 16, PT = TR * TC * 16, PY = TH * TW * 16;      // bytes of one 8-channel plane of X / Y0, T, Y1
+// bytes of one 8-channel plane of X / Y0, T, Y1.  Every plane pitch is a multiple of 256 bytes (all 64 banks): a ds_read_b128 lane group
+// mixes lanes of two planes (q and q + 1), and with equal bank phases the 16 pixels it covers fall on 16 disjoint bank quads.  T's
+// natural pitch (10 x 34 x 16 = 5 440 B = 16 banks off) put the two planes' pixels on top of each other: 2-way conflicts on every
+// tap read of m.cv2 (SQ_LDS_BANK_CONFLICT 48 % of the kernel's LDS cycles in round 2).
+#ifdef AICAM_C2F_OLD_LAYOUT
+constexpr int PX = XR * XC * 16, PT = TR * TC * 16, PY = TH * TW * 16;
+#else
+constexpr int PX = XR * XC * 16, PT = (TR * TC * 16 + 255) / 256 * 256, PY = TH * TW * 16;
+#endif
+static_assert(PX % 256 == 0 && PY % 256 == 0, "plane pitch");
+// X is written by S1 four planes of a pixel at a time (consecutive lanes = the four 16-byte channel groups of one pixel: a coalesced
+// 64-byte global read) -- with equal bank phases that is a 4-way store conflict.  Plane g therefore keeps pixel p in slot
+// p ^ 2g (inside its aligned group of 8): a store group (2 pixels x 4 planes) hits 8 distinct slots, and a read of 16 consecutive
+// pixels of plane q (S2) still covers the same aligned 16 slots, each once.
+__device__ __forceinline__ int x_slot(int p, int g) {
+#ifdef AICAM_C2F_OLD_LAYOUT
+    return p;
+#else
+    return (p & ~7) | ((p & 7) ^ (2 * g));
+#endif
+}
+static_assert((XR * XC) % 8 == 0, "swizzle group");
 constexpr int LDS_X = 0, LDS_Y0 = 4 * PX, LDS_T = LDS_Y0 + 4 * PX, LDS_Y1 = LDS_T + 2 * PT;
 constexpr int LDS_BYTES = LDS_Y1 + 2 * PY;
 
@@ -59,7 +80,7 @@ __global__ __launch_bounds__(256) void c2f16_fused_kernel(const C2fArgs a, int t
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
         if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
             v = *reinterpret_cast<const uint4*>(xg + ((size_t)iy * a.W + ix) * a.x_cs + g * 8);
-        *reinterpret_cast<uint4*>(smem + LDS_X + g * PX + p * 16) = v;
+        *reinterpret_cast<uint4*>(smem + LDS_X + g * PX + x_slot(p, g) * 16) = v;
     }
     // weights as A fragments
     half8 w1[2], w2[5], w3[5], w4[2][2];
@@ -84,7 +105,7 @@ __global__ __launch_bounds__(256) void c2f16_fused_kernel(const C2fArgs a, int t
     // ---- S2: cv1 on the 12 x 36 region (27 tiles of 16 pixels): Y0 = SiLU(W1 x + b1), zero outside the image
     for (int tile = wv; tile < (XR * XC) / 16; tile += 4) {
         const int p = tile * 16 + r;
-        const half8 xb = *reinterpret_cast<const half8*>(smem + LDS_X + q * PX + p * 16);
+        const half8 xb = *reinterpret_cast<const half8*>(smem + LDS_X + q * PX + x_slot(p, q) * 16);
         const int pr = p / XC, pc = p - pr * XC;
         const bool inside = (unsigned)(oy0 - 2 + pr) < (unsigned)a.H && (unsigned)(ox0 - 2 + pc) < (unsigned)a.W;
 #pragma unroll

@@ -405,7 +405,9 @@ template <int CPP> __device__ __forceinline__ int patch_swz(int p) { return CPP 
 //  * taps, chunks and ring stages are fully unrolled; the weight stream is a pointer increment.
 // VALU per MFMA drops from ~12 to <1 (SQ_INSTS_VALU / SQ_INSTS_MFMA, profiles/).
 // TAIL: a 1x1 conv (a.w_tail) runs in the epilogue on the tile in registers (tail_1x1, conv_common.hpp).
-template <typename T, int MT, int NT, int WM, int WN, int TH, int TW, int NSTAGE, int LGCPP, bool TAIL = false>
+// KORD: 0 = K-steps in memory order (kh, kw, cc); 2 = (kw, cc, kh), the accumulation order of the weights-resident 64-channel
+// kernels (ConvArgs::k_order): the same layer then gives the same bits below and above their batch threshold.
+template <typename T, int MT, int NT, int WM, int WN, int TH, int TW, int NSTAGE, int LGCPP, bool TAIL = false, int KORD = 0>
 __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(const ConvArgs a, int tiles_x, int tiles_y) {
     constexpr int CH = 16 / (int)sizeof(T);
     constexpr int BKE = 4 * CH;
@@ -429,13 +431,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(const ConvA
 
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     int bx, tby;
-    xcd_tile_xy(a.xcd_map, bx, tby);
+    if (!xcd_tile_xy_live(a.xcd_map, a.n_dev ? min((int)gridDim.x, a.n_dev[0] * tiles_x * tiles_y) : (int)gridDim.x, bx, tby)) return;   // device-side item count: the grid was sized for a bound
     const int tx = bx % tiles_x; bx /= tiles_x;
     const int ty = bx % tiles_y;
     const int img = bx / tiles_y;
     const int oy0 = ty * TH, ox0 = tx * TW;
     const int n0 = tby * BN;
-    if (a.n_dev && img >= a.n_dev[0]) return;               // device-side item count: the grid was sized for a bound
 
     const T* __restrict__ wg = reinterpret_cast<const T*>(a.w);
     const T* zero = reinterpret_cast<const T*>(a.zero);
@@ -462,11 +463,16 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(const ConvA
     const T* wptr = wrow_ok ? wg + (size_t)(n0 + r0) * a.Kp + kc * CH : zero;
     const int winc = wrow_ok ? BKE : 0;
     char* wdst = ring + (16 * wv) * 64;
+    // step s of the walk -> (kh, kw, cc) and the K-step's position in the packed weights (memory order is (kh, kw, cc))
+    auto step_kh = [](int s) constexpr { return KORD == 2 ? s % 3 : s / (3 * CSTEPS); };
+    auto step_kw = [](int s) constexpr { return KORD == 2 ? s / (3 * CSTEPS) : (s / CSTEPS) % 3; };
+    auto step_cc = [](int s) constexpr { return KORD == 2 ? (s / 3) % CSTEPS : s % CSTEPS; };
+    auto step_mem = [=](int s) constexpr { return (step_kh(s) * 3 + step_kw(s)) * CSTEPS + step_cc(s); };
 #pragma unroll
     for (int st = 0; st < NSTAGE - 1; ++st) {
-        __builtin_amdgcn_global_load_lds((gptr_t)wptr, (lptr_t)(wdst + st * WSTAGE), 16, 0, 0);
-        wptr += winc;
+        __builtin_amdgcn_global_load_lds((gptr_t)(wptr + step_mem(st) * winc), (lptr_t)(wdst + st * WSTAGE), 16, 0, 0);
     }
+    const T* wnext = wptr + (NSTAGE - 1) * winc;            // memory order (KORD 0): the stream is a pointer increment
 
     const int wm = wv / WN, wn = wv % WN;
     const int q = lane >> 4, r = lane & 15;
@@ -493,32 +499,40 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(const ConvA
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (KORD == 2) {                 // bias first (ConvArgs::bias_init): the epilogue's `bias` is a page of zeros
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            floatx4 b;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) b[e] = a.bias_init[n0 + wn * NT * 16 + perm_ch<NT>(j, q, e)];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) acc[i][j] = b;
+        }
+    }
 
     typedef typename Frag<T>::type frag_t;
 #pragma unroll
-    for (int kh = 0; kh < 3; ++kh) {
-#pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-#pragma unroll
-            for (int cc = 0; cc < CSTEPS; ++cc) {
-                constexpr int dummy = 0; (void)dummy;
-                const int step = (kh * 3 + kw) * CSTEPS + cc;       // compile-time after unrolling
-                const int cur = step % NSTAGE, nxt = (step + NSTAGE - 1) % NSTAGE;
-                wait_vmcnt<(NSTAGE - 2) * B_PER>();
-                __builtin_amdgcn_s_barrier();
-                {   // refill the stage that step-1 released (zero page once the real K-steps are exhausted)
-                    const T* src = (step + NSTAGE - 1 < NSTEPS) ? wptr : zero;
-                    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(wdst + nxt * WSTAGE), 16, 0, 0);
-                    wptr += winc;
-                }
-                frag_t xf[MT], wf[NT];
-#pragma unroll
-                for (int i = 0; i < MT; ++i) xf[i] = *reinterpret_cast<const frag_t*>(smem + xaddr[kw][cc][i] + kh * ROWB);
-#pragma unroll
-                for (int j = 0; j < NT; ++j) wf[j] = *reinterpret_cast<const frag_t*>(smem + woff[j] + cur * WSTAGE);
-                mma_tiles<T, MT, NT>(acc, wf, xf);
+    for (int step = 0; step < NSTEPS; ++step) {                     // fully unrolled: kh / kw / cc / ring stages are compile-time
+        const int kh = step_kh(step), kw = step_kw(step), cc = step_cc(step);
+        const int cur = step % NSTAGE, nxt = (step + NSTAGE - 1) % NSTAGE;
+        wait_vmcnt<(NSTAGE - 2) * B_PER>();
+        __builtin_amdgcn_s_barrier();
+        {   // refill the stage that step-1 released (zero page once the real K-steps are exhausted)
+            const T* src = zero;
+            if constexpr (KORD == 0) {
+                if (step + NSTAGE - 1 < NSTEPS) src = wnext;
+                wnext += winc;
+            } else {
+                if (step + NSTAGE - 1 < NSTEPS) src = wptr + step_mem(step + NSTAGE - 1 < NSTEPS ? step + NSTAGE - 1 : 0) * winc;
             }
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(wdst + nxt * WSTAGE), 16, 0, 0);
         }
+        frag_t xf[MT], wf[NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) xf[i] = *reinterpret_cast<const frag_t*>(smem + xaddr[kw][cc][i] + kh * ROWB);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) wf[j] = *reinterpret_cast<const frag_t*>(smem + woff[j] + cur * WSTAGE);
+        mma_tiles<T, MT, NT>(acc, wf, xf);
     }
     wait_vmcnt<0>();
 
@@ -537,7 +551,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(const ConvA
     }
 }
 
-template <typename T, int MT, int NT, int WM, int WN, int TH, int TW, int NSTAGE, int LGCPP, bool TAIL = false>
+template <typename T, int MT, int NT, int WM, int WN, int TH, int TW, int NSTAGE, int LGCPP, bool TAIL = false, int KORD = 0>
 static bool launch_patch(const ConvArgs& a, hipStream_t s) {
     constexpr int CH = 16 / (int)sizeof(T), NTHR = 64 * WM * WN, RP = NTHR / 4;
     constexpr int BN = WN * NT * 16, BNP = (BN + RP - 1) / RP * RP;
@@ -548,7 +562,7 @@ static bool launch_patch(const ConvArgs& a, hipStream_t s) {
     if (a.Cin != CPP * CH) return false;
     const int tiles_x = ceil_div(a.Wo, TW), tiles_y = ceil_div(a.Ho, TH);
     const int n_img = a.M / (a.Ho * a.Wo);
-    auto kfn = conv3x3_patch_kernel<T, MT, NT, WM, WN, TH, TW, NSTAGE, LGCPP, TAIL>;
+    auto kfn = conv3x3_patch_kernel<T, MT, NT, WM, WN, TH, TW, NSTAGE, LGCPP, TAIL, KORD>;
     static bool attr = false;
     if (lds > 64 * 1024 && !attr) {
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -570,7 +584,12 @@ static bool try_patch(const ConvArgs& a, hipStream_t s) {
     static const bool c32 = getenv("AICAM_NO_PATCH_C32") == nullptr;   // Cin = Cout = 32 (YOLOv8n P3 bottlenecks): 244 -> 460 TFLOP/s
     if (off || a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.Wo < 16 || a.Ho < 8) return false;
     if (a.M < 200000 && !all) return false;
+    if (a.k_order == 1) return false;                                       // (cc, kh, kw): only the implicit-GEMM kernels walk K that way
     const bool wide = a.Wo % 32 == 0 || (a.Wo % 16 != 0 && a.Wo >= 32);   // 8 x 32 tiles unless 16 x 16 tiles cover the map exactly
+    if (a.k_order == 2) {                                                   // fp16, Cin = Cout = 64, W % 32 == 0 (launch_conv_igemm): the resident kernels' order
+        if constexpr (sizeof(T) == 2) return a.Cout == 64 && wide && launch_patch<T, 4, 4, 4, 1, 8, 32, 3, 3, false, 2>(a, s);
+        return false;
+    }
     if (a.Cout == 64) {
         constexpr int LG64 = sizeof(T) == 2 ? 3 : 4;    // Cin = 64: 8 chunks (fp16) / 16 chunks (fp32) per pixel
         if (wide) return launch_patch<T, 4, 4, 4, 1, 8, 32, 3, LG64>(a, s);
@@ -587,7 +606,7 @@ static bool try_patch(const ConvArgs& a, hipStream_t s) {
 // the Cout = 64 patch kernel with a 1x1 tail (same eligibility as try_patch)
 bool conv_try_patch_tail(const ConvArgs& a, hipStream_t s) {
     static const bool off = getenv("AICAM_NO_PATCH") != nullptr;
-    if (off || a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.Wo < 16 || a.Ho < 8 || a.M < 200000 || a.Cout != 64) return false;
+    if (off || a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.Wo < 16 || a.Ho < 8 || a.M < 200000 || a.Cout != 64 || a.k_order != 0) return false;
     const bool wide = a.Wo % 32 == 0 || (a.Wo % 16 != 0 && a.Wo >= 32);
     if (wide) return launch_patch<half_t, 4, 4, 4, 1, 8, 32, 3, 3, true>(a, s);
     return launch_patch<half_t, 4, 4, 4, 1, 16, 16, 3, 3, true>(a, s);

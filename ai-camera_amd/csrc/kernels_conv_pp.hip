@@ -45,13 +45,12 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(const ConvArgs a) {
     const int lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
     const int slot = t & 3, r0 = t >> 2;
     const int kc = slot ^ lds_swz(r0);
+    const int M = a.n_dev ? min(a.M, a.n_dev[0] * (a.Ho * a.Wo)) : a.M;     // device-side item count: the grid was sized for a bound
     int tbx, tby;
-    xcd_tile_xy(a.xcd_map, tbx, tby);
+    if (!xcd_tile_xy_live(a.xcd_map, (M + BM - 1) / BM, tbx, tby)) return;
     const int m0 = tbx * BM;
     const int n0 = tby * BN;
     const bool late = wv >= 4;
-    const int M = a.n_dev ? min(a.M, a.n_dev[0] * (a.Ho * a.Wo)) : a.M;     // device-side item count: the grid was sized for a bound
-    if (m0 >= M) return;
 
     const T* __restrict__ xg = reinterpret_cast<const T*>(a.x);
     const T* __restrict__ wg = reinterpret_cast<const T*>(a.w);
@@ -114,7 +113,8 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(const ConvArgs a) {
         winc[j] = okr ? BKE : 0;
     }
     int tap = 0, kh = 0, kw = 0, cc = 0;
-    const bool cmaj = a.k_chunk_major != 0;    // K walked (channel chunk, tap): the source pointers are rebuilt every step
+    const int kord = a.k_order;                 // != 0: K-steps in another order than memory's, source pointers rebuilt every step
+    const bool cmaj = kord != 0;
     auto set_tap = [&] {
         const long toff = ((long)kh * a.W + kw) * a.x_cs + kc * CH + (cmaj ? cc * BKE : 0);
 #pragma unroll
@@ -140,9 +140,13 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(const ConvArgs a) {
                 asm volatile("" : "+v"(src));
                 __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sbase + BM * 64 + j * (RP * 64)), 16, 0, 0);
             }
-            ++tap;
-            if (++kw == a.KW) { kw = 0; ++kh; }
-            if (tap == ntap) { tap = 0, kh = 0, kw = 0; ++cc; }
+            if (kord == 1) {                        // (cc, kh, kw)
+                if (++kw == a.KW) { kw = 0; if (++kh == a.KH) { kh = 0; ++cc; } }
+            } else {                                // (kw, cc, kh)
+                if (++kh == a.KH) { kh = 0; if (++cc == csteps) { cc = 0; ++kw; } }
+                if (kw == a.KW) { kw = 0; cc = csteps; }          // past the last step: zero page from here on
+            }
+            tap = kh * a.KW + kw;
             set_tap();
             return;
         }
@@ -301,15 +305,14 @@ __global__ __launch_bounds__(512) void conv3x3_pp_patch_kernel(const ConvArgs a,
     const int t = threadIdx.x;
     const int lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
     const bool late = wv >= 4;
+    const int n_img = a.n_dev ? min(a.M / (a.Ho * a.Wo), a.n_dev[0]) : a.M / (a.Ho * a.Wo);     // device-side item count: the grid was sized for a bound
     int bx, tby;
-    xcd_tile_xy(a.xcd_map, bx, tby);
+    if (!xcd_tile_xy_live(a.xcd_map, ((n_img + NI - 1) / NI) * tiles_x * tiles_y, bx, tby)) return;
     const int tx = bx % tiles_x; bx /= tiles_x;
     const int ty = bx % tiles_y;
     const int img0 = (bx / tiles_y) * NI;
     const int oy0 = ty * TH, ox0 = tx * TW;
     const int n0 = tby * BN;
-    const int n_img = a.n_dev ? min(a.M / (a.Ho * a.Wo), a.n_dev[0]) : a.M / (a.Ho * a.Wo);     // device-side item count: the grid was sized for a bound
-    if (img0 >= n_img) return;
 
     const T* __restrict__ xg = reinterpret_cast<const T*>(a.x);
     const T* __restrict__ wg = reinterpret_cast<const T*>(a.w);
@@ -493,7 +496,7 @@ static int ppp_mode() {
     return mode;
 }
 // The layer SHAPES this kernel takes (a property of the graph, not of the batch): 1 = Cout 64 tile, 2 = Cout 128, 3 = Cout % 256 on
-// 16 x 8 tiles, 4 = on 8 x 4 tiles; 0 = not one of them.  Such a layer is walked chunk-major by EVERY conv kernel (ConvArgs::k_chunk_major).
+// 16 x 8 tiles, 4 = on 8 x 4 tiles; 0 = not one of them.  Such a layer is walked chunk-major by EVERY conv kernel (ConvArgs::k_order = 1).
 template <typename T>
 static int pp_patch_shape(const ConvArgs& a) {
     constexpr int BKE = 64 / (int)sizeof(T);
@@ -538,7 +541,9 @@ template <typename T>
 static bool try_pp(const ConvArgs& a, hipStream_t s) {
     static const bool pp = getenv("AICAM_NO_PP") == nullptr;
     static const int pp_min = [] { const char* e = getenv("AICAM_PP_MIN"); return e ? atoi(e) : 200; }();
-    static const int pp128_k = [] { const char* e = getenv("AICAM_PP128_K"); return e ? atoi(e) : 32; }();
+    // 18 K-steps: ReID layer2.0.conv1 (3x3 / 2, 64 -> 128, K = 576) takes the 512 x 128 ping-pong tile: 1 058 -> 948 us per 7 680 crops
+    // against the 8-wave 256 x 128 LDS-DMA tile (tools/conv_bench.py 64 32 64 128 3 7680 1 0 2); below that the short loop loses
+    static const int pp128_k = [] { const char* e = getenv("AICAM_PP128_K"); return e ? atoi(e) : 18; }();
     constexpr int BKE_ = 64 / (int)sizeof(T);
     const int c = a.Cout;
     if (!pp || a.Cin % BKE_ != 0 || !(a.Kp >= 16 * BKE_ || pp_min == 0)) return false;

@@ -1182,6 +1182,65 @@ __global__ __launch_bounds__(TRK_DEV_TMAX) void gallery_shard_kernel(const DevTr
     }
 }
 
+// ------------------------------------------------------------------------------------------------ cross-camera nearest neighbours
+// configs[4] annotation pass ("an extra cosine_min_gallery pass") on the all-gathered shards, fp32
+// [world, t_max, 2 + dim] = (valid, track id, unit embedding).  One block per row i of ANY rank (every rank computes the whole
+// table, so the global-id policy of global_id.cpp needs no second exchange): distance max(0, 1 - <e_i, e_j>) (matching.py:136-141)
+// to every valid row j of another rank, the products summed k-ascending in fp32 with separate multiply and add (-ffp-contract=off):
+// d(i, j) and d(j, i) are the same bits on every rank.  Output: the nearest such row (ties: the lowest row), or -1.
+__global__ __launch_bounds__(256) void gallery_nearest_kernel(const float* __restrict__ g, int world, int t_max, int dim,
+                                                              int* __restrict__ ids, int* __restrict__ near_row, float* __restrict__ near_dist) {
+    extern __shared__ float s_e[];                       // [dim] row i
+    __shared__ unsigned long long s_best[4];
+    const int i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int w = 2 + dim, n = world * t_max, ri = i / t_max;
+    const float* gi = g + (size_t)i * w;
+    const bool valid_i = gi[0] > 0.5f;
+    if (tid == 0) ids[i] = valid_i ? (int)gi[1] : -1;
+    if (!valid_i) {                                       // block-uniform
+        if (tid == 0) { near_row[i] = -1; near_dist[i] = kInfty; }
+        return;
+    }
+    for (int k = tid; k < dim; k += 256) s_e[k] = gi[2 + k];
+    __syncthreads();
+    unsigned long long best = ~0ull;                      // (distance bits << 32 | row): distances are >= +0, so the bit pattern orders like the value
+    for (int j = tid; j < n; j += 256) {
+        if (j / t_max == ri) continue;
+        const float* gj = g + (size_t)j * w;
+        if (!(gj[0] > 0.5f)) continue;
+        float dot = 0.f;
+        int k = 0;
+        for (; k + 2 <= dim; k += 2) {                    // rows are 8-byte aligned (w even, payload at +2 floats)
+            const float2 b = *reinterpret_cast<const float2*>(gj + 2 + k);
+            dot = dot + s_e[k] * b.x;
+            dot = dot + s_e[k + 1] * b.y;
+        }
+        for (; k < dim; ++k) dot = dot + s_e[k] * gj[2 + k];
+        const float d = cos_dist(dot);
+        const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)j;
+        best = key < best ? key : best;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long other = __shfl_xor(best, o);
+        best = other < best ? other : best;
+    }
+    if (lane == 0) s_best[wv] = best;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long b = s_best[0];
+        for (int q = 1; q < 4; ++q) b = s_best[q] < b ? s_best[q] : b;
+        near_row[i] = b == ~0ull ? -1 : (int)(unsigned)b;
+        near_dist[i] = b == ~0ull ? kInfty : __uint_as_float((unsigned)(b >> 32));
+    }
+}
+
+void launch_gallery_nearest(const float* gathered, int world, int t_max, int dim, int* ids, int* near_row, float* near_dist, hipStream_t s) {
+    if (world * t_max <= 0) return;
+    hipLaunchKernelGGL(gallery_nearest_kernel, dim3(world * t_max), dim3(256), (size_t)dim * 4, s, gathered, world, t_max, dim, ids, near_row, near_dist);
+    KCHECK();
+}
+
 void launch_gallery_shard(const DevTrkHdr* hdr, const DevTrack* trk, const float* gal_n, int gmax, int dim, float* out, int t_max, hipStream_t s) {
     hipLaunchKernelGGL(gallery_shard_kernel, dim3(1), dim3(TRK_DEV_TMAX), 0, s, hdr, trk, gal_n, gmax, dim, out, t_max);
     KCHECK();

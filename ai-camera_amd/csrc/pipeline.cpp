@@ -81,9 +81,11 @@ struct Pipeline {
     double t_issue = 0, t_wait = 0, t_track = 0;
     long n_frames_done = 0;
     // association on the device, k frames per launch (aic_pipeline_option("device_assoc")): 0 = host C++ cascade / LSAP, one launch +
-    // sync per frame; 2 = always on the device; 1 (default) = on the device while a frame's assignment problems fit ONE wavefront's
-    // registers (<= 64 tracks and <= 64 detections: lsap_wave64, cost matrices in LDS), else on the host for that launch group --
-    // beyond 64 x 64 the single-wave LSAP is slower than the host's (configs[2], 100 x 100: 290 vs 230 us per frame)
+    // sync per frame; 2 = always on the device; 1 (default) = on the device while a frame's assignment problems are at most 128 x 128
+    // (lsap_wave64 / lsap_wave_reg<2>, and the unique-optimum check in front of them), else on the host for that launch group.
+    // configs[2] (100 x 100, YOLOv8m at 1080p), round 3: 2 205 frames/s on the device, 2 246 on the host -- both bound by the convs; the
+    // device path leaves the host 1 us per frame of work instead of 213
+    int assoc_limit = 128;           // auto mode: largest assignment problem side the device takes (aic_pipeline_option("device_assoc_limit"))
     int dev_assoc = getenv("AICAM_TRK_HOST") ? 0 : (getenv("AICAM_TRK_DEV") ? 2 : 1);
     std::atomic<int> tracks_seen{0};      // live tracks after the most recent launch group
     // `tracks_before`: the track count the decision may use.  It must not depend on timing -- the producer issues group k while the
@@ -92,7 +94,7 @@ struct Pipeline {
     // frames then always take the same path (both give the same rows; a moving choice made a defect of one of them look random).
     bool use_device(int n_max, int tracks_before) const {
         if (!dev_assoc || !trk.dev_capable() || n_max > TRK_DEV_NMAX) return false;   // beyond 512 detections in a frame only the host chain applies (it takes 1536)
-        return dev_assoc == 2 || (n_max <= 64 && tracks_before + n_max / 2 <= 64) || x_shard[0] != nullptr;
+        return dev_assoc == 2 || (n_max <= assoc_limit && tracks_before + n_max / 2 <= assoc_limit) || x_shard[0] != nullptr;
     }
     // configs[4]: gallery shard of this stream on the tracker stream, ordered behind the group's association; every launch group
     // counts, whichever path associated it (the ranks' exchange counts must agree).  Double-buffered: the stream's association only
@@ -876,6 +878,41 @@ int aic_pipeline_exchange_wait(aic_pipeline* p, int64_t seq, int timeout_ms, int
     });
 }
 
+int aic_gallery_annotate(int device_id, void* stream, const float* gathered_dev, int world, int rank, int t_max, int dim,
+                         double max_cosine_distance, int32_t* track_id, int32_t* near_row, float* near_dist, float* annotation) {
+    return guarded([&] {
+        AIC_REQUIRE(gathered_dev && world >= 1 && rank >= 0 && rank < world && t_max > 0 && dim > 0 && dim % 2 == 0 && dim <= 8192, AIC_ERR_INVALID, "bad argument");
+        Device& d = device(device_id);
+        d.use();
+        hipStream_t s = stream ? (hipStream_t)stream : d.s_trk;
+        const int n = world * t_max;
+        DevBuf<int> d_i((size_t)2 * n);
+        DevBuf<float> d_f(n);
+        std::vector<int> ids(n), nr(n);
+        std::vector<float> nd(n);
+        {
+            Prof pr(d, PROF_TRK, s, 2.0 * n * (double)(n - t_max) * dim, (double)n * (2 + dim) * 4);
+            launch_gallery_nearest(gathered_dev, world, t_max, dim, d_i.p, d_i.p + n, d_f.p, s);
+        }
+        HIP_CHECK(hipMemcpyAsync(ids.data(), d_i.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipMemcpyAsync(nr.data(), d_i.p + n, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipMemcpyAsync(nd.data(), d_f.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        if (track_id) std::copy(ids.begin(), ids.end(), track_id);
+        if (near_row) std::copy(nr.begin(), nr.end(), near_row);
+        if (near_dist) std::copy(nd.begin(), nd.end(), near_dist);
+        if (annotation) {                       // this rank's rows: (rank, track id, distance) of the closest track of another camera within the threshold
+            const float thr = (float)max_cosine_distance;
+            for (int r = 0; r < t_max; ++r) {
+                const int i = rank * t_max + r, j = nr[i];
+                float* o = annotation + (size_t)r * 3;
+                if (ids[i] >= 0 && j >= 0 && nd[i] <= thr) { o[0] = (float)(j / t_max); o[1] = (float)ids[j]; o[2] = nd[i]; }
+                else { o[0] = -1.f; o[1] = -1.f; o[2] = -1.f; }
+            }
+        }
+    });
+}
+
 int aic_pipeline_exchange_done(aic_pipeline* p, int64_t seq) {
     return guarded([&] {
         AIC_REQUIRE(p, AIC_ERR_INVALID, "NULL pipeline");
@@ -895,6 +932,10 @@ int aic_pipeline_option(aic_pipeline* p, const char* key, int value) {
         else if (k == "device_assoc") {
             AIC_REQUIRE(value >= 0 && value <= 2, AIC_ERR_INVALID, "device_assoc: 0 host, 1 auto, 2 always on the device");
             p->p.dev_assoc = value;
+        }
+        else if (k == "device_assoc_limit") {
+            AIC_REQUIRE(value >= 1 && value <= TRK_DEV_NMAX, AIC_ERR_INVALID, "device_assoc_limit must be in 1..512");
+            p->p.assoc_limit = value;
         }
         else if (k == "device_filter") {
             AIC_REQUIRE(value == 0 || value == 1, AIC_ERR_INVALID, "device_filter: 0 host filter, 1 on the device");

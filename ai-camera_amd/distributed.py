@@ -73,6 +73,33 @@ def gpu_numa_nodes():
     return nodes
 
 
+def gpu_pci_bus_id(dev: int):
+    """PCI bus id ("0000:c1:00.0") of HIP device `dev` AS THIS PROCESS ENUMERATES IT (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES
+    masks and the KFD topology order included), from the runtime itself; None without a HIP runtime or device.  This is a GPU
+    call (it initialises the runtime): what must come AFTER the binding are the page-locked allocations and the worker threads."""
+    try:   # through torch's own HIP runtime (a second copy of libamdhip64 loaded by name beside it would be a second runtime in the process)
+        import torch
+        if not torch.cuda.is_available() or int(dev) >= torch.cuda.device_count():
+            return None
+        p = torch.cuda.get_device_properties(int(dev))
+        return f"{int(p.pci_domain_id):04x}:{int(p.pci_bus_id):02x}:{int(p.pci_device_id):02x}.0"
+    except Exception:    # noqa: BLE001
+        return None
+
+
+def gpu_numa_node(dev: int):
+    """(numa node, pci bus id) of HIP device `dev`: the runtime's own bus id looked up in sysfs; falls back to the bus-address-order
+    guess of gpu_numa_nodes() (no device mask, no runtime) with bus id None."""
+    bus = gpu_pci_bus_id(dev)
+    if bus:
+        try:
+            return int(open(f"/sys/bus/pci/devices/{bus}/numa_node").read().strip()), bus
+        except (OSError, ValueError):
+            pass
+    nodes = gpu_numa_nodes()
+    return (nodes[dev] if dev < len(nodes) else -1), None
+
+
 def bind_rank_to_gpu_numa(local_rank: int, world: int):
     """os.sched_setaffinity for this process (and every thread it starts later): the allowed cores of the GPU's NUMA node,
     split among the ranks that share the node; without NUMA information an even slice of the allowed cores.  Call before the
@@ -84,8 +111,9 @@ def bind_rank_to_gpu_numa(local_rank: int, world: int):
     if world <= 1 and os.environ.get("AICAM_BIND_SINGLE") is None:
         return {"bound": False, "cores": len(allowed), "reason": "single rank: the cores the box grants are all ours"}
     try:
-        nodes = gpu_numa_nodes()
-        node = nodes[local_rank] if local_rank < len(nodes) else -1
+        per_rank = [gpu_numa_node(r) for r in range(world)]        # rank r runs on HIP device r of this node (one process per GPU)
+        nodes = [n for n, _ in per_rank]
+        node, bus = per_rank[local_rank] if local_rank < len(per_rank) else (-1, None)
         mine, sharers, my_pos = allowed, world, local_rank
         if node >= 0:
             cl = set(_cpulist(open(f"/sys/devices/system/node/node{node}/cpulist").read()))
@@ -96,7 +124,7 @@ def bind_rank_to_gpu_numa(local_rank: int, world: int):
         per = max(1, len(mine) // sharers)
         cores = mine[my_pos * per:(my_pos + 1) * per] or mine
         os.sched_setaffinity(0, cores)
-        return {"bound": True, "numa_node": node, "cores": len(cores), "first_core": cores[0], "last_core": cores[-1]}
+        return {"bound": True, "numa_node": node, "pci_bus_id": bus, "cores": len(cores), "first_core": cores[0], "last_core": cores[-1]}
     except Exception as e:            # noqa: BLE001 -- placement is an optimisation, never a failure
         return {"bound": False, "reason": str(e)}
 
@@ -180,6 +208,22 @@ def reduce_max_time(seconds: float) -> float:
     return float(t.item())
 
 
+def gather_floats(values):
+    """Every rank's list of floats on every rank ([world][len(values)]; one small all_gather): the per-rank figures of the bench line."""
+    import torch
+    import torch.distributed as dist
+    v = [float(x) for x in values]
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+        return [v]
+    world = dist.get_world_size()
+    t = torch.tensor(v, dtype=torch.float64)
+    if dist.get_backend() == "nccl":
+        t = t.cuda()
+    out = torch.empty(world * len(v), dtype=torch.float64, device=t.device)
+    dist.all_gather_into_tensor(out, t)
+    return out.cpu().view(world, len(v)).tolist()
+
+
 def reduce_sum(value: float) -> float:
     import torch
     import torch.distributed as dist
@@ -231,13 +275,16 @@ class GalleryExchange:
         self._thread = None
         self.count = 0
         self.last_annotation = None
+        self.global_ids = GlobalIds(self.world) if self.world >= 1 else None
         self.error = None
         # The exchange runs on its own thread while the caller's thread keeps using the default group (barriers, the bench's
         # max-reduce).  Collectives of one communicator must be issued in the same order on every rank, which two threads cannot
         # promise: the exchange gets a communicator of its own.  new_group() is itself collective -- every rank constructs its
         # GalleryExchange at the same point of the program.
-        self.backend = dist.get_backend() if self.world > 1 else None
-        self.group = dist.new_group() if self.world > 1 else None
+        # (with a process group initialised the collective is issued even in a world of 1: the rank path is then the same code)
+        live = dist.is_available() and dist.is_initialized()
+        self.backend = dist.get_backend() if live else None
+        self.group = dist.new_group() if live else None
         dev = torch.device("cpu") if device is None else torch.device("cuda", device)
         self._shards = [torch.zeros((self.t_max, 2 + self.dim), dtype=torch.float32, device=dev) for _ in range(2)]
         self._gathered = torch.zeros((self.world * self.t_max, 2 + self.dim), dtype=torch.float32, device=dev)
@@ -249,7 +296,7 @@ class GalleryExchange:
     def all_gather(self, shard, async_op=True):
         import torch
         import torch.distributed as dist
-        if self.world == 1:
+        if self.group is None:                        # no process group: a single stream, the gather is a copy
             self._gathered.copy_(shard)
             return _Handle(None, self._gathered, 1)
         if self.backend == "gloo" and self._gathered.is_cuda:
@@ -289,7 +336,10 @@ class GalleryExchange:
                     with torch.cuda.stream(stream):
                         h = self.all_gather(self._shards[buf.value])
                         g = h.wait()
-                        self.last_annotation = annotate_device(g, self.rank, self.world)
+                        res = annotate_device(g, self.rank, self.world, stream=sp.value, device=self.device)   # HIP, exchange stream, synced
+                        if res is not None:
+                            self.last_annotation = res[0]
+                            self.global_ids.update(*res[1:])
                         stream.synchronize()
                     L.call("aic_pipeline_exchange_done", pipe._h, seq)
                     seq += 1
@@ -316,20 +366,69 @@ class GalleryExchange:
         return self.count
 
 
-def annotate_device(gathered, my_rank, world, max_cosine_distance=0.2):
-    """Annotation pass on the gathered shards (device tensors): for each valid local row the closest valid row of any OTHER
-    rank within the threshold -> fp32 [t_max, 3] (rank, track id, distance; rank = -1: none).  Plain tensor algebra on the
-    exchange stream: 128 x 896 x 512 MACs, off every critical path; per-stream association does not read it."""
-    import torch
-    mine = gathered[my_rank]
-    out = torch.full((mine.shape[0], 3), -1.0, dtype=torch.float32, device=gathered.device)
-    if world == 1:
-        return out
-    others = torch.cat([gathered[r] for r in range(world) if r != my_rank])
-    ranks = torch.cat([torch.full((gathered.shape[1],), float(r), device=gathered.device) for r in range(world) if r != my_rank])
-    d = (1.0 - mine[:, 2:] @ others[:, 2:].T).clamp_min(0.0)
-    d = torch.where((mine[:, :1] > 0.5) & (others[:, 0] > 0.5)[None, :], d, torch.full_like(d, 1e5))
-    best, j = d.min(1)
-    ok = best <= max_cosine_distance
-    out[ok, 0], out[ok, 1], out[ok, 2] = ranks[j[ok]], others[j[ok], 1], best[ok]
-    return out
+class GlobalIds:
+    """Cross-camera global-ID table (csrc/global_id.cpp through aic_gid_*; README.md:209, BASELINE.json configs[4]).  A track's
+    global id is the (rank << 32 | track id) of the first sighting of its identity; two tracks of different cameras that are
+    each other's nearest neighbour within the cosine threshold adopt the smaller of their global ids.  Every rank feeds update()
+    the same all-gathered data, so every rank holds the same table: no extra communication, deterministic."""
+
+    def __init__(self, world, max_cosine_distance=0.2):
+        import ctypes as C
+        from . import _lib as L
+        self.world, self.thr = int(world), float(max_cosine_distance)
+        self._h = C.c_void_p()
+        L.call("aic_gid_create", self.world, C.byref(self._h))
+
+    def update(self, track_id, near_row, near_dist):
+        """One exchange: the arrays of annotate_device / oracle.xcam_oracle.nearest_rows over all world * t_max rows. -> links made."""
+        import ctypes as C
+        from . import _lib as L
+        tid = np.ascontiguousarray(track_id, np.int32)
+        t_max = len(tid) // self.world
+        n = C.c_int32()
+        L.call("aic_gid_update", self._h, self.world, t_max, L.ptr(tid), L.ptr(np.ascontiguousarray(near_row, np.int32)),
+               L.ptr(np.ascontiguousarray(near_dist, np.float32)), self.thr, C.byref(n))
+        return n.value
+
+    def lookup(self, rank, track_id):
+        """Global id of (rank, track id) as (first rank, first track id), or None when the track was never in a shard."""
+        import ctypes as C
+        from . import _lib as L
+        g = C.c_int64()
+        L.call("aic_gid_lookup", self._h, int(rank), int(track_id), C.byref(g))
+        return None if g.value < 0 else (int(g.value >> 32), int(g.value & 0xFFFFFFFF))
+
+    def size(self):
+        import ctypes as C
+        from . import _lib as L
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        L.call("aic_gid_size", self._h, C.byref(a), C.byref(b), C.byref(c))
+        return dict(tracks=a.value, identities=b.value, links=c.value)
+
+    def close(self):
+        from . import _lib as L
+        if getattr(self, "_h", None):
+            L.call("aic_gid_destroy", self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def annotate_device(gathered, my_rank, world, max_cosine_distance=0.2, stream=None, device=0):
+    """Annotation pass on the gathered shards IN HBM (a device tensor [world, t_max, 2 + dim], or its address + shape): the HIP
+    kernel gallery_nearest_kernel through aic_gallery_annotate on the exchange stream -- no tensor-library arithmetic.  Returns
+    (annotation fp32 [t_max, 3] = (rank, track id, distance) of the closest track of ANOTHER camera within the threshold, -1 =
+    none; track_id [n], near_row [n], near_dist [n] over all n = world * t_max rows, what GlobalIds.update takes)."""
+    import ctypes as C
+    from . import _lib as L
+    t_max, w = int(gathered.shape[-2]), int(gathered.shape[-1])
+    n = world * t_max
+    tid, near, dist = np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.float32)
+    ann = np.zeros((t_max, 3), np.float32)
+    L.call("aic_gallery_annotate", int(device), C.c_void_p(int(stream)) if stream else None, C.c_void_p(gathered.data_ptr()), int(world),
+           int(my_rank), t_max, w - 2, float(max_cosine_distance), L.ptr(tid), L.ptr(near), L.ptr(dist), L.ptr(ann))
+    return ann, tid, near, dist

@@ -303,6 +303,27 @@ int aic_pipeline_exchange_enable(aic_pipeline* p, float* shard0_dev, float* shar
 int aic_pipeline_exchange_stream(aic_pipeline* p, void** stream);
 int aic_pipeline_exchange_wait(aic_pipeline* p, int64_t seq, int timeout_ms, int32_t* buffer, int32_t* ready);
 int aic_pipeline_exchange_done(aic_pipeline* p, int64_t seq);
+/* The annotation pass on an all-gathered set of shards ("consumed read-only by an extra cosine_min_gallery pass"):
+ * gathered_dev = fp32 [world, t_max, 2 + dim] in HBM, `stream` = the hipStream_t to run on (the exchange stream; NULL = the
+ * device's tracker stream), synchronised before returning.  Host outputs over ALL world * t_max rows (any may be NULL):
+ * track_id[i] (-1 = slot empty), near_row[i] = the valid row of ANOTHER rank closest in cosine distance (ties: lowest row; -1 =
+ * none), near_dist[i]; annotation[t_max, 3] = (rank, track id, distance) for this rank's rows where that distance is within
+ * max_cosine_distance, else -1.  d(i, j) == d(j, i) bit for bit, so every rank derives the same table from the same bytes. */
+int aic_gallery_annotate(int device, void* stream, const float* gathered_dev, int world, int rank, int t_max, int dim,
+                         double max_cosine_distance, int32_t* track_id, int32_t* near_row, float* near_dist,
+                         float* annotation);
+/* Cross-camera global-ID policy on top of it (README.md:209 "smarter gallery management in ReID"; BASELINE.json configs[4]).
+ * HOST code (csrc/global_id.cpp).  A track's global id is the (rank << 32 | track id) of the first sighting of its identity:
+ * new tracks get their own, and two tracks of different cameras that are each other's nearest neighbour within the threshold
+ * adopt the smaller of their global ids (transitively).  update() takes the arrays of aic_gallery_annotate; every rank feeds
+ * it the same gathered data and therefore holds the same table -- no further communication.  lookup(): -1 = never seen. */
+typedef struct aic_gid aic_gid;
+int aic_gid_create(int world, aic_gid** out);
+int aic_gid_destroy(aic_gid* g);
+int aic_gid_update(aic_gid* g, int world, int t_max, const int32_t* track_id, const int32_t* near_row, const float* near_dist,
+                   double max_cosine_distance, int32_t* n_links);
+int aic_gid_lookup(aic_gid* g, int rank, int track_id, int64_t* global_id);
+int aic_gid_size(aic_gid* g, int64_t* n_tracks, int64_t* n_identities, int64_t* n_links);
 int aic_host_register(void* ptr, size_t bytes);   /* hipHostRegister: page-lock caller memory */
 int aic_host_unregister(void* ptr);
 int aic_pipeline_tracker(aic_pipeline* p, aic_tracker** out);
@@ -314,8 +335,9 @@ int aic_pipeline_stats(aic_pipeline* p, double* issue_s, double* wait_s, double*
  * (<= batch; 0 = batch).  "device_assoc": 2 = association on the device, k frames per launch (cascade, LSAP and
  * lifecycle in csrc/kernels_trk_dev.hip, no host round trip per frame); 0 = cost matrices on the device, cascade / LSAP /
  * lifecycle in host C++ (csrc/assoc_host.cpp, lsap.cpp), one launch + one sync per frame; 1 (default) = per launch group, on
- * the device while the assignment problems fit one wavefront's registers (<= 64 tracks x 64 detections), else on the host;
- * a group with a frame of more than 512 detections always takes the host chain.  "device_filter" (inject = 0): 1 (default) = the
+ * the device while the assignment problems are at most 128 tracks x 128 detections (one or two columns per lane of the wave
+ * LSAP; unique optima never reach it), else on the host;
+ * a group with a frame of more than 512 detections always takes the host chain ("device_assoc_limit": the 128 of the auto mode).  "device_filter" (inject = 0): 1 (default) = the
  * tracker's confidence / class filter runs on the device and ReID is sized from a device-side count, 0 = filter on the host.
  * Same results in every mode. */
 int aic_pipeline_option(aic_pipeline* p, const char* key, int value);

@@ -96,6 +96,45 @@ def main(path):
         em, eut, eud = O.cascade_on_matrices(app, maha, iou, state.tolist(), tsu.tolist(), 0.2, 0.7, max_age)
         assert list(zip(mt[:nm[0]].tolist(), md[:nm[0]].tolist())) == [(int(a), int(b)) for a, b in em], it
         assert ut[:nut[0]].tolist() == [int(v) for v in eut] and ud[:nud[0]].tolist() == [int(v) for v in eud], it
+    # 4. the cross-camera global-id table (csrc/global_id.cpp): random nearest-neighbour tables, ids churned over 40 exchanges;
+    #    invariants: a global id never grows, mutual neighbours within the threshold share one, lookups of unseen tracks are -1
+    lib.aic_gid_update.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]
+    lib.aic_gid_lookup.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    world, t_max = 4, 12
+    h = C.c_void_p()
+    assert lib.aic_gid_create(world, C.byref(h)) == 0
+    seen = {}
+    for it in range(40):
+        n = world * t_max
+        tid = rng.integers(-1, 30, n).astype(np.int32)
+        near = np.full(n, -1, np.int32)
+        dist = rng.uniform(0, 0.4, n).astype(np.float32)
+        for i in rng.permutation(n)[:n // 2]:                      # some mutual pairs across ranks, some one-sided pointers
+            j = int(rng.integers(0, n))
+            if j // t_max != i // t_max and tid[i] >= 0 and tid[j] >= 0:
+                near[i] = j
+                if rng.uniform() < 0.6:
+                    near[j], dist[j] = i, dist[i]
+        nl = C.c_int32()
+        assert lib.aic_gid_update(h, world, t_max, ptr(tid), ptr(near), ptr(dist), 0.2, C.byref(nl)) == 0
+        for i in range(n):
+            if tid[i] < 0:
+                continue
+            g = C.c_int64()
+            assert lib.aic_gid_lookup(h, i // t_max, int(tid[i]), C.byref(g)) == 0 and g.value >= 0
+            key = (i // t_max, int(tid[i]))
+            assert g.value <= seen.get(key, (key[0] << 32) | key[1]), (it, key)      # adopts smaller ids only
+            seen[key] = g.value
+            j = int(near[i])
+            if j >= 0 and near[j] == i and dist[i] <= np.float32(0.2) and tid[j] >= 0:
+                g2 = C.c_int64()
+                lib.aic_gid_lookup(h, j // t_max, int(tid[j]), C.byref(g2))
+                assert g2.value == g.value, (it, i, j)
+    g = C.c_int64()
+    assert lib.aic_gid_lookup(h, 3, 12345, C.byref(g)) == 0 and g.value == -1
+    bad = np.zeros(world * t_max, np.int32)
+    assert lib.aic_gid_update(h, world + 1, t_max, ptr(bad), ptr(bad), ptr(np.zeros(world * t_max, np.float32)), 0.2, None) != 0
+    assert lib.aic_gid_destroy(h) == 0
     print("asan driver OK")
 
 

@@ -30,9 +30,31 @@ WORKER = textwrap.dedent("""
         oids, oemb = per_rank[r]
         assert len(oids) == 6 and (oids // 100 == r + 1).all()
     assert np.allclose(per_rank[rank][1], emb)
+    # cross-camera global ids (csrc/global_id.cpp): both ranks derive the table from the same gathered bytes.  The nearest-neighbour
+    # table is the HIP pass's job on a GPU (aic_gallery_annotate); here, without one, the checker restatement stands in for it.
+    from oracle import xcam_oracle as X
+    gids = D.GlobalIds(world)
+    unit = emb / np.linalg.norm(emb, axis=1, keepdims=True)
+    look = []
+    for step in range(3):
+        ids_s, emb_s = 100 * (rank + 1) + ids, unit.copy()
+        if step >= 1 and rank == 1:                                  # a person only camera 1 sees, from the second exchange on
+            ids_s = np.concatenate([ids_s, [777]])
+            lone = np.zeros((1, 32), np.float32); lone[0, 7] = 1.0
+            emb_s = np.concatenate([emb_s, lone])
+        if step == 2:                                                # camera 0 re-acquires identity 0 under a NEW track id: same global id
+            ids_s = ids_s.copy()
+            if rank == 0:
+                ids_s[list(ids).index(0)] = 150
+        got_s = D.all_gather_gallery(D.pack_gallery_shard(ids_s, emb_s, 32, t_max=16))
+        tid, near, dist_ = X.nearest_rows(got_s)
+        links = gids.update(tid, near, dist_)
+        look.append([links] + [gids.lookup(r, 100 * (r + 1) + int(i)) for r in range(world) for i in sorted(ids)] +
+                    [gids.lookup(1, 777), gids.lookup(0, 150), gids.lookup(0, 999)])
+    sz = gids.size()
     t = D.reduce_max_time(1.0 + rank)
     total = D.reduce_sum(10.0 * (rank + 1))
-    print(json.dumps({"rank": rank, "tmax": t, "sum": total}))
+    print(json.dumps({"rank": rank, "tmax": t, "sum": total, "look": look, "size": sz, "ids": sorted(int(i) for i in ids)}))
     dist.barrier()
     dist.destroy_process_group()
 """)
@@ -62,6 +84,20 @@ def test_gloo_world2(tmp_path):
     import json
     res = [json.loads(o.strip().splitlines()[-1]) for o in outs]
     assert all(r["tmax"] == 2.0 and r["sum"] == 30.0 for r in res)
+    # global ids: identical tables on both ranks after every exchange; the planted shared identities carry camera 0's (rank, track id)
+    a, b = (r for r in sorted(res, key=lambda r: r["rank"]))
+    assert a["look"] == b["look"] and a["size"] == b["size"]
+    ids = a["ids"]
+    for step, row in enumerate(a["look"]):
+        links, per = row[0], row[1:1 + 2 * len(ids)]
+        assert links == (len(ids) if step == 0 else (1 if step == 2 else 0)), (step, links)   # first exchange links every pair; the third the re-acquired track
+        for k, i in enumerate(ids):
+            assert per[k] == [0, 100 + i] and per[len(ids) + k] == [0, 100 + i], (step, i)    # camera 1's track 200+i adopted (0, 100+i)
+        lone, reacq, never = row[-3:]
+        assert lone == (None if step == 0 else [1, 777])          # seen by one camera only: its own id
+        assert reacq == ([0, 100] if step == 2 else None)         # track 150 of camera 0 = identity 0 again: the identity's first id
+        assert never is None
+    assert a["size"]["tracks"] == 2 * len(ids) + 2 and a["size"]["identities"] == len(ids) + 1 and a["size"]["links"] == len(ids) + 1
 
 
 def test_single_process_defaults():
@@ -92,6 +128,9 @@ def test_bench_launch_path_gloo_world2():
     assert out["config"]["gallery_shards_seen"] == 2                 # both ranks' valid rows arrived
     aff = out["config"]["affinity"]
     assert aff["bound"] is True and aff["cores"] >= 1
+    pr = out["config"]["per_rank"]                                   # every rank's own rate in rank 0's line
+    assert [p["rank"] for p in pr] == [0, 1] and abs(pr[0]["fps"] - 2048 * 3 / 0.25) < 1 and abs(pr[1]["fps"] - 2048 * 3 / 0.26) < 1
+    assert pr[0]["first_core"] != pr[1]["first_core"]
 
 
 def test_rank_core_binding_is_disjoint():

@@ -245,6 +245,28 @@ def match_outputs(a, b, thr=0.9):
     return pairs
 
 
+def assoc_margin(last_costs, max_cos=0.2, chi2=9.487729036781154, window=3e-4):
+    """How close the oracle's appearance association of one frame is to going the other way: the smallest of (a) the distance of any
+    gated appearance cost from the acceptance threshold (linear_assignment.py:58,76) and (b) the gap between the two best acceptable
+    candidates of any track (row) or detection (column).  A perturbation of the costs below this margin cannot change the matches."""
+    if last_costs is None:
+        return np.inf
+    app, gate, _ = last_costs
+    if app.size == 0:
+        return np.inf
+    eff = np.where(gate > chi2, np.inf, app).astype(np.float64)
+    m = np.inf
+    fin = np.isfinite(eff) & (eff < 1e4)
+    if fin.any():
+        m = min(m, float(np.abs(eff[fin] - max_cos).min()))
+    for mat in (eff, eff.T):
+        for row in mat:
+            v = np.sort(row[np.isfinite(row) & (row <= max_cos + window)])
+            if len(v) >= 2:
+                m = min(m, float(v[1] - v[0]))
+    return m
+
+
 def test_fp16_own_detections_vs_fp32_oracle_chain(gpu, engines):
     """inject=0 (the detector's OWN boxes feed crop/ReID/association) for 320 frames, fp16 (the mode the bench runs) and fp32,
     against the fp32 ORACLE chain (letterbox -> torch fp32 YOLO -> NMS -> scale_bboxes -> filter -> crops -> torch fp32 ReID ->
@@ -290,7 +312,8 @@ def test_fp16_own_detections_vs_fp32_oracle_chain(gpu, engines):
         trk = O.OracleTracker()
         stat = {d: dict(id_map={}, switches=0, n_hit=0, n_out=0, det_frac=[], box_dev=0.0, score_dev=0.0) for d in runs}
         n_ref = 0
-        oracle_out = []
+        oracle_out, margins = [], []
+        first_bad = {d: None for d in runs}                     # first frame where a run's outputs stop being the oracle's (ids up to renaming)
         for f in range(n_frames):
             ob, osc, ol = oracle_detect(frames[f])
             keep = [i for i in range(len(ob)) if osc[i] >= min_conf]
@@ -301,6 +324,7 @@ def test_fp16_own_detections_vs_fp32_oracle_chain(gpu, engines):
             trk.update(list(tlwh), list(c), [config.class_name(int(k)) for k in ol[keep]], [emb[i] if valid[i] else None for i in range(len(b))])
             exp = trk.output_tuples()
             oracle_out.append(exp)
+            margins.append(assoc_margin(trk.last_costs))
             n_ref += len(exp)
             for d, (tracks, dets) in runs.items():
                 st = stat[d]
@@ -311,16 +335,22 @@ def test_fp16_own_detections_vs_fp32_oracle_chain(gpu, engines):
                     j = iou.argmax(1)
                     ok = (iou.max(1) > 0.98) & (hl[hk][j] == ol[keep])           # the same anchor's detection
                     st["det_frac"].append(ok.mean())
+                    st.setdefault("det_by_frame", {})[f] = float(ok.mean()) if len(ok) == int(hk.sum()) else 0.0
                     if ok.any():
                         st["box_dev"] = max(st["box_dev"], float(np.abs(b[ok] - hb[hk][j[ok]]).max()))
                         st["score_dev"] = max(st["score_dev"], float(np.abs(c[ok] - hs[hk][j[ok]]).max()))
                 st["n_out"] += len(tracks[f])
-                for i, j in match_outputs(exp, tracks[f]):
+                pairs = match_outputs(exp, tracks[f])
+                bad = len(pairs) != len(exp) or len(tracks[f]) != len(exp)
+                for i, j in pairs:
                     st["n_hit"] += 1
                     oid, hid = exp[i][4], tracks[f][j][4]
                     if oid in st["id_map"] and st["id_map"][oid] != hid:
                         st["switches"] += 1
+                        bad = True
                     st["id_map"][oid] = hid
+                if bad and first_bad[d] is None:
+                    first_bad[d] = f
         for d, st in stat.items():
             print(f"[{d}] own-detections chain vs fp32 oracle chain, {n_frames} frames, tracker floor {min_conf:.3f}: "
                   f"{np.mean(st['det_frac']):.4f} of the oracle's detections reproduced (IoU > 0.98, same class), max box dev {st['box_dev']:.2f} px, "
@@ -343,7 +373,22 @@ def test_fp16_own_detections_vs_fp32_oracle_chain(gpu, engines):
         # inside one epoch) -- fp32 agreement then wandered between 0.54 and 1.0 from run to run.
         assert np.mean(f32["det_frac"]) > 0.999 and f32["box_dev"] < 0.02 and f32["n_hit"] / n_ref > 0.95 and f32["switches"] <= 0.02 * n_ref
         assert np.mean(f16["det_frac"]) > 0.97 and f16["box_dev"] < 12.0 and f16["score_dev"] < 0.005
-        assert 0.5 < f16["n_out"] / n_ref < 2.0 and f16["n_hit"] / n_ref > 0.1
+        assert 0.5 < f16["n_out"] / n_ref < 2.0
+        # The fp16 figure is not a floor that garbage would pass: the FIRST frame on which the fp16 chain's outputs leave the oracle's
+        # (after it the two trackers hold different states and every later difference is a consequence) must have a CAUSE the
+        # fp16 noise can explain, inside the window in which an association shows up in the outputs (n_init = 3 frames of
+        # confirmation + the frame itself): the oracle's own association margin there is below 3e-4 -- three times the fp16
+        # embedding error (1e-4), i.e. a near-tie -- or the fp16 detector's boxes already differed there (a score next to the
+        # floor, a box next to an NMS decision).  A tracker that is wrong for any other reason fails here.
+        fb = first_bad["fp16"]
+        if fb is not None:
+            lo = max(0, fb - 4)
+            near_tie = min(margins[lo:fb + 1])
+            det_diff = min(f16.get("det_by_frame", {}).get(k, 1.0) for k in range(lo, fb + 1)) < 1.0
+            print(f"[fp16] first frame off the oracle's outputs: {fb}; smallest oracle association margin in frames {lo}..{fb}: {near_tie:.2e}; "
+                  f"detections differ there: {det_diff}")
+            assert near_tie < 3e-4 or det_diff, (fb, near_tie)
+        assert first_bad["fp32"] is None or f32["n_hit"] / n_ref > 0.95
     finally:
         config.CLASSES_TO_TRACK.clear()
         config.CLASSES_TO_TRACK.update(old)

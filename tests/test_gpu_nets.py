@@ -244,7 +244,7 @@ def test_reid_large_batch_kernels(gpu, engines, dtype, tol_split, tol, n_crops):
 def test_reid_embeddings_do_not_depend_on_the_batch(gpu, engines, dtype):
     """A crop's embedding must not depend on how many crops shared its launch: kernel variants are chosen by batch size (ping-pong
     patch kernels at 832 and 256, the LDS-DMA implicit GEMMs below), and every variant a layer can get walks K in the same order --
-    (channel chunk, tap) for the layer shapes the patch kernel takes (ConvArgs::k_chunk_major), (tap, channel chunk) for the rest.
+    that of the ping-pong patch kernel for the shapes it takes, that of the weights-resident 64-channel kernels for theirs (ConvArgs::k_order), memory order for the rest.
     Bit-identical rows, not a tolerance: a track's gallery must not change with the group size its frames were batched in."""
     x = np.random.default_rng(3).standard_normal((832, 3, 128, 64)).astype(np.float32)
     big = HipEngine(engines[1], dtype=dtype, max_items=832, warm_up=False)
@@ -392,8 +392,9 @@ np.savez(%r, n=n, **{"o%%d" %% i: o for i, o in enumerate(out if isinstance(out,
 """
 
 
-def _run_with_and_without_tail(tmp_path, path, x, items, method):
-    """-> (outputs, conv launches) of this process (1x1 tails fused) and of a child with AICAM_NO_TAIL=1 (every conv on its own)."""
+def _run_with_and_without_tail(tmp_path, path, x, items, method, child_env=None):
+    """-> (outputs, conv launches) of this process (1x1 tails fused) and of a child with AICAM_NO_TAIL=1 (every conv on its own),
+    or with `child_env` instead (another kernel switch that is read once per process)."""
     import subprocess
     import sys
     L = pkg("_lib")
@@ -407,7 +408,7 @@ def _run_with_and_without_tail(tmp_path, path, x, items, method):
     out = out if isinstance(out, tuple) else (out,)
     np.save(tmp_path / "x.npy", x)
     code = _TAIL_CHILD % (ROOT, str(tmp_path / "x.npy"), path, items, method, str(tmp_path / "unfused.npz"))
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, AICAM_NO_TAIL="1"), capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **(child_env or {"AICAM_NO_TAIL": "1"})), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-1500:]
     z = np.load(tmp_path / "unfused.npz")
     return out, n_fused, tuple(z["o%d" % i] for i in range(len(out))), int(z["n"])
@@ -424,6 +425,18 @@ def test_fused_head_tail(gpu, engines, tmp_path):
     print(f"fused head tails: conv launches {n_u} -> {n_f}; max |dfl| {np.abs(dfl).max():.2f}, max |cls| {np.abs(cls).max():.2f}")
     assert n_u - n_f == 7, (n_u, n_f)
     assert np.isfinite(dfl).all() and np.abs(dfl).max() > 0.1 and np.abs(cls).max() > 0.1
+    assert np.array_equal(dfl, dfl_u) and np.array_equal(cls, cls_u)
+
+
+def test_merged_detect_branch_heads(gpu, engines, tmp_path):
+    """22.box{l}.0 and 22.cls{l}.0 read the same feature map: the engine runs them as ONE conv with 64 + 80 output channels side by side
+    (Model::Model merges them at load time; their readers take channel slices).  Per output channel nothing changes, so the raw head
+    of 48 images (level 0 on the 512 x 144 tile, levels 1 / 2 on the 128 x 144 one) must be BIT-IDENTICAL to the engine loaded with
+    AICAM_NO_MERGE=1 in a child process, with three conv launches fewer."""
+    x = np.random.default_rng(9).standard_normal((48, 3, 640, 640)).astype(np.float32) * 0.5
+    (dfl, cls), n_f, (dfl_u, cls_u), n_u = _run_with_and_without_tail(tmp_path, engines[0], x, 48, "yolo_head_np", {"AICAM_NO_MERGE": "1"})
+    assert n_u - n_f == 3, (n_u, n_f)
+    assert np.abs(dfl).max() > 0.1 and np.abs(cls).max() > 0.1
     assert np.array_equal(dfl, dfl_u) and np.array_equal(cls, cls_u)
 
 

@@ -184,6 +184,55 @@ def test_gallery_exchange_hooks_single_gpu(gpu, engines):
     pipe.close()
 
 
+def test_gallery_annotate_kernel_and_global_ids(gpu, lib):
+    """configs[4] annotation pass in HIP (aic_gallery_annotate -> gallery_nearest_kernel) against its NumPy statement
+    (oracle/xcam_oracle.py, same summation order): nearest rows and distances bit for bit over three cameras with shared
+    identities, look-alikes, empty slots and an empty camera; distances symmetric; and the global-id table built from it."""
+    import torch
+    from oracle import xcam_oracle as X
+    D = pkg("distributed")
+    rng = np.random.default_rng(5)
+    world, t_max, dim = 4, 128, 512
+    base = rng.standard_normal((40, dim)).astype(np.float32)
+    g = np.zeros((world, t_max, 2 + dim), np.float32)
+    shared = {}
+    for r in range(3):                                             # camera 3 has no confirmed track at all
+        n = 25 + 5 * r
+        who = rng.permutation(40)[:n]
+        e = base[who] + 0.05 * rng.standard_normal((n, dim)).astype(np.float32)      # the same persons, seen with noise: cosine distance ~2e-3
+        e /= np.linalg.norm(e, axis=1, keepdims=True)
+        g[r, :n, 0], g[r, :n, 1], g[r, :n, 2:] = 1.0, 1000 * r + np.arange(n), e
+        for k, p in enumerate(who):
+            shared.setdefault(int(p), []).append((r, 1000 * r + k))
+    gt = torch.from_numpy(g).cuda()
+    ids, near, dist = X.nearest_rows(g)
+    res = {}
+    for rank in range(world):
+        ann, tid, nr, nd = D.annotate_device(gt, rank, world)
+        assert np.array_equal(tid, ids) and np.array_equal(nr, near) and np.array_equal(nd, dist), rank
+        res[rank] = ann
+        for r in range(t_max):                                     # this rank's annotation rows restate the table
+            i = rank * t_max + r
+            if ids[i] >= 0 and near[i] >= 0 and dist[i] <= np.float32(0.2):
+                assert ann[r].tolist() == [near[i] // t_max, ids[near[i]], dist[i]]
+            else:
+                assert (ann[r] == -1).all()
+    assert (res[3] == -1).all()
+    v = np.flatnonzero(near >= 0)
+    mutual = v[near[near[v]] == v]
+    assert len(mutual) > 20 and np.array_equal(dist[mutual], dist[near[mutual]])      # d(i, j) == d(j, i), the very bits
+    gids = D.GlobalIds(world)
+    links = gids.update(ids, near, dist)
+    assert links > 10
+    for p, seen in shared.items():                                 # every camera's track of one person carries the same global id: the smallest (rank, id)
+        if len(seen) == 3:
+            got = {gids.lookup(r, t) for r, t in seen}
+            assert len(got) <= 2                                   # (mutual-nearest links pair cameras; three cameras may need a second exchange)
+    assert gids.update(ids, near, dist) == 0                       # idempotent on the same data
+    sz = gids.size()
+    assert sz["tracks"] == 25 + 30 + 35 and sz["identities"] == sz["tracks"] - sz["links"]
+
+
 def test_gallery_exchange_consumer_failure_is_loud_not_a_hang(gpu, engines, monkeypatch):
     """The pipeline waits for the consumer before it reuses a shard buffer.  A consumer that dies (a collective that raises) must
     release it: the run finishes with the same tracks, and stop() raises with the cause."""
@@ -338,8 +387,8 @@ def test_device_filter_crowded_groups_take_extra_reid_rounds(gpu, engines):
 
 
 def test_association_mode_switches_between_launch_groups(gpu, engines):
-    """Default (auto) mode: the association of a launch group runs on the device while its problems fit one wavefront (<= 64 tracks x 64
-    detections) and in host C++ beyond.  A scene that grows from 40 to 76 persons crosses that line mid-run, so the track table
+    """Auto mode: the association of a launch group runs on the device while its problems are within the limit (default 128 tracks x 128
+    detections; 64 here) and in host C++ beyond.  A scene that grows from 40 to 76 persons crosses that line mid-run, so the track table
     travels HBM -> host (and the Kalman state / galleries stay where they are): ids, classes, boxes of every frame and the final
     table must still be the oracle's."""
     n_frames, batch = 40, 8
@@ -350,6 +399,7 @@ def test_association_mode_switches_between_launch_groups(gpu, engines):
     # fp32 engines: with 76 small, overlapping persons two crossing targets can sit within fp16 noise of each other in appearance
     # cost (one such swap, 11 px, was seen in fp16 -- identically in all three association modes); the subject here is the switch
     pipe = TP(engines[0], engines[1], (720, 1280), batch=batch, ring_frames=n_frames, max_persons=80, dtype="fp32", inject=True)
+    pipe.option("device_assoc_limit", 64)
     pipe.upload(0, frames)
     pipe.inject(0, [sc.detections(f)[:3] for f in range(n_frames)])
     tracks, nd = pipe.run(0, n_frames)

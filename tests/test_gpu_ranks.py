@@ -82,12 +82,34 @@ side.wait_stream(torch.cuda.current_stream())
 with torch.cuda.stream(side):
     w = dist.all_gather_into_tensor(out, shard, group=grp, async_op=True)
     w.wait()
-    ann = D.annotate_device(out.view(1, 128, 514), 0, 1)
+    ann = D.annotate_device(out.view(1, 128, 514), 0, 1, stream=side.cuda_stream)[0]      # the HIP annotation pass on the exchange stream
     side.synchronize()
 assert torch.equal(out, shard) and ann.shape == (128, 3)
+# the full GalleryExchange thread path over RCCL (world of 1): pack on the tracker stream -> consumer thread -> all_gather_into_tensor
+# on the library's exchange stream (torch.cuda.ExternalStream) -> HIP annotation -> global-id table -> buffer released
+ef = importlib.import_module("ai-camera_amd.engine_file")
+syn = importlib.import_module("ai-camera_amd.synthetic")
+TP = importlib.import_module("ai-camera_amd.pipeline").TrackingPipeline
+yp, rp = ef.ensure_seeded_engines({ROOT!r})
+sc = syn.Scene(seed=21, n_targets=12)
+frames = sc.render_batch(0, 32)
+pipe = TP(yp, rp, (720, 1280), batch=8, ring_frames=32, max_persons=16, dtype="fp16", inject=True)
+pipe.option("taper", 0)
+pipe.upload(0, frames)
+pipe.inject(0, [sc.detections(f)[:3] for f in range(32)])
+ex = D.GalleryExchange(dim=512, device=0)
+assert ex.backend == "nccl" and ex.world == 1
+ex.start(pipe, every_frames=8)
+pipe.run(0, 32)
+assert ex.stop() == 4
+assert ex.last_annotation.shape == (128, 3) and (ex.last_annotation[:, 0] < 0).all()
+assert ex.global_ids.size()["tracks"] == 12 and ex.global_ids.lookup(0, 1) == (0, 1)
+pipe.close()
 dist.barrier()
 dist.destroy_process_group()
 print("RCCL_OK")
 """
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    if r.returncode != 0 and os.path.isdir(os.path.join(ROOT, "gpurun_out")):        # the whole child log survives the run (pytest shortens the assertion text)
+        open(os.path.join(ROOT, "gpurun_out", "rccl_child.err"), "w").write(r.stdout + "\n---- stderr\n" + r.stderr)
     assert r.returncode == 0 and "RCCL_OK" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])

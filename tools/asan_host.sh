@@ -8,7 +8,7 @@ R=$(cd "$(dirname "$0")/.." && pwd)
 B=$R/ai-camera_amd/csrc/build
 mkdir -p $B
 g++ -std=c++17 -O1 -g -fno-omit-frame-pointer -fsanitize=address,undefined -fno-sanitize-recover=undefined -fPIC -shared \
-    $R/ai-camera_amd/csrc/lsap.cpp $R/ai-camera_amd/csrc/assoc_host.cpp $R/ai-camera_amd/csrc/host_stub.cpp -o $B/libaicam_host_asan.so
+    $R/ai-camera_amd/csrc/lsap.cpp $R/ai-camera_amd/csrc/assoc_host.cpp $R/ai-camera_amd/csrc/global_id.cpp $R/ai-camera_amd/csrc/host_stub.cpp -o $B/libaicam_host_asan.so
 echo $B/libaicam_host_asan.so
 if [ "$1" = "--test" ]; then
     LD_PRELOAD=$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so) ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 \

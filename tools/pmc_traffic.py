@@ -29,6 +29,9 @@ out = {
     "method": sys.argv[3],
 }
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, root)
+import importlib
+out["sources_digest"] = importlib.import_module("ai-camera_amd.build").sources_digest()   # bench.py quotes this file only for these sources
 try:    # algorithmic bytes of the same workload (library counter, AICAM_NO_TAPER=1 run).  What does not change with the kernels is the
         # TOTAL over the sampled launch groups; per launch it moves whenever launches are merged, so it is re-derived from the total
     prev = json.load(open(os.path.join(root, "profiles", "pmc_traffic.json")))

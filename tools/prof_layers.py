@@ -74,6 +74,17 @@ def main(d, frames=16, crops=480, top=30, fused_stem=1, fused_yolo_stem=1, fused
             else:
                 merged.append(L)
         layers = merged
+    if fused_block:     # 22.box{l}.0 and 22.cls{l}.0 read the same map: one conv with the output channels side by side (Model::Model merge)
+        merged = []
+        for L in layers:
+            if L[0] == "yolo" and L[1].startswith("22.cls") and L[1].endswith(".0"):
+                k = next((i for i, q in enumerate(merged) if q[1] == L[1].replace("cls", "box")), None)
+                if k is not None and merged[k][2] == L[2] and merged[k][4] == L[4]:
+                    q = merged[k]
+                    merged[k] = (q[0], q[1] + "+cls.0", q[2], q[3] + L[3], q[4])
+                    continue
+            merged.append(L)
+        layers = merged
     per = len(layers)
     # a launch group starts at its (fused) YOLO stem; groups of other sizes (tapered tail of a call: fewer frames, and below
     # the fused-block threshold two more launches) are dropped: keep the groups with `per` conv launches and the modal grid
