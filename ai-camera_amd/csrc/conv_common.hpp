@@ -170,8 +170,107 @@ template <int NT> __device__ __forceinline__ int perm_ch(int j, int q, int e) {
 }
 template <int NT> __device__ __forceinline__ int perm_row(int j, int r) { return perm_ch<NT>(j, r >> 2, r & 3); }
 
-template <typename T, int MT, int NT, int ACT, int RES, bool F32OUT>
+// fp16 output of whole tile pairs in PHASES, four or eight vectors at a time: their residual vectors are requested first (independent 16-byte
+// loads), then the eight output vectors are formed, then all eight are stored.  Written tile by tile (load -> add -> activate -> store) the compiler reuses
+// one set of data registers for every store and one for every residual and fences each reuse with s_waitcnt vmcnt(0) (stores count
+// in vmcnt on gfx950): 16 exposed store round trips per wave and, with a residual, 16 exposed load round trips on top -- the
+// 4.2 us (7.7 us with residual) a 512 x 128 tile spent after its last MFMA.  Same arithmetic, same roundings.
+template <int MT, int NT, int ACT, int RES>
+__device__ __forceinline__ void epilogue_wide_phased(const ConvArgs& a, floatx4 (&acc)[MT][NT], const int (&mrow)[MT], int n_base, int q) {
+    constexpr int NP = NT / 2, ODD = NT & 1, NV = NP + ODD;                  // vectors per pixel tile: NP of 8 channels (+ one of 4 for an odd last tile)
+    constexpr int VPP = (MT * NT >= 32) ? 4 : 8;                            // vectors per pass: 4 where the accumulators alone take 128 VGPRs
+    constexpr int MC = (MT * NV > VPP) ? (VPP / NV > 0 ? VPP / NV : 1) : MT;  // pixel tiles per pass
+    static_assert(MT % MC == 0, "whole passes");
+    const float* __restrict__ bias = a.bias;
+    const half_t* __restrict__ rg = reinterpret_cast<const half_t*>(a.res);
+    half_t* __restrict__ yg = reinterpret_cast<half_t*>(a.y);
+    floatx4 b4[NT];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int n = n_base + 32 * p + 8 * q;
+        b4[2 * p] = *reinterpret_cast<const floatx4*>(bias + n);          // bias is padded to cout_pad
+        b4[2 * p + 1] = *reinterpret_cast<const floatx4*>(bias + n + 4);
+    }
+    const int n_odd = n_base + 16 * (NT - 1) + 4 * q;                       // the odd last tile keeps the identity map: 4 channels per lane
+    if constexpr (ODD) b4[NT - 1] = *reinterpret_cast<const floatx4*>(bias + n_odd);
+#pragma unroll
+    for (int i0 = 0; i0 < MT; i0 += MC) {
+        half8 o[MC][NP > 0 ? NP : 1];
+        half4 o4[MC];
+        if constexpr (RES != 0) {                          // rows past the end / channels past Cout read a valid address (row 0; the pixel's
+#pragma unroll                                             // last channels) and are never stored
+            for (int i = 0; i < MC; ++i) {
+                const size_t rbase = (size_t)max(mrow[i0 + i], 0) * a.r_cs + a.r_coff;
+#pragma unroll
+                for (int p = 0; p < NP; ++p) o[i][p] = *reinterpret_cast<const half8*>(rg + rbase + min(n_base + 32 * p + 8 * q, a.Cout - 8));
+                if constexpr (ODD) o4[i] = *reinterpret_cast<const half4*>(rg + rbase + min(n_odd, a.Cout - 4));
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < MC; ++i) {
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = acc[i0 + i][2 * p + (e >> 2)][e & 3] + b4[2 * p + (e >> 2)][e & 3];
+                if constexpr (RES != 0) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = RES == 1 ? act_fast<ACT>(v[e] + (float)o[i][p][e]) : act_fast<ACT>(v[e]) + (float)o[i][p][e];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = act_fast<ACT>(v[e]);
+                }
+                o[i][p] = half8{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3], (half_t)v[4], (half_t)v[5], (half_t)v[6], (half_t)v[7]};
+            }
+            if constexpr (ODD) {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i0 + i][NT - 1][e] + b4[NT - 1][e];
+                if constexpr (RES != 0) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = RES == 1 ? act_fast<ACT>(v[e] + (float)o4[i][e]) : act_fast<ACT>(v[e]) + (float)o4[i][e];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = act_fast<ACT>(v[e]);
+                }
+                o4[i] = half4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+            }
+        }
+        // every output vector of the pass exists, in registers of its own, BEFORE its first store: left to itself the compiler sinks each
+        // vector's arithmetic into its store's predicated block and recycles one set of data registers, one s_waitcnt vmcnt(0) per store
+#pragma unroll
+        for (int i = 0; i < MC; ++i) {
+#pragma unroll
+            for (int p = 0; p < NP; ++p) asm volatile("" : "+v"(o[i][p]));
+            if constexpr (ODD) asm volatile("" : "+v"(o4[i]));
+        }
+#pragma unroll
+        for (int i = 0; i < MC; ++i) {
+            const int m = mrow[i0 + i];
+            const size_t ybase = (size_t)max(m, 0) * a.y_cs + a.y_coff;
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                const int n = n_base + 32 * p + 8 * q;
+                if (m >= 0 && n < a.Cout) *reinterpret_cast<half8*>(yg + ybase + n) = o[i][p];
+            }
+            if constexpr (ODD) {
+                if (m >= 0 && n_odd < a.Cout) *reinterpret_cast<half4*>(yg + ybase + n_odd) = o4[i];
+            }
+        }
+    }
+}
+
+// PHASED: only the 8-wave kernels ask for it.  They run one block per CU whatever their register count; in the 4-wave kernels the
+// extra live vectors cost occupancy (256 px x 64 ch tile: 240 -> 272 registers = one wave per SIMD instead of two, and YOLOv8n's
+// thin 1x1 layers ran 7 - 30 % slower: profiles/r03, first refresh).
+template <typename T, int MT, int NT, int ACT, int RES, bool F32OUT, bool PHASED = false>
 __device__ __forceinline__ void epilogue_wide(const ConvArgs& a, floatx4 (&acc)[MT][NT], const int (&mrow)[MT], int n_base, int q) {
+#ifndef AICAM_EPI_SERIAL                                   // (-DAICAM_EPI_SERIAL: the tile-by-tile form everywhere, A/B builds)
+    if constexpr (PHASED && sizeof(T) == 2 && !F32OUT) {
+        epilogue_wide_phased<MT, NT, ACT, RES>(a, acc, mrow, n_base, q);
+        return;
+    }
+#endif
     constexpr int NP = NT / 2;
     const float* __restrict__ bias = a.bias;
     const T* __restrict__ rg = reinterpret_cast<const T*>(a.res);
@@ -293,10 +392,10 @@ __device__ __forceinline__ void epilogue_generic(const ConvArgs& a, floatx4 (&ac
     }
 }
 
-template <typename T, int MT, int NT, bool PERM = false>
+template <typename T, int MT, int NT, bool PERM = false, bool PHASED = false>
 __device__ __forceinline__ void epilogue_dispatch(const ConvArgs& a, floatx4 (&acc)[MT][NT], const int (&mrow)[MT], int n_base, int q) {
     const int key = (a.Cout & (PERM ? 7 : 3)) ? -1 : (a.act | (a.res_mode << 2) | (a.out_f32 << 4));
-#define AIC_EPI(ACT, RES, F32) do { if constexpr (PERM) epilogue_wide<T, MT, NT, ACT, RES, F32>(a, acc, mrow, n_base, q); \
+#define AIC_EPI(ACT, RES, F32) do { if constexpr (PERM) epilogue_wide<T, MT, NT, ACT, RES, F32, PHASED>(a, acc, mrow, n_base, q); \
                                     else epilogue_fast<T, MT, NT, ACT, RES, F32>(a, acc, mrow, n_base, q); } while (0)
     switch (key) {
         case 1: AIC_EPI(1, 0, false); break;             // SiLU

@@ -459,7 +459,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const Conv
         static_assert(sizeof(T) == 2 && WN == 1, "the tail needs fp16 and a wave that owns every channel of its pixels");
         tail_1x1<MT, NT>(a, acc, mrow, lane);
     } else {
-        epilogue_dispatch<T, MT, NT, true>(a, acc, mrow, n0 + wn * NT * 16, q);
+        epilogue_dispatch<T, MT, NT, true, WM * WN == 8>(a, acc, mrow, n0 + wn * NT * 16, q);
     }
 }
 

@@ -64,6 +64,21 @@ __global__ __launch_bounds__(256) void conv3x3_c16_kernel(const ConvArgs a, int 
 
     half_t* yg = reinterpret_cast<half_t*>(a.y);
     const half_t* rg = reinterpret_cast<const half_t*>(a.res);
+    // The wave's four output vectors are formed first and stored afterwards, each from registers of its own (and the residual
+    // vectors are requested up front): stored tile by tile, one set of data registers is recycled and every store is fenced with
+    // s_waitcnt vmcnt(0) -- four exposed store round trips per wave (conv_common.hpp, epilogue_wide_phased)
+    typedef typename std::conditional<NCT == 1, half4, half8>::type ovec_t;
+    constexpr int NE = NCT == 1 ? 4 : 8;
+    const int ch = NCT == 1 ? 4 * q : 8 * q;                            // perm_ch<2>: tiles 0, 1 -> channels 8q + 4*(ct) + e
+    ovec_t o[4];
+    size_t pix[4];
+#pragma unroll
+    for (int tile = 0; tile < 4; ++tile) pix[tile] = ((size_t)img * a.Ho + oy0 + 2 * wv + (tile >> 1)) * a.Wo + ox0 + (tile & 1) * 16 + r;
+    const bool res = a.res_mode == 2;
+    if (res) {
+#pragma unroll
+        for (int tile = 0; tile < 4; ++tile) o[tile] = *reinterpret_cast<const ovec_t*>(rg + pix[tile] * a.r_cs + a.r_coff + ch);
+    }
 #pragma unroll
     for (int tile = 0; tile < 4; ++tile) {
         const int oyl = 2 * wv + (tile >> 1), oxl = (tile & 1) * 16 + r;
@@ -71,37 +86,26 @@ __global__ __launch_bounds__(256) void conv3x3_c16_kernel(const ConvArgs a, int 
         half8 xb[5];
 #pragma unroll
         for (int m = 0; m < 5; ++m) xb[m] = *reinterpret_cast<const half8*>(smem + base + d[m]);
-        const size_t pix = ((size_t)img * a.Ho + oy0 + oyl) * a.Wo + ox0 + oxl;
-        float v[NCT][4];
+        float v[NE];
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) {
             floatx4 acc = bi[ct];
 #pragma unroll
             for (int m = 0; m < 5; ++m) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[ct][m], xb[m], acc, 0, 0, 0);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[ct][e] = act_fast<1>(acc[e]);
+            for (int e = 0; e < 4; ++e) v[4 * ct + e] = act_fast<1>(acc[e]);
         }
-        if constexpr (NCT == 1) {
-            const int ch = 4 * q;
-            if (a.res_mode == 2) {
-                const half4 h = *reinterpret_cast<const half4*>(rg + pix * a.r_cs + a.r_coff + ch);
+        if (res) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[0][e] += (float)h[e];
-            }
-            const half4 o = {(half_t)v[0][0], (half_t)v[0][1], (half_t)v[0][2], (half_t)v[0][3]};
-            *reinterpret_cast<half4*>(yg + pix * a.y_cs + a.y_coff + ch) = o;
-        } else {
-            const int ch = 8 * q;                                       // perm_ch<2>: tiles 0, 1 -> channels 8q + 4*(ct) + e
-            if (a.res_mode == 2) {
-                const half8 h = *reinterpret_cast<const half8*>(rg + pix * a.r_cs + a.r_coff + ch);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e >> 2][e & 3] += (float)h[e];
-            }
-            const half8 o = {(half_t)v[0][0], (half_t)v[0][1], (half_t)v[0][2], (half_t)v[0][3],
-                             (half_t)v[1][0], (half_t)v[1][1], (half_t)v[1][2], (half_t)v[1][3]};
-            *reinterpret_cast<half8*>(yg + pix * a.y_cs + a.y_coff + ch) = o;
+            for (int e = 0; e < NE; ++e) v[e] += (float)o[tile][e];
         }
+#pragma unroll
+        for (int e = 0; e < NE; ++e) o[tile][e] = (half_t)v[e];
     }
+#pragma unroll
+    for (int tile = 0; tile < 4; ++tile) asm volatile("" : "+v"(o[tile]));
+#pragma unroll
+    for (int tile = 0; tile < 4; ++tile) *reinterpret_cast<ovec_t*>(yg + pix[tile] * a.y_cs + a.y_coff + ch) = o[tile];
 }
 
 template <int COUT, int S>

@@ -204,7 +204,7 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(const ConvArgs a) {
         const int m = m0 + (wm * MT + i) * 16 + r;
         mrow[i] = m < M ? m : -1;
     }
-    epilogue_dispatch<T, MT, NT, true>(a, acc, mrow, n0 + wn * NT * 16, q);
+    epilogue_dispatch<T, MT, NT, true, true>(a, acc, mrow, n0 + wn * NT * 16, q);
     if (g_pp_times_on) { wait_vmcnt<0>(); PP_STAMP(3); }
 }
 
@@ -465,7 +465,7 @@ __global__ __launch_bounds__(512) void conv3x3_pp_patch_kernel(const ConvArgs a,
         const int img = img0 + il;
         mrow[i] = img < n_img ? (img * a.Ho + oy0 + ly) * a.Wo + ox0 + lx : -1;
     }
-    epilogue_dispatch<T, MT, NT, true>(a, acc, mrow, n0 + wn * NT * 16, q);
+    epilogue_dispatch<T, MT, NT, true, true>(a, acc, mrow, n0 + wn * NT * 16, q);
 }
 
 template <typename T, int MT, int NT, int WM, int WN, int TH, int TW, int NSTAGE>

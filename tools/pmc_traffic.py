@@ -43,7 +43,7 @@ try:    # algorithmic bytes of the same workload (library counter, AICAM_NO_TAPE
         out["algorithmic_bytes_per_launch_same_basis"] = total / n1
 except Exception:
     pass
-tag = sys.argv[4] if len(sys.argv) > 4 else "r02"
+tag = sys.argv[4] if len(sys.argv) > 4 else "r03"
 for name in ("pmc_traffic.json", f"{tag}_pmc_traffic.json"):
     json.dump(out, open(os.path.join(root, "profiles", name), "w"), indent=1)
 print(json.dumps(out, indent=1))

@@ -5,10 +5,10 @@
 #   tools/refresh_profiles.sh [tag]      tag (default r02) prefixes every file copied into profiles/
 set -e
 R=$PWD
-TAG=${1:-r02}
+TAG=${1:-r03}
 O=$R/gpurun_out/refresh_$TAG
 rm -rf $O && mkdir -p $O
-B="--cpu-frames 0 --no-curve"
+B="--cpu-frames 0 --no-curve --no-own"     # the traces describe the headline workload only
 cd /tmp && export TMPDIR=/tmp
 # the bench command itself (from-host span) under the kernel trace: its conv durations must agree with the HIP-event figure of the bench line
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py $B > $O/bench_under_rocprof.json 2> $O/trace.log
