@@ -172,7 +172,7 @@ Model::Model(Device& d, const void* blob, size_t nbytes, int dtype_, int max_ite
     // ---- merge: two convs that read the SAME tensor slice with the same window, stride, padding and activation and no residual
     // (YOLOv8's detect branches: 22.box{l}.0 and 22.cls{l}.0 both start from the level's feature map) become ONE conv whose output
     // channels are the two sets side by side in one new buffer; their readers take channel slices of it.  The map is read once
-    // instead of twice and the GEMM is 144 wide instead of 64 and 80.  Per output channel nothing changes (same K order, same
+    // instead of twice and the GEMM is 144 wide instead of 64 and 80 (levels with maps up to 40 x 40, see below).  Per output channel nothing changes (same K order, same
     // epilogue): the head is bit-identical (tests/test_gpu_nets.py::test_merged_detect_branch_heads).  AICAM_NO_MERGE=1: off.
     if (dtype == AIC_F16 && !getenv("AICAM_NO_MERGE") && !getenv("AICAM_NO_FUSE")) {
         for (size_t i = 0; i < ops.size(); ++i) {
@@ -187,6 +187,11 @@ Model::Model(Device& d, const void* blob, size_t nbytes, int dtype_, int max_ite
                 if (!same || di == dj || c[5] != 0 || p[5] != 0 || c[7] != 3) continue;
                 const BufDesc bi = bufs[di], bj = bufs[dj];
                 if (bi.f32 || bj.f32 || bi.c != c[6] || bj.c != p[6] || bi.h != bj.h || bi.w != bj.w || (c[6] % vec) || (p[6] % vec)) continue;
+                // maps up to 40 x 40 only (measured, profiles/r03: on the 80 x 80 level the 64-channel conv has the 3x3 patch kernel at
+                // 645 TFLOP/s and the 144-wide 4-wave tile reaches 470: 1 157 us merged against 633 + 374; on the 40 x 40 and 20 x 20
+                // levels the merged conv wins, 490 against 513 us and 233 against 286)
+                static const int merge_px = [] { const char* e = getenv("AICAM_MERGE_MAXPX"); return e ? atoi(e) : 1600; }();
+                if (bi.h * bi.w > merge_px) continue;
                 bool clash = false;                     // the second conv now runs at the first one's place: nobody may touch its output in between,
                 for (size_t k = 0; k < ops.size(); ++k) {   // and nobody else may write either buffer
                     const int* u = ops[k].v;

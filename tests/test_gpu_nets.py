@@ -430,12 +430,15 @@ def test_fused_head_tail(gpu, engines, tmp_path):
 
 def test_merged_detect_branch_heads(gpu, engines, tmp_path):
     """22.box{l}.0 and 22.cls{l}.0 read the same feature map: the engine runs them as ONE conv with 64 + 80 output channels side by side
-    (Model::Model merges them at load time; their readers take channel slices).  Per output channel nothing changes, so the raw head
-    of 48 images (level 0 on the 512 x 144 tile, levels 1 / 2 on the 128 x 144 one) must be BIT-IDENTICAL to the engine loaded with
-    AICAM_NO_MERGE=1 in a child process, with three conv launches fewer."""
+    (Model::Model merges them at load time, on the levels where that is faster: maps up to 40 x 40; their readers take channel
+    slices).  Per output channel nothing changes, so the raw head of 48 images must be BIT-IDENTICAL to the engine loaded with
+    AICAM_NO_MERGE=1 in a child process, with two conv launches fewer (levels 1 and 2) -- and again with AICAM_MERGE_MAXPX=6400 in the
+    parent's place, which merges the 80 x 80 level too (three fewer: the 256 x 144 tile)."""
     x = np.random.default_rng(9).standard_normal((48, 3, 640, 640)).astype(np.float32) * 0.5
     (dfl, cls), n_f, (dfl_u, cls_u), n_u = _run_with_and_without_tail(tmp_path, engines[0], x, 48, "yolo_head_np", {"AICAM_NO_MERGE": "1"})
-    assert n_u - n_f == 3, (n_u, n_f)
+    assert n_u - n_f == 2, (n_u, n_f)
+    (_, _), _, (dfl_a, cls_a), n_a = _run_with_and_without_tail(tmp_path, engines[0], x, 48, "yolo_head_np", {"AICAM_MERGE_MAXPX": "6400"})
+    assert n_u - n_a == 3 and np.array_equal(dfl, dfl_a) and np.array_equal(cls, cls_a)
     assert np.abs(dfl).max() > 0.1 and np.abs(cls).max() > 0.1
     assert np.array_equal(dfl, dfl_u) and np.array_equal(cls, cls_u)
 

@@ -79,7 +79,7 @@ def main(d, frames=16, crops=480, top=30, fused_stem=1, fused_yolo_stem=1, fused
         for L in layers:
             if L[0] == "yolo" and L[1].startswith("22.cls") and L[1].endswith(".0"):
                 k = next((i for i, q in enumerate(merged) if q[1] == L[1].replace("cls", "box")), None)
-                if k is not None and merged[k][2] == L[2] and merged[k][4] == L[4]:
+                if k is not None and merged[k][2] == L[2] and merged[k][4] == L[4] and L[2] // frames <= 1600:     # maps up to 40 x 40 (engine.cpp)
                     q = merged[k]
                     merged[k] = (q[0], q[1] + "+cls.0", q[2], q[3] + L[3], q[4])
                     continue
