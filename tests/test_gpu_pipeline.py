@@ -386,6 +386,48 @@ def test_device_filter_crowded_groups_take_extra_reid_rounds(gpu, engines):
         config.CLASSES_TO_TRACK.update(old)
 
 
+def test_more_than_512_detections_in_a_frame_fall_back_to_the_host_chain(gpu, engines):
+    """The epoch kernel takes at most 512 detections per frame (one thread per detection); the host chain takes 1 536.  With
+    device_assoc = 2 ("always on the device") a launch group holding such a frame must take the host chain for that group -- not fail
+    the call with AIC_ERR_CAPACITY -- and give the rows of device_assoc = 0 (include/aicam.h: "same results in every mode").
+    max_det 700 at conf 0.02 with every class tracked and no tracker floor: 600+ detections in every frame."""
+    old = set(config.CLASSES_TO_TRACK)
+    config.CLASSES_TO_TRACK.clear()
+    config.CLASSES_TO_TRACK.update(config.CLASSES)
+    try:
+        n_frames = 6
+        sc = syn.Scene(seed=33, n_targets=8)
+        frames = sc.render_batch(0, n_frames)
+        TP = pkg("pipeline").TrackingPipeline
+        out = {}
+        for mode in (2, 0):
+            reid = HipEngine(engines[1], dtype="fp16", max_items=256, warm_up=False)
+            pipe = TP(engines[0], reid, (720, 1280), batch=2, ring_frames=n_frames, max_persons=64, dtype="fp16", inject=False, conf_thresh=0.02,
+                      max_det=700, min_confidence=0.0, n_init=2, max_tracks=512)
+            pipe.option("device_assoc", mode)
+            pipe.upload(0, frames)
+            try:
+                nt, rows, nd = (x.copy() for x in pipe.run_raw(0, n_frames))
+            except pkg("_lib").AicError as e:          # 700 new tracks in frame 0 exhaust the 512 track slots: the same loud capacity error in both modes
+                out[mode] = ("capacity", str(e))
+                pipe.close(), reid.close()
+                continue
+            c = pipe.counters()
+            out[mode] = (nt, rows, nd, c)
+            pipe.close(), reid.close()
+        a, b = out[2], out[0]
+        if a[0] == "capacity" or b[0] == "capacity":
+            assert a[0] == b[0] == "capacity" and "capacity" in a[1]
+        else:
+            assert a[2].min() > 512 and np.array_equal(a[2], b[2]) and np.array_equal(a[0], b[0])
+            for f in range(n_frames):
+                assert np.array_equal(a[1][f][:min(a[0][f], 64)], b[1][f][:min(b[0][f], 64)]), f
+            assert a[3]["assoc_host_frames"] == n_frames and a[3]["assoc_device_frames"] == 0      # mode 2 took the host chain for these groups
+    finally:
+        config.CLASSES_TO_TRACK.clear()
+        config.CLASSES_TO_TRACK.update(old)
+
+
 def test_association_mode_switches_between_launch_groups(gpu, engines):
     """Auto mode: the association of a launch group runs on the device while its problems are within the limit (default 128 tracks x 128
     detections; 64 here) and in host C++ beyond.  A scene that grows from 40 to 76 persons crosses that line mid-run, so the track table
