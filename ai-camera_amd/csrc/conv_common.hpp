@@ -178,7 +178,10 @@ template <int NT> __device__ __forceinline__ int perm_row(int j, int r) { return
 template <int MT, int NT, int ACT, int RES>
 __device__ __forceinline__ void epilogue_wide_phased(const ConvArgs& a, floatx4 (&acc)[MT][NT], const int (&mrow)[MT], int n_base, int q) {
     constexpr int NP = NT / 2, ODD = NT & 1, NV = NP + ODD;                  // vectors per pixel tile: NP of 8 channels (+ one of 4 for an odd last tile)
-    constexpr int VPP = (MT * NT >= 32) ? 4 : 8;                            // vectors per pass: 4 where the accumulators alone take 128 VGPRs
+    // vectors per pass: 4 where the accumulators alone take 128 VGPRs.  (With a residual the tile spends 9.8 us after its last MFMA instead
+    // of 3.8 -- AICAM_PP_TIMES; requesting all MT * NV residual vectors at once changes nothing, 9.2 us: it is not four exposed round
+    // trips but the 128 KB themselves, which a CU pulls from HBM at ~22 GB/s; from an L2-resident address the same tile takes 4.7 us.)
+    constexpr int VPP = (MT * NT >= 32) ? 4 : 8;
     constexpr int MC = (MT * NV > VPP) ? (VPP / NV > 0 ? VPP / NV : 1) : MT;  // pixel tiles per pass
     static_assert(MT % MC == 0, "whole passes");
     const float* __restrict__ bias = a.bias;
@@ -538,7 +541,7 @@ inline int conv_impl() {   // AICAM_CONV=v1 selects the register-staged kernel (
 
 // ---- host entry points of the other conv units; each returns false when the layer is not one of its shapes
 bool conv_try_pp_patch(int dtype, const ConvArgs& a, hipStream_t s);   // kernels_conv_pp.hip: v5 ping-pong patch (3x3/s1, Cout 128 / 256k)
-bool conv_pp_patch_shape(int dtype, const ConvArgs& a);                // true when conv_try_pp_patch would take this layer at a large enough batch
+int conv_pp_patch_shape(int dtype, const ConvArgs& a);                 // != 0 (the tile shape, pp_patch_shape) when conv_try_pp_patch would take this layer at a large enough batch
 bool conv_try_pp(int dtype, const ConvArgs& a, hipStream_t s);         // kernels_conv_pp.hip: v4 ping-pong im2col (long K, Cout 128 / 256k)
 bool conv_try_patch(int dtype, const ConvArgs& a, hipStream_t s);      // kernels_conv_direct.hip: 4-wave patch kernel (Cout 64 / 32)
 bool conv_try_patch_tail(const ConvArgs& a, hipStream_t s);            // same kernel, Cout 64, with a.w_tail's 1x1 in its epilogue (fp16)

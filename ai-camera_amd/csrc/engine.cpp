@@ -105,13 +105,16 @@ Model::Model(Device& d, const void* blob, size_t nbytes, int dtype_, int max_ite
     const int bke = 4 * vec;
     // one device weight = the output channels of one or more engine-file weights stacked (a merged conv, below)
     struct WSrc { const float* w; const float* b; int cout; };
-    auto pack_weights = [&](ConvWeights& w, const std::vector<WSrc>& parts, int cin, int kh, int kw) {
+    // `second` (one part only): a 1x1 conv of cin2 channels with the same output channels, folded in as K columns behind the window's
+    // (ConvArgs::x2); the bias becomes the sum of the two
+    auto pack_weights = [&](ConvWeights& w, const std::vector<WSrc>& parts, int cin, int kh, int kw, const WSrc* second = nullptr, int cin2 = 0) {
         w.cout = 0;
         for (const WSrc& p : parts) w.cout += p.cout;
         w.cin = cin, w.kh = kh, w.kw = kw;
         w.cin_eff = w.cin == 3 ? 8 : w.cin;
         AIC_REQUIRE(w.cin_eff % vec == 0, AIC_ERR_FORMAT, "conv input channels must be a multiple of 16 bytes");
-        w.K = w.kh * w.kw * w.cin_eff;
+        w.cin2 = second ? cin2 : 0;
+        w.K = w.kh * w.kw * w.cin_eff + w.cin2;
         w.Kp = round_up(w.K, bke);
         w.cout_pad = round_up(w.cout, 128) + 128;
         // + 8 K-steps of zero slack: the conv kernel's drain iterations step the weight pointer past the last row
@@ -130,6 +133,18 @@ Model::Model(Device& d, const void* blob, size_t nbytes, int dtype_, int max_ite
                         }
             std::copy(p.b, p.b + p.cout, bias.begin() + co0);
             co0 += p.cout;
+        }
+        if (second) {
+            const size_t k0 = (size_t)w.kh * w.kw * w.cin_eff;
+            for (int co = 0; co < second->cout; ++co) {
+                for (int ci = 0; ci < cin2; ++ci) {
+                    const float v = second->w[(size_t)co * cin2 + ci];
+                    const size_t k = (size_t)co * w.Kp + k0 + ci;
+                    if (dtype == AIC_F16) reinterpret_cast<uint16_t*>(packed.data())[k] = f32_to_f16_bits(v);
+                    else reinterpret_cast<float*>(packed.data())[k] = v;
+                }
+                bias[co] += second->b[co];
+            }
         }
         w.w.alloc(packed.size());
         HIP_CHECK(hipMemcpy(w.w.p, packed.data(), packed.size(), hipMemcpyHostToDevice));
@@ -167,6 +182,51 @@ Model::Model(Device& d, const void* blob, size_t nbytes, int dtype_, int max_ite
             }
             flops_per_item += 2.0 * db.h * db.w * (double)v[6] * v[3] * v[7] * v[8];
             ++n_convs;
+        }
+    }
+    // ---- fold: a ResNet downsample branch (1x1 / stride s, linear, read only as the residual of the block's last conv) into that conv:
+    // relu(conv3x3(t) + b + ds(x) + b') is ONE GEMM over K = [window of t | channels of x] (ConvArgs::x2).  The 1x1's launch goes away and
+    // with it its output tensor -- written once, read once, 2 GB per 15 360 crops on ReID layer2 (1.58 ms of downsample launches per
+    // 512-frame group, and the 9 us residual epilogue of the three convs that added them).  The sum no longer passes through an fp16
+    // rounding of the branch: closer to the fp32 oracle, not bit-identical to the unfolded graph (tests/test_gpu_nets.py).
+    // AICAM_NO_DS_FOLD=1: off.
+    if (dtype == AIC_F16 && !getenv("AICAM_NO_DS_FOLD") && !getenv("AICAM_NO_FUSE")) {
+        for (size_t j = 0; j < ops.size(); ++j) {
+            int* c = ops[j].v;
+            if (c[0] != OP_CONV || c[14] != 1 || ops[j].fuse || c[15] >= nw || c[13] != 0 || c[16] != 0) continue;
+            const int rbuf = c[12];
+            size_t i = ops.size();
+            for (size_t k = 0; k < j; ++k)
+                if (ops[k].v[0] == OP_CONV && ops[k].v[4] == rbuf && !ops[k].fuse) i = k;
+            if (i == ops.size()) continue;
+            const int* p = ops[i].v;
+            if (p[7] != 1 || p[8] != 1 || p[10] != 0 || p[11] != 0 || p[14] != 0 || p[5] != 0 || p[6] != c[6] || p[15] >= nw) continue;
+            if (bufs[rbuf].c != c[6] || bufs[rbuf].f32) continue;
+            bool clash = false;                         // nobody else reads or writes the branch's tensor; its source is still intact at the last conv
+            for (size_t k = 0; k < ops.size(); ++k) {
+                const int* u = ops[k].v;
+                if (k != i && u[4] == rbuf) clash = true;
+                if (u[1] == rbuf || (k != j && u[0] == OP_CONV && u[14] && u[12] == rbuf)) clash = true;
+                if (k > i && k <= j && u[4] == p[1]) clash = true;
+            }
+            for (auto& o : outs)
+                if (o.v[0] == rbuf) clash = true;
+            if (clash) continue;
+            const BufDesc& xb = bufs[c[1]];
+            const BufDesc& yb = bufs[c[4]];
+            ConvArgs q{};
+            q.H = xb.h, q.W = xb.w, q.Cin = c[3], q.Ho = yb.h, q.Wo = yb.w, q.Cout = c[6], q.KH = c[7], q.KW = c[8], q.stride = c[9], q.pad = c[10];
+            q.out_f32 = yb.f32;
+            if (!conv_x2_supported(dtype, q, p[3])) continue;
+            const WSrc second = wsrc_of(p[15]);
+            weights.emplace_back();
+            pack_weights(weights.back(), {wsrc_of(c[15])}, c[3], c[7], c[8], &second, p[3]);
+            c[15] = (int)weights.size() - 1;
+            c[14] = 0, c[12] = 0, c[13] = 0;            // no residual any more
+            c[16] = p[1] + 1, c[17] = p[2], c[18] = p[3], c[19] = p[9];
+            ops[i].fuse = 2;                            // absorbed: run_range skips it
+            storage[rbuf].release();
+            bufs[rbuf].p = nullptr;
         }
     }
     // ---- merge: two convs that read the SAME tensor slice with the same window, stride, padding and activation and no residual
@@ -390,6 +450,12 @@ void Model::run_range(size_t op0, size_t op1, int i0, int n, hipStream_t s) {
                 a.res = nullptr, a.r_cs = 0, a.r_coff = 0, a.res_mode = u[14], a.act = u[11];
                 if (u[14]) { a.res = at(bufs[u[12]]), a.r_cs = bufs[u[12]].c, a.r_coff = u[13]; }
                 a.KH = w.kh, a.KW = w.kw, a.stride = u[9], a.pad = u[10];
+                if (u[16]) {                            // folded 1x1 second source
+                    const BufDesc& b2 = bufs[u[16] - 1];
+                    a.x2 = at(b2), a.x2_cs = b2.c, a.x2_coff = u[17], a.H2 = b2.h, a.W2 = b2.w, a.s2 = u[19], a.Cin2 = u[18];
+                    fl += 2.0 * n * yb.h * yb.w * (double)w.cout * u[18];
+                    by += ((double)n * yb.h * yb.w * u[18] + (double)w.cout * u[18]) * (dtype == AIC_F16 ? 2 : 4);
+                }
                 a.Kp = w.Kp, a.M = n * yb.h * yb.w, a.out_f32 = yb.f32, a.cout_pad = w.cout_pad, a.zero = d_zero.p;
                 a.tap_rows = 0;
                 a.n_dev = n_items_dev;

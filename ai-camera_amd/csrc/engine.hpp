@@ -8,8 +8,11 @@ enum { OP_CONV = 1, OP_SPPF_POOL = 2, OP_UPSAMPLE2X = 3, OP_MAXPOOL3S2 = 4, OP_A
 enum { KIND_YOLO = 1, KIND_REID = 2 };
 
 struct BufDesc { int h, w, c, f32; void* p; size_t per_item; int esize; };
-struct ConvWeights { DevBuf<char> w; DevBuf<float> bias; int cout, cin, cin_eff, kh, kw, K, Kp, cout_pad; };
-struct OpDesc { int v[20]; int fuse = 0; };   // fuse: 1 = conv fused with the max-pool that follows, 2 = skipped (absorbed)
+struct ConvWeights { DevBuf<char> w; DevBuf<float> bias; int cout, cin, cin_eff, kh, kw, K, Kp, cout_pad; int cin2 = 0; };   // cin2: K columns of a folded 1x1 second source behind the window's
+// fuse: 1 = conv fused with the max-pool that follows, 2 = skipped (absorbed).  v[16..19] (0 in engine files) are set at load time for a
+// conv that took a 1x1 conv of another tensor in as a second source (ConvArgs::x2): v[16] = that tensor's buffer + 1, v[17] = its channel
+// offset, v[18] = its channels, v[19] = the 1x1's stride
+struct OpDesc { int v[20]; int fuse = 0; };
 struct OutDesc { int v[8]; };
 
 struct Model {

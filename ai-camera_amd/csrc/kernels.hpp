@@ -35,6 +35,12 @@ struct ConvArgs {
                         //   2 = (kw, cc, kh)  the order of the weights-resident 64-channel kernels (conv3x3_c64_resident / _block).
                         // Set by launch_conv_igemm from the layer SHAPE: a layer one of those kernels can take is accumulated in that
                         // kernel's order by EVERY kernel its batch size may select, so embeddings do not depend on the batch
+    // ---- optional SECOND SOURCE: a 1x1 conv of another tensor accumulated into the same outputs (ResNet's downsample branch folded into
+    // the block's last conv: relu(conv3x3(t) + b + conv1x1/s(x) + b') is ONE GEMM over K = [window of t | channels of x]).  The packed
+    // weight rows hold the window's K columns, then Cin2 more; `bias` is the sum of both.  Only layers walked chunk-major (k_order 1)
+    // by the LDS-DMA implicit-GEMM kernels take it; x2's K-steps come after the window's.  x2 == NULL: none.
+    const void* x2;       // NHWC, element type T; output pixel (oh, ow) reads x2 pixel (oh * s2, ow * s2)
+    int x2_cs, x2_coff, H2, W2, s2, Cin2;
     // ---- optional 1x1 "tail" conv run in this conv's epilogue (fp16 only; conv_tail_supported()).  This conv's own output
     // (SiLU(acc + bias) rounded to fp16, exactly what it would have stored) never leaves the registers: it is the B operand of
     // the tail's MFMAs.  y / y_cs / y_coff of THIS conv are then unused.  w_tail == NULL: no tail.
@@ -46,6 +52,8 @@ struct ConvArgs {
 // true when launch_conv_igemm can run `lead` with `tail` (a 1x1 / stride 1 / pad 0 conv reading exactly lead's output) in its epilogue:
 // fp16, lead = SiLU without residual with Cout 64 or 80 (a wave then owns every channel of its pixels), tail.Cout <= lead.Cout
 bool conv_tail_supported(int dtype, const ConvArgs& lead, const ConvArgs& tail);
+// true when launch_conv_igemm takes a conv of this shape (x2 fields ignored) with a second source (ConvArgs::x2) of cin2 channels
+bool conv_x2_supported(int dtype, const ConvArgs& a, int cin2);
 // dtype: AIC_F16 or AIC_F32 (type of x / w / res and, unless out_f32, y)
 void launch_conv_igemm(int dtype, const ConvArgs& a, hipStream_t s);
 // a whole 64-channel BasicBlock (c1: conv3x3+ReLU, c2: conv3x3 + block input, ReLU) in one fp16 kernel with the intermediate in

@@ -335,7 +335,27 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const Conv
         int tap = 0, kh = 0, kw = 0, cc = 0;
         const int kord = a.k_order;                 // != 0: K-steps in another order than memory's, source pointers rebuilt every step
         const bool cmaj = kord != 0;
+        // second source (ConvArgs::x2, chunk-major walks only): its channel chunk e is accumulated right after tap (0, 0) of the window's chunk
+        // e + 1 -- the place conv3x3_pp_patch_kernel has for it; every kernel walks the same order.  xs: the step being set up is that chunk, e = cc - 1
+        const int csteps2 = (a.x2 && kord == 1) ? a.Cin2 / BKE : 0;
+        bool xs = false;
         auto set_tap = [&] {
+            if (xs) {
+                const int c2 = cc - 1;
+#pragma unroll
+                for (int i = 0; i < A_PER; ++i) {
+                    const int m = m0 + r0 + RP * i;
+                    const T* p = zero;
+                    if (m < M) {
+                        int img, rem, oh, ow;
+                        fast_divmod(m, HoWo, inv_howo, img, rem);
+                        fast_divmod(rem, a.Wo, inv_wo, oh, ow);
+                        p = reinterpret_cast<const T*>(a.x2) + (((long)img * a.H2 + oh * a.s2) * a.W2 + ow * a.s2) * a.x2_cs + a.x2_coff + kc * CH + c2 * BKE;
+                    }
+                    aptr[i] = p, ainc[i] = 0;
+                }
+                return;
+            }
             const long toff = ((long)kh * a.W + kw) * a.x_cs + kc * CH + (cmaj ? cc * BKE : 0);
 #pragma unroll
             for (int i = 0; i < A_PER; ++i) {
@@ -353,15 +373,19 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const Conv
                 aptr[i] += ainc[i];
             }
             if (cmaj) {
-                const int koff = tap * a.Cin + cc * BKE;
+                const int koff = xs ? ntap * a.Cin + (cc - 1) * BKE : tap * a.Cin + cc * BKE;
 #pragma unroll
                 for (int j = 0; j < B_PER; ++j) {
                     const T* src = (winc[j] && cc < csteps) ? wptr[j] + koff : zero;
                     asm volatile("" : "+v"(src));
                     __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sbase + BM * 64 + j * (RP * 64)), 16, 0, 0);
                 }
-                if (kord == 1) {                        // (cc, kh, kw)
-                    if (++kw == a.KW) { kw = 0; if (++kh == a.KH) { kh = 0; ++cc; } }
+                if (kord == 1) {                        // (cc, kh, kw), the second source's chunk cc - 1 behind tap (0, 0) of chunks 1 .. csteps2
+                    if (!xs && kh == 0 && kw == 0 && cc >= 1 && cc <= csteps2 && cc < csteps) xs = true;
+                    else {
+                        xs = false;
+                        if (++kw == a.KW) { kw = 0; if (++kh == a.KH) { kh = 0; ++cc; } }
+                    }
                 } else {                                // (kw, cc, kh)
                     if (++kh == a.KH) { kh = 0; if (++cc == csteps) { cc = 0; ++kw; } }
                     if (kw == a.KW) { kw = 0; cc = csteps; }          // past the last step: zero page from here on
@@ -502,7 +526,7 @@ static void launch_conv_t(const ConvArgs& a_in, hipStream_t s) {
     const int c = a.Cout;
     constexpr int DT = sizeof(T) == 2 ? AIC_F16 : AIC_F32;
     if (conv_impl() == 2 && conv_try_pp_patch(DT, a, s)) return;
-    if (conv_impl() == 2 && conv_try_patch(DT, a, s)) return;
+    if (conv_impl() == 2 && !a.x2 && conv_try_patch(DT, a, s)) return;        // (a second source: the ping-pong patch kernel above or the LDS-DMA implicit GEMMs below)
     const long blocks128 = (long)ceil_div(a.M, 128);
     if (c % 128 == 0 || c > 160) {
         static const bool t256 = getenv("AICAM_NO_T256") == nullptr;   // +12% on ReID layer3/4 over 256x128 (profiles/)
@@ -550,6 +574,17 @@ bool conv_tail_supported(int dtype, const ConvArgs& lead, const ConvArgs& tail) 
     return true;
 }
 
+// A second source rides on the chunk-major walk of conv_igemm_dma_kernel / conv_igemm_pp_kernel: the layer must be one that every
+// batch size sends there in that order -- a ping-pong-patch SHAPE (k_order 1) whose Cout takes the 128-multiple branch of launch_conv_t.
+bool conv_x2_supported(int dtype, const ConvArgs& a, int cin2) {
+    static const bool off = getenv("AICAM_NO_X2") != nullptr;
+    const int bke = dtype == AIC_F16 ? 32 : 16;
+    if (off || conv_impl() != 2 || getenv("AICAM_K_TAP_MAJOR")) return false;
+    const int shape = conv_pp_patch_shape(dtype, a);             // 2: 512 x 128 tile, 3 / 4: 256 x 256 on 16 x 8 / 8 x 4 maps (shape 1, Cout 64, has no such kernel)
+    if (shape < 2 || a.Cout % 128 || a.w_tail || a.out_f32 || cin2 <= 0 || cin2 % bke) return false;
+    return cin2 / bke < a.Cin / bke;                             // its chunk e rides behind the window's chunk e + 1
+}
+
 static void launch_conv_tail(const ConvArgs& a, hipStream_t s) {
     if (a.Cout == 64) {
         if (conv_try_patch_tail(a, s)) return;
@@ -575,6 +610,7 @@ void launch_conv_igemm(int dtype, const ConvArgs& a0, hipStream_t s) {
                          a.Ho == a.H && a.Wo == a.W && ((a.W % 32 == 0 && a.H % 8 == 0) || (a.W == 32 && a.H % 4 == 0));
         a.k_order = conv_pp_patch_shape(dtype, a) ? 1 : (c64 ? 2 : 0);
     }
+    if (a.x2) AIC_REQUIRE(a.k_order == 1 && a.Cout % 128 == 0 && !a.w_tail, AIC_ERR_INVALID, "conv with a second source: unsupported shape (check conv_x2_supported)");
     if (a.w_tail) {
         AIC_REQUIRE(dtype == AIC_F16 && (a.Cout == 64 || a.Cout == 80) && a.act == 1 && a.res_mode == 0, AIC_ERR_INVALID,
                     "conv with a 1x1 tail: unsupported lead (check conv_tail_supported before setting w_tail)");

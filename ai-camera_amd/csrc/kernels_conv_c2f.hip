@@ -11,10 +11,13 @@
 // the 16 lanes that share a K slice read 16 consecutive pixels = 256 contiguous bytes (pixel-major 64- or 32-byte pixels put
 // lanes r and r + 4 / r + 8 on the same banks: 63 % LDS bank-conflict cycles measured, SQ_LDS_BANK_CONFLICT):
 //   X   4 planes [12 x 36]  the input tile with halo 2 (zeros outside the image)
-//   Y0  4 planes [12 x 36]  cv1's output: planes 0-1 = the pass-through half, 2-3 = the bottleneck's input; ZERO outside the
-//                           image (what the 3x3 convs' zero padding sees -- NOT cv1 applied to padding)
-//   T   2 planes [10 x 34]  m.cv1's output with halo 1, zero outside the image
-//   Y1  2 planes [ 8 x 32]  m.cv2's output + its input (the shortcut)
+//   Y0a 2 planes [ 8 x 32]  cv1's output, pass-through half: only cv2 reads it, and only at the tile's own pixels
+//   Y0b 2 planes [12 x 36]  cv1's output, the bottleneck's input, with halo 2; ZERO outside the image (what the 3x3 convs' zero
+//                           padding sees -- NOT cv1 applied to padding)
+//   T   2 planes [10 x 34]  m.cv1's output with halo 1, zero outside the image           } in X's place: X is dead once cv1 has run
+//   Y1  2 planes [ 8 x 32]  m.cv2's output + its input (the shortcut)                     }
+// 49.7 KB in all: three blocks per CU (the first form kept all four tensors apart and cv1's pass-through half with its halo, 74.7 KB, two
+// blocks per CU -- the kernel waits on its own latencies, SQ_WAIT_ANY 49 %, so residency is what it lacks).
 // MFMA conventions are those of conv3x3_c16_kernel (kernels_conv_direct.hip): weights = A operand (lane (r, q): row r, K elements
 // 8q..8q+7 of a 32-deep step), pixels = B operand (one aligned 16-byte ds_read per lane and step), a 3x3 over 16 channels =
 // 5 steps of two taps each with the bias as accumulator init; the 1x1 convs add the bias after the accumulation like the generic
@@ -50,8 +53,9 @@ __device__ __forceinline__ int x_slot(int p, int g) {
 #endif
 }
 static_assert((XR * XC) % 8 == 0, "swizzle group");
-constexpr int LDS_X = 0, LDS_Y0 = 4 * PX, LDS_T = LDS_Y0 + 4 * PX, LDS_Y1 = LDS_T + 2 * PT;
-constexpr int LDS_BYTES = LDS_Y1 + 2 * PY;
+constexpr int LDS_X = 0, LDS_T = 0, LDS_Y1 = LDS_T + 2 * PT, LDS_Y0A = 4 * PX, LDS_Y0B = LDS_Y0A + 2 * PY;
+constexpr int LDS_BYTES = LDS_Y0B + 2 * PX;
+static_assert(LDS_Y1 + 2 * PY <= 4 * PX, "T and Y1 live in X's place");
 
 }  // namespace
 
@@ -102,21 +106,31 @@ __global__ __launch_bounds__(256) void c2f16_fused_kernel(const C2fArgs a, int t
     for (int e = 0; e < 4; ++e) { bi2[e] = a.b2[4 * q + e]; bi3[e] = a.b3[4 * q + e]; }
     __syncthreads();
 
-    // ---- S2: cv1 on the 12 x 36 region (27 tiles of 16 pixels): Y0 = SiLU(W1 x + b1), zero outside the image
+    // ---- S2: cv1.  Channels 16-31 (the bottleneck's input) on the 12 x 36 region (27 tiles of 16 pixels): Y0b = SiLU(W1 x + b1), zero
+    // outside the image; channels 0-15 (pass-through) on the tile's own 8 x 32 pixels only
     for (int tile = wv; tile < (XR * XC) / 16; tile += 4) {
         const int p = tile * 16 + r;
         const half8 xb = *reinterpret_cast<const half8*>(smem + LDS_X + q * PX + x_slot(p, q) * 16);
         const int pr = p / XC, pc = p - pr * XC;
         const bool inside = (unsigned)(oy0 - 2 + pr) < (unsigned)a.H && (unsigned)(ox0 - 2 + pc) < (unsigned)a.W;
+        floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[1], xb, acc, 0, 0, 0);
+        half4 o;
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
-            floatx4 acc = {0.f, 0.f, 0.f, 0.f};
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[ct], xb, acc, 0, 0, 0);
-            half4 o;
+        for (int e = 0; e < 4; ++e) o[e] = inside ? (half_t)act_fast<1>(acc[e] + bi1[1][e]) : (half_t)0.f;
+        *reinterpret_cast<half4*>(smem + LDS_Y0B + (q >> 1) * PX + p * 16 + (q & 1) * 8) = o;
+    }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = inside ? (half_t)act_fast<1>(acc[e] + bi1[ct][e]) : (half_t)0.f;
-            *reinterpret_cast<half4*>(smem + LDS_Y0 + (2 * ct + (q >> 1)) * PX + p * 16 + (q & 1) * 8) = o;
-        }
+    for (int tile = 0; tile < 4; ++tile) {
+        const int oyl = 2 * wv + (tile >> 1), oxl = (tile & 1) * 16 + r;
+        const int p = (oyl + 2) * XC + oxl + 2;
+        const half8 xb = *reinterpret_cast<const half8*>(smem + LDS_X + q * PX + x_slot(p, q) * 16);
+        floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[0], xb, acc, 0, 0, 0);
+        half4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (half_t)act_fast<1>(acc[e] + bi1[0][e]);
+        *reinterpret_cast<half4*>(smem + LDS_Y0A + (q >> 1) * PY + (oyl * TW + oxl) * 16 + (q & 1) * 8) = o;
     }
     __syncthreads();
 
@@ -126,12 +140,12 @@ __global__ __launch_bounds__(256) void c2f16_fused_kernel(const C2fArgs a, int t
 #pragma unroll
         for (int m = 0; m < 5; ++m) {
             const int tap = min(2 * m + (q >> 1), 8), kh = tap / 3, kw = tap - 3 * kh;
-            d[m] = (2 + (q & 1)) * PX + (kh * XC + kw) * 16;
+            d[m] = (q & 1) * PX + (kh * XC + kw) * 16;
         }
         for (int tile = wv; tile < (TR * TC + 15) / 16; tile += 4) {
             const int p = min(tile * 16 + r, TR * TC - 1);
             const int pr = p / TC, pc = p - pr * TC;
-            const int base = LDS_Y0 + (pr * XC + pc) * 16;          // top-left tap of this output pixel
+            const int base = LDS_Y0B + (pr * XC + pc) * 16;         // top-left tap of this output pixel
             floatx4 acc = bi2;
 #pragma unroll
             for (int m = 0; m < 5; ++m)
@@ -161,7 +175,7 @@ __global__ __launch_bounds__(256) void c2f16_fused_kernel(const C2fArgs a, int t
 #pragma unroll
             for (int m = 0; m < 5; ++m)
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w3[m], *reinterpret_cast<const half8*>(smem + base + d[m]), acc, 0, 0, 0);
-            const half4 res = *reinterpret_cast<const half4*>(smem + LDS_Y0 + (2 + (q >> 1)) * PX + ((oyl + 2) * XC + oxl + 2) * 16 + (q & 1) * 8);
+            const half4 res = *reinterpret_cast<const half4*>(smem + LDS_Y0B + (q >> 1) * PX + ((oyl + 2) * XC + oxl + 2) * 16 + (q & 1) * 8);
             half4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = (half_t)(act_fast<1>(acc[e]) + (float)res[e]);
@@ -175,7 +189,8 @@ __global__ __launch_bounds__(256) void c2f16_fused_kernel(const C2fArgs a, int t
 #pragma unroll
     for (int tile = 0; tile < 4; ++tile) {
         const int oyl = 2 * wv + (tile >> 1), oxl = (tile & 1) * 16 + r;
-        const half8 x0 = *reinterpret_cast<const half8*>(smem + LDS_Y0 + q * PX + ((oyl + 2) * XC + oxl + 2) * 16);
+        const int a0 = q < 2 ? LDS_Y0A + q * PY + (oyl * TW + oxl) * 16 : LDS_Y0B + (q - 2) * PX + ((oyl + 2) * XC + oxl + 2) * 16;
+        const half8 x0 = *reinterpret_cast<const half8*>(smem + a0);
         const half8 x1 = *reinterpret_cast<const half8*>(smem + LDS_Y1 + (q & 1) * PY + (oyl * TW + oxl) * 16);   // k 32..47; k 48..63 meet zero weights
         float v[2][4];
 #pragma unroll

@@ -19,9 +19,9 @@ namespace aic {
 //        segments after the read was issued, hence after the late half's C_k.
 // Needs Cin % K-step == 0 (uniform tap per K-step) and 8 waves; one block per CU (LDS: NSTAGE stages).
 // Optional per-block phase timestamps (100 MHz wall clock) for tools/conv_bench.py: AICAM_PP_TIMES=1.
-__device__ unsigned long long g_pp_times[4 * 4096];
+__device__ unsigned long long g_pp_times[8 * 4096];     // [0, 4*4096): 100 MHz wall clock; [4*4096, 8*4096): shader clock (s_memtime)
 __device__ int g_pp_times_on;
-#define PP_STAMP(k) do { if (g_pp_times_on && threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 4096) g_pp_times[4 * blockIdx.x + (k)] = wall_clock64(); } while (0)
+#define PP_STAMP(k) do { if (g_pp_times_on && threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 4096) { g_pp_times[4 * blockIdx.x + (k)] = wall_clock64(); g_pp_times[4 * 4096 + 4 * blockIdx.x + (k)] = clock64(); } } while (0)
 
 template <typename T, int MT, int NT, int WM, int WN, int NSTAGE>
 __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(const ConvArgs a) {
@@ -115,7 +115,27 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(const ConvArgs a) {
     int tap = 0, kh = 0, kw = 0, cc = 0;
     const int kord = a.k_order;                 // != 0: K-steps in another order than memory's, source pointers rebuilt every step
     const bool cmaj = kord != 0;
+    // second source (ConvArgs::x2, chunk-major walks only): its channel chunk e is accumulated right after tap (0, 0) of the window's chunk
+    // e + 1 -- the place conv3x3_pp_patch_kernel has for it; every kernel walks the same order.  xs: the step being set up is that chunk, e = cc - 1
+    const int csteps2 = (a.x2 && kord == 1) ? a.Cin2 / BKE : 0;
+    bool xs = false;
     auto set_tap = [&] {
+        if (xs) {
+            const int c2 = cc - 1;
+#pragma unroll
+            for (int i = 0; i < A_PER; ++i) {
+                const int m = m0 + r0 + RP * i;
+                const T* p = zero;
+                if (m < M) {
+                    int img, rem, oh, ow;
+                    fast_divmod(m, HoWo, inv_howo, img, rem);
+                    fast_divmod(rem, a.Wo, inv_wo, oh, ow);
+                    p = reinterpret_cast<const T*>(a.x2) + (((long)img * a.H2 + oh * a.s2) * a.W2 + ow * a.s2) * a.x2_cs + a.x2_coff + kc * CH + c2 * BKE;
+                }
+                aptr[i] = p, ainc[i] = 0;
+            }
+            return;
+        }
         const long toff = ((long)kh * a.W + kw) * a.x_cs + kc * CH + (cmaj ? cc * BKE : 0);
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
@@ -133,15 +153,19 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(const ConvArgs a) {
             aptr[i] += ainc[i];
         }
         if (cmaj) {
-            const int koff = tap * a.Cin + cc * BKE;
+            const int koff = xs ? ntap * a.Cin + (cc - 1) * BKE : tap * a.Cin + cc * BKE;
 #pragma unroll
             for (int j = 0; j < B_PER; ++j) {
                 const T* src = (winc[j] && cc < csteps) ? wptr[j] + koff : zero;
                 asm volatile("" : "+v"(src));
                 __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sbase + BM * 64 + j * (RP * 64)), 16, 0, 0);
             }
-            if (kord == 1) {                        // (cc, kh, kw)
-                if (++kw == a.KW) { kw = 0; if (++kh == a.KH) { kh = 0; ++cc; } }
+            if (kord == 1) {                        // (cc, kh, kw), the second source's chunk cc - 1 behind tap (0, 0) of chunks 1 .. csteps2
+                if (!xs && kh == 0 && kw == 0 && cc >= 1 && cc <= csteps2 && cc < csteps) xs = true;
+                else {
+                    xs = false;
+                    if (++kw == a.KW) { kw = 0; if (++kh == a.KH) { kh = 0; ++cc; } }
+                }
             } else {                                // (kw, cc, kh)
                 if (++kh == a.KH) { kh = 0; if (++cc == csteps) { cc = 0; ++kw; } }
                 if (kw == a.KW) { kw = 0; cc = csteps; }          // past the last step: zero page from here on
@@ -173,14 +197,17 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(const ConvArgs a) {
 #pragma unroll
         for (int u = 0; u < NSTAGE; ++u) {
             if (step0 + u < nsteps) {
-                // ---- LOAD segment
-                issue((u + NSTAGE - 2) % NSTAGE);
+                // ---- LOAD segment: fragment reads first, LDS-DMA issue behind them (see conv3x3_pp_patch_kernel)
                 const char* base = smem + u * STAGE;
                 frag_t xf[MT], wf[NT];
 #pragma unroll
                 for (int j = 0; j < NT; ++j) wf[j] = *reinterpret_cast<const frag_t*>(base + woff[j]);
 #pragma unroll
                 for (int i = 0; i < MT; ++i) xf[i] = *reinterpret_cast<const frag_t*>(base + xoff[i]);
+#ifndef AICAM_PP_READS_LAST
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+                issue((u + NSTAGE - 2) % NSTAGE);
                 wait_vmcnt<(NSTAGE - 3) * LPS>();      // step+1 has landed (this wave's part)
                 __builtin_amdgcn_s_barrier();
                 // ---- COMPUTE segment
@@ -209,10 +236,16 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(const ConvArgs a) {
 }
 
 static void pp_times_report(hipStream_t s, int nblk) {
-    static std::vector<unsigned long long> h(4 * 4096);
+    static std::vector<unsigned long long> h(8 * 4096);
     HIP_CHECK(hipStreamSynchronize(s));
-    HIP_CHECK(hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_pp_times), sizeof(unsigned long long) * 4 * 4096));
+    HIP_CHECK(hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_pp_times), sizeof(unsigned long long) * 8 * 4096));
     nblk = std::min(nblk, 4096);
+    double cyc = 0, us = 0;                    // shader cycles / wall time of the K loops: the clock the chip holds inside them
+    for (int b = 0; b < nblk; ++b) {
+        cyc += (double)(h[4 * 4096 + 4 * b + 2] - h[4 * 4096 + 4 * b + 1]);
+        us += (double)(h[4 * b + 2] - h[4 * b + 1]) * 0.01;
+    }
+    fprintf(stderr, "[pp_times] k-loop: %.0f shader cycles per block, %.3f GHz\n", cyc / nblk, cyc / us * 1e-3);
     unsigned long long t0 = ~0ull, t3 = 0;
     double d[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
     for (int b = 0; b < nblk; ++b) {
@@ -282,8 +315,22 @@ constexpr int ppp_ipix_pad(int th, int tw) {
     return ipix;
 }
 
-template <typename T, int MT, int NT, int WM, int WN, int TH, int TW, int NSTAGE>
-__global__ __launch_bounds__(512) void conv3x3_pp_patch_kernel(const ConvArgs a, int tiles_x, int tiles_y) {
+// X2 (ConvArgs::x2: a 1x1 / stride-s conv of a second tensor accumulated into the same outputs -- a ResNet downsample branch folded into
+// the block's last conv): the second source's channel chunk e (BM pixels x one K-step) sits in a buffer of its own behind the weight ring.
+// It streams in during the window's chunk e in the LDS-DMA slots that carry no patch pass (taps 6 .. 8; the 512-pixel tile needs four
+// passes, two of them at tap 6, whose counted wait is one higher) and is consumed by ONE extra step right after tap (0, 0) of chunk e + 1:
+// the last pass is issued in L(tap 8), waited for in L(tap 0), read in L(extra) -- the usual two segments; the buffer is refilled from
+// tap 6 on, five steps after it was read.  The implicit-GEMM kernels walk the same order (set_tap / xs there).
+// lane id worked out on the spot (two v_mbcnt) and opaque to the optimiser: values derived from it inside the K loop are computed where
+// they are used instead of being carried through the loop in registers the 512 x 128 tile does not have
+__device__ __forceinline__ int lane_here() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+
+template <typename T, int MT, int NT, int WM, int WN, int TH, int TW, int NSTAGE, bool X2 = false>
+__global__ __launch_bounds__(512) void conv3x3_pp_patch_kernel(const ConvArgs a, int tiles_x, int tiles_y, int ny, int run) {
     constexpr int CH = 16 / (int)sizeof(T);
     constexpr int BKE = 4 * CH;
     constexpr int RP = 128;
@@ -298,21 +345,35 @@ __global__ __launch_bounds__(512) void conv3x3_pp_patch_kernel(const ConvArgs a,
     constexpr int NPASS = (NPIX + 127) / 128, NPIXP = NPASS * 128;
     constexpr int PLANE = NPIXP * 16, PBUF = 4 * PLANE, DUMMY = 8192, WSTAGE = BNP * 64;
     constexpr int RING = 2 * PBUF + DUMMY;
+    constexpr int EOFF = RING + NSTAGE * WSTAGE, NE = BM / 128;        // second source: buffer offset, LDS-DMA passes per chunk
     static_assert(WM * WN == 8 && BM % TPIX == 0 && NPASS <= 11 - NSTAGE && TW % 4 == 0 && NSTAGE >= 4, "geometry");
+    static_assert(!X2 || (NSTAGE == 4 && NPASS <= 5 && (NE == 2 || NE == 4) && MT % 2 == 0), "second source: slots at taps 6..8, counted waits of the 4-stage ring");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int t = threadIdx.x;
     const int lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
     const bool late = wv >= 4;
+    PP_STAMP(0);
     const int n_img = a.n_dev ? min(a.M / (a.Ho * a.Wo), a.n_dev[0]) : a.M / (a.Ho * a.Wo);     // device-side item count: the grid was sized for a bound
-    int bx, tby;
-    if (!xcd_tile_xy_live(a.xcd_map, ((n_img + NI - 1) / NI) * tiles_x * tiles_y, bx, tby)) return;
-    const int tx = bx % tiles_x; bx /= tiles_x;
-    const int ty = bx % tiles_y;
-    const int img0 = (bx / tiles_y) * NI;
-    const int oy0 = ty * TH, ox0 = tx * TW;
-    const int n0 = tby * BN;
+    // A block takes a RUN of `run` consecutive tiles (channel tile fastest, then the pixel tiles of an image, then images) and
+    // carries the pipeline across them: the weights of the next tile's first steps and its first patch chunk are in flight while the
+    // last chunk of this one is computed, so only the first tile of a run pays the 3-4.5 us prologue (and the block launch) that every
+    // tile used to pay -- a sixth of a layer2 tile's time (AICAM_PP_TIMES).  Runs, not tiles, are dealt to the XCDs in contiguous
+    // stretches; the live runs (device-side count) are re-dealt over the first blocks of the grid.
+    const int ntiles = ((n_img + NI - 1) / NI) * tiles_x * tiles_y * ny;
+    const int nruns = (ntiles + run - 1) / run;
+    if ((int)blockIdx.x >= nruns) return;
+    int t_cur = xcd_tile((int)blockIdx.x, nruns, a.xcd_map) * run;
+    const int t_end = min(t_cur + run, ntiles);
+    int img0, oy0, ox0, n0;                     // the tile being computed (block-uniform)
+    auto coords = [&](int tt, int& im, int& oy, int& ox, int& nn) {
+        const int nt = tt % ny; int m = tt / ny;
+        const int tx = m % tiles_x; m /= tiles_x;
+        const int ty = m % tiles_y;
+        im = (m / tiles_y) * NI, oy = ty * TH, ox = tx * TW, nn = nt * BN;
+    };
+    coords(t_cur, img0, oy0, ox0, n0);
 
     const T* __restrict__ xg = reinterpret_cast<const T*>(a.x);
     const T* __restrict__ wg = reinterpret_cast<const T*>(a.w);
@@ -320,49 +381,68 @@ __global__ __launch_bounds__(512) void conv3x3_pp_patch_kernel(const ConvArgs a,
 
     // ---- patch passes: pass i, wave w -> plane w&3, pixels i*128 + (w>>2)*64 + lane
     const int plane = wv & 3;
-    int poff[NPASS];                       // element offset of this thread's chunk at channel chunk 0, or -1 (zero page)
-#pragma unroll
-    for (int i = 0; i < NPASS; ++i) {
-        const int p = i * 128 + (wv >> 2) * 64 + lane;
+    // The source element of pass i is worked out when the pass is issued (some twenty VALU instructions in a LOAD segment that has
+    // room for them) instead of living in NPASS registers: with the tile loop around it the kernel has no register to spare, and every
+    // spilled value reloaded after an epilogue is an s_waitcnt vmcnt(0) -- 8 us per tile on the 512 x 128 tile.
+    char* const pdst = smem + plane * PLANE + (wv >> 2) * 1024;     // + buffer*PBUF + pass*2048 (+ lane*16 by the DMA)
+    auto issue_patch = [&](int i, int buf, int chunk_off, int im0, int oy, int ox) {        // i: compile-time pass index; tile (im0, oy, ox)
+        const int p = i * 128 + (wv >> 2) * 64 + lane_here();
         const int il = p / IPIXP, rem = p - il * IPIXP;
         const int py = rem / PW, px = rem - py * PW;
-        const int img = img0 + il, iy = oy0 + py - 1, ix = ox0 + px - 1;
+        const int img = im0 + il, iy = oy + py - 1, ix = ox + px - 1;
         const bool ok = p < NPIX && rem < IPIX && img < n_img && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-        poff[i] = ok ? (((img * a.H + iy) * a.W + ix) * a.x_cs + a.x_coff + plane * CH) : -1;
-    }
-    char* const pdst = smem + plane * PLANE + (wv >> 2) * 1024;     // + buffer*PBUF + pass*2048 (+ lane*16 by the DMA)
-    auto issue_patch = [&](int i, int buf, int chunk_off) {        // i: compile-time pass index
-        const T* src = poff[i] >= 0 ? xg + poff[i] + chunk_off : zero;
+        const T* src = ok ? xg + (((img * a.H + iy) * a.W + ix) * a.x_cs + a.x_coff + plane * CH + chunk_off) : zero;
         asm volatile("" : "+v"(src));
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(pdst + buf * PBUF + i * 2048), 16, 0, 0);
     };
     auto issue_dummy = [&] {
-        const T* src = zero;
+        const T* z = zero;
+        asm volatile("" : "+s"(z));                 // the address is copied from its scalar registers here: a vector copy carried through the loop was spilled
+        const T* src = z;
         asm volatile("" : "+v"(src));
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + 2 * PBUF + wv * 1024), 16, 0, 0);
     };
 
-    // ---- weight stream: row r0 + RP*j of the block's channel tile, K offset of step (chunk c, tap) = tap*Cin + c*BKE
+    // ---- weight stream: row r0 + RP*j of the tile's channel tile, K offset of step (chunk c, tap) = tap*Cin + c*BKE.  The stream runs
+    // NSTAGE - 2 steps ahead of the compute and simply continues with the next tile of the run (n0_w: the channel tile it fetches for)
     const int slot = t & 3, r0 = t >> 2;
     const int kc = slot ^ lds_swz(r0);
     int wofs[B_PER];                          // element offset of this thread's weight chunk at K = 0, or -1 (zero page)
+    auto set_wofs = [&](int nn) {
 #pragma unroll
-    for (int j = 0; j < B_PER; ++j) wofs[j] = (r0 + RP * j < BN) ? (n0 + r0 + RP * j) * a.Kp + kc * CH : -1;
-    const int nchunks = a.Cin / BKE, nsteps = 9 * nchunks;
+        for (int j = 0; j < B_PER; ++j) wofs[j] = (r0 + RP * j < BN) ? (nn + r0 + RP * j) * a.Kp + kc * CH : -1;
+    };
+    set_wofs(n0);
+    const int nchunks = a.Cin / BKE;
+    const int ns2 = X2 ? a.Cin2 / BKE : 0;           // chunks of the second source (< nchunks)
+    const int nsteps = 9 * nchunks + ns2;
     char* const wdst = smem + RING + (16 * wv) * 64;
     int is_c = 0, is_tap = 0, is_k = 0, is_st = 0;   // the step whose weights are fetched next (and its ring stage)
+    bool is_x = false;                               // ... is the second source's chunk is_c - 1
+    int n0_next = n0;                               // channel tile of the run's next tile (== n0 when there is none)
+    bool has_next = false;
     auto issue_w = [&] {
-        const int koff = is_tap * a.Cin + is_c * BKE;
+        const int koff = (X2 && is_x) ? 9 * a.Cin + (is_c - 1) * BKE : is_tap * a.Cin + is_c * BKE;
         char* sbase = wdst + is_st * WSTAGE;
 #pragma unroll
         for (int j = 0; j < B_PER; ++j) {
-            const T* src = (wofs[j] >= 0 && is_k < nsteps) ? wg + wofs[j] + koff : zero;
+            // nothing to fetch (a row past the tile, a step past the end): a weight row past Cout -- rows Cout .. cout_pad - 1 of the packed
+            // weights are zeros -- so that the select is one 32-bit offset and no vector copy of the zero page's address lives in the loop
+            const T* src = wg + ((wofs[j] >= 0 && is_k < nsteps) ? wofs[j] + koff : a.Cout * a.Kp);
             asm volatile("" : "+v"(src));
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sbase + j * (RP * 64)), 16, 0, 0);
         }
         ++is_k;
         if (++is_st == NSTAGE) is_st = 0;
-        if (++is_tap == 9) { is_tap = 0; ++is_c; }
+        if (X2 && !is_x && is_tap == 0 && is_c >= 1 && is_c <= ns2) is_x = true;
+        else {
+            is_x = false;
+            if (++is_tap == 9) { is_tap = 0; ++is_c; }
+        }
+        if (is_k == nsteps && has_next) {            // the stream moves on to the next tile of the run
+            is_k = 0, is_c = 0, is_tap = 0;
+            if (ny > 1) set_wofs(n0_next);
+        }
     };
 
     const int wm = wv / WN, wn = wv % WN;
@@ -393,15 +473,13 @@ __global__ __launch_bounds__(512) void conv3x3_pp_patch_kernel(const ConvArgs a,
     static_assert(NT % 2 == 0, "tile pairs");
 
     floatx4 acc[MT][NT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
     typedef typename Frag<T>::type frag_t;
 
-    // ---- prologue: patch chunk 0, weights of steps 0 and 1
+    // ---- prologue (first tile of the run only): patch chunk 0, weights of steps 0 and 1
 #pragma unroll
-    for (int i = 0; i < NPASS; ++i) issue_patch(i, 0, 0);
+    for (int i = 0; i < NPASS; ++i) issue_patch(i, 0, 0, img0, oy0, ox0);
+    has_next = !X2 && t_cur + 1 < t_end;        // (second-source kernels: one tile per block -- they have no register for the run's state)
+    if (has_next) { int i0, y0, x0; coords(t_cur + 1, i0, y0, x0, n0_next); }
 #pragma unroll
     for (int st = 0; st < NSTAGE - 2; ++st) {
         issue_w();
@@ -409,19 +487,65 @@ __global__ __launch_bounds__(512) void conv3x3_pp_patch_kernel(const ConvArgs a,
     }
     wait_vmcnt<(NSTAGE - 3) * LPS>();          // patch chunk 0 and the weights of step 0 have landed (this wave's part)
     __builtin_amdgcn_s_barrier();
-    if (late) __builtin_amdgcn_s_barrier();
+    PP_STAMP(1);
 
     int rd_st = 0;                             // ring stage of the step being computed
+    int img_n = img0, oy_n = oy0, ox_n = ox0;   // the run's next tile
+    // second source: pass p of chunk e -> rows p * 128 + t / 4 of the tile (rows in the order of mrow below), K-chunk kc of the row's 64 bytes
+    auto issue_e = [&](int p, int e, bool on) {
+        const int ln = lane_here(), rl = 16 * wv + (ln >> 2), kcl = (ln & 3) ^ lds_swz(rl);      // r0 and kc of this thread, worked out here
+        const int m = p * 128 + rl;
+        int il, ly, lx;
+        if constexpr (G == 1) {
+            il = m / TPIX;
+            const int rem = m - il * TPIX;
+            ly = rem / TW, lx = rem - ly * TW;
+        } else {
+            const int tl = m >> 4, rr = m & 15;
+            il = (tl / TH) * G + rr / TW, ly = tl % TH, lx = rr % TW;
+        }
+        const int img = img0 + il;
+        const T* src = (on && img < n_img) ? reinterpret_cast<const T*>(a.x2) + (((long)img * a.H2 + (oy0 + ly) * a.s2) * a.W2 + (ox0 + lx) * a.s2) * a.x2_cs +
+                                                 a.x2_coff + e * BKE + kcl * CH
+                                           : zero;
+        asm volatile("" : "+v"(src));
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + EOFF + p * 8192 + (16 * wv) * 64), 16, 0, 0);
+    };
+    auto xstep = [&](int) {                    // the extra step: weights from the ring as ever, pixels from the second source's buffer
+        const int so = rd_st * WSTAGE;
+        if (++rd_st == NSTAGE) rd_st = 0;
+        frag_t xf[MT], wf[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) wf[j] = *reinterpret_cast<const frag_t*>(smem + woff2[j & 1] + so + (j >> 1) * 2048);
+        const int ln = lane_here(), rr = ln & 15, qq = ln >> 4;     // (the two addresses are worked out here, not carried -- and spilled -- through the loop)
+        const int eb = EOFF + (wm * MT * 16 + rr) * 64, s0 = lds_swz(rr), e0 = eb + 16 * (qq ^ s0), e1 = eb + 16 * (qq ^ s0 ^ 2);   // rows 16 apart: swizzle bit 1 flips
+#pragma unroll
+        for (int i = 0; i < MT; ++i) xf[i] = *reinterpret_cast<const frag_t*>(smem + ((i & 1) ? e1 : e0) + i * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+        issue_w();
+        issue_dummy();
+        wait_vmcnt<(NSTAGE - 3) * LPS>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+        mma_tiles<T, MT, NT>(acc, wf, xf);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+    };
     auto chunk = [&](int c, auto bufc) {       // bufc: compile-time parity of the patch buffer read in this chunk
         constexpr int BUF = decltype(bufc)::value;
-        const bool more = c + 1 < nchunks;
-        const int noff = (c + 1) * BKE;
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            // ---- LOAD segment
-            issue_w();
-            if (tap >= 1 && tap <= NPASS && more) issue_patch(tap >= 1 && tap <= NPASS ? tap - 1 : 0, BUF ^ 1, noff);
-            else issue_dummy();
+        // the patch that streams in during this chunk: the next channel chunk of this tile, or -- in the last chunk -- chunk 0 of the
+        // run's next tile (nchunks is even: that is buffer 0, where every tile starts)
+        const bool inner = c + 1 < nchunks;
+        const bool more = inner || has_next;
+        const int noff = inner ? (c + 1) * BKE : 0;
+        const int p_im = inner ? img0 : img_n, p_oy = inner ? oy0 : oy_n, p_ox = inner ? ox0 : ox_n;
+        static_for<9>([&](auto tapc) {
+            constexpr int tap = decltype(tapc)::value;
+            // ---- LOAD segment: the fragment reads, then the LDS-DMA issue (an LDS-DMA costs 60-185 cycles to issue)
+            constexpr bool EP = X2 && tap >= 6 && tap >= 9 - NE + (NE == 4 ? 1 : 0);      // this tap's spare slot carries a pass of the second source
             const int so = rd_st * WSTAGE;
             if (++rd_st == NSTAGE) rd_st = 0;
             const int tapoff = BUF * PBUF + ((tap / 3) * PW + tap % 3) * 16;
@@ -430,7 +554,17 @@ __global__ __launch_bounds__(512) void conv3x3_pp_patch_kernel(const ConvArgs a,
             for (int j = 0; j < NT; ++j) wf[j] = *reinterpret_cast<const frag_t*>(smem + woff2[j & 1] + so + (j >> 1) * 2048);
 #pragma unroll
             for (int i = 0; i < MT; ++i) xf[i] = *reinterpret_cast<const frag_t*>(smem + xa0 + tapoff + patch_pix(16 * i) * 16);
-            wait_vmcnt<(NSTAGE - 3) * LPS>();
+            __builtin_amdgcn_sched_barrier(0);
+            issue_w();
+            if (tap >= 1 && tap <= NPASS && more) issue_patch(tap >= 1 && tap <= NPASS ? tap - 1 : 0, BUF ^ 1, noff, p_im, p_oy, p_ox);
+            else if constexpr (!EP) issue_dummy();
+            if constexpr (EP) {
+                if constexpr (NE == 4) {
+                    if (tap == 6) { issue_e(0, c, c < ns2); issue_e(1, c, c < ns2); } else issue_e(tap - 5, c, c < ns2);
+                } else issue_e(tap - 7, c, c < ns2);
+            }
+            if constexpr (X2 && NE == 4 && tap == 6) wait_vmcnt<(NSTAGE - 3) * LPS + 1>();
+            else wait_vmcnt<(NSTAGE - 3) * LPS>();
             __builtin_amdgcn_s_barrier();
             // ---- COMPUTE segment
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -440,51 +574,91 @@ __global__ __launch_bounds__(512) void conv3x3_pp_patch_kernel(const ConvArgs a,
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
-        }
+            if constexpr (X2 && tap == 0) {
+                if (c >= 1 && c <= ns2) xstep(0);
+            }
+        });
     };
-    for (int c = 0; c < nchunks; c += 2) {     // Cin / BKE is even for every layer that reaches this kernel
-        chunk(c, std::integral_constant<int, 0>{});
-        chunk(c + 1, std::integral_constant<int, 1>{});
-    }
-    if (!late) __builtin_amdgcn_s_barrier();
-    wait_vmcnt<0>();
-
-    int mrow[MT];
+    for (;;) {
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        int il, ly, lx;
-        if constexpr (G == 1) {
-            const int ml = (wm * MT + i) * 16 + r;
-            il = ml / TPIX;
-            const int rem = ml - il * TPIX;
-            ly = rem / TW, lx = rem - ly * TW;
-        } else {
-            const int tl = wm * MT + i;
-            il = (tl / TH) * G + r / TW, ly = tl % TH, lx = r % TW;
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+        if (has_next) coords(t_cur + 1, img_n, oy_n, ox_n, n0_next);
+        if (late) __builtin_amdgcn_s_barrier();    // waves 4..7 run one segment behind
+        for (int c = 0; c < nchunks; c += 2) {     // Cin / BKE is even for every layer that reaches this kernel
+            chunk(c, std::integral_constant<int, 0>{});
+            chunk(c + 1, std::integral_constant<int, 1>{});
         }
-        const int img = img0 + il;
-        mrow[i] = img < n_img ? (img * a.Ho + oy0 + ly) * a.Wo + ox0 + lx : -1;
+        if (!late) __builtin_amdgcn_s_barrier();   // every wave has executed the same number of barriers: both halves store together
+        if (!has_next) wait_vmcnt<0>();
+        if (!has_next) PP_STAMP(2);
+
+        int mrow[MT];
+        const int ln = lane_here(), rr = ln & 15, qe = ln >> 4;    // (hoisted out of the tile loop, the lane parts of the eight rows are 24 registers the
+                                                                    //  kernel does not have -- they were spilled and reloaded one wait at a time)
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            int il, ly, lx;
+            if constexpr (G == 1) {
+                const int ml = (wm * MT + i) * 16 + rr;
+                il = ml / TPIX;
+                const int rem = ml - il * TPIX;
+                ly = rem / TW, lx = rem - ly * TW;
+            } else {
+                const int tl = wm * MT + i;
+                il = (tl / TH) * G + rr / TW, ly = tl % TH, lx = rr % TW;
+            }
+            const int img = img0 + il;
+            mrow[i] = img < n_img ? (img * a.Ho + oy0 + ly) * a.Wo + ox0 + lx : -1;
+        }
+        epilogue_dispatch<T, MT, NT, true, true>(a, acc, mrow, n0 + wn * NT * 16, qe);
+        if (!has_next) break;
+        ++t_cur;
+        img0 = img_n, oy0 = oy_n, ox0 = ox_n, n0 = n0_next;
+        has_next = !X2 && t_cur + 1 < t_end;
     }
-    epilogue_dispatch<T, MT, NT, true, true>(a, acc, mrow, n0 + wn * NT * 16, q);
+    if (g_pp_times_on) { wait_vmcnt<0>(); PP_STAMP(3); }
 }
 
-template <typename T, int MT, int NT, int WM, int WN, int TH, int TW, int NSTAGE>
+template <typename T, int MT, int NT, int WM, int WN, int TH, int TW, int NSTAGE, bool X2 = false>
 static bool launch_pp_patch(const ConvArgs& a, hipStream_t s) {
     constexpr int BM = WM * MT * 16, BN = WN * NT * 16, BNP = (BN + 127) / 128 * 128;
     constexpr int NI = BM / (TH * TW), NPIX = NI * ppp_ipix_pad(TH, TW), NPASS = (NPIX + 127) / 128;
-    constexpr size_t lds = (size_t)2 * 4 * NPASS * 128 * 16 + 8192 + (size_t)NSTAGE * BNP * 64;
+    constexpr size_t lds = (size_t)2 * 4 * NPASS * 128 * 16 + 8192 + (size_t)NSTAGE * BNP * 64 + (X2 ? BM * 64 : 0);
     static_assert(lds <= 160 * 1024, "does not fit the LDS");
     if (a.H % TH || a.W % TW || a.Ho != a.H || a.Wo != a.W) return false;
     const int tiles_x = a.W / TW, tiles_y = a.H / TH;
     const int n_img = a.M / (a.Ho * a.Wo);
-    auto kfn = conv3x3_pp_patch_kernel<T, MT, NT, WM, WN, TH, TW, NSTAGE>;
+    auto kfn = conv3x3_pp_patch_kernel<T, MT, NT, WM, WN, TH, TW, NSTAGE, X2>;
     static bool attr = false;
     if (!attr) {
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr = true;
     }
-    dim3 grid(ceil_div(n_img, NI) * tiles_x * tiles_y, ceil_div(a.Cout, BN));
-    hipLaunchKernelGGL(kfn, grid, dim3(512), lds, s, a, tiles_x, tiles_y);
+    // tiles per block: at most AICAM_PPP_RUN (default 6).  Same box, 15 360 crops: layer2 conv1 1 993 (one tile per block, the kernel before) ->
+    // 1 975 / 1 945 / 1 912 us at runs of 1 / 4 / 6; with a residual 2 257 -> 2 256 (its 9 us epilogue is what is left); layer3 / 4 -2 % / 0
+    static const int run_max = [] { const char* e = getenv("AICAM_PPP_RUN"); return e ? std::max(1, atoi(e)) : 6; }();
+    const int ny = ceil_div(a.Cout, BN);
+    const long ntiles = (long)ceil_div(n_img, NI) * tiles_x * tiles_y * ny;
+    int run = 1;                                  // (second source: one tile per block)  the longest run that does not add a round of tiles (256 CUs, one block each) and leaves >= 4 rounds of blocks
+    {
+        long best = -1;
+        for (int r = 1; r <= (X2 ? 1 : run_max); ++r) {
+            const long blocks = (ntiles + r - 1) / r, rounds = (blocks + 255) / 256;
+            if (r > 1 && rounds < 4) break;
+            const long cost = rounds * r;                 // tile times until the last block ends
+            if (best < 0 || cost <= best) best = cost, run = r;
+        }
+    }
+    static const bool times = getenv("AICAM_PP_TIMES") != nullptr;
+    if (times) {
+        const int on = 1;
+        HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_pp_times_on), &on, sizeof(int)));
+    }
+    const int nblk = (int)ceil_div(ntiles, (long)run);
+    hipLaunchKernelGGL(kfn, dim3(nblk), dim3(512), lds, s, a, tiles_x, tiles_y, ny, run);
+    if (times) { KCHECK(); pp_times_report(s, nblk); }
     KCHECK();
     return true;
 }
@@ -517,6 +691,12 @@ static bool try_pp_patch(const ConvArgs& a, hipStream_t s) {
     if ((long)a.M * a.x_cs >= (1l << 31)) return false;                       // 32-bit element offsets inside the kernel
     const int c = a.Cout;
     const bool deep = ppp_mode() & 8;
+    if (a.x2) {                                     // a second source (conv_x2_supported: shapes 2, 3 and 4)
+        if (shape == 2 && a.M / 512 >= pp_min) return launch_pp_patch<T, 8, 4, 4, 2, 32, 16, 4, true>(a, s);
+        if (shape == 3 && (long)(a.M / 256) * (c / 256) >= pp_min) return launch_pp_patch<T, 8, 4, 2, 4, 16, 8, 4, true>(a, s);
+        if (shape == 4 && (long)(a.M / 256) * (c / 256) >= pp_min) return launch_pp_patch<T, 8, 4, 2, 4, 8, 4, 4, true>(a, s);
+        return false;
+    }
     if (shape == 1 && a.M / 512 >= pp_min) return deep ? launch_pp_patch<T, 4, 4, 8, 1, 16, 32, 6>(a, s) : launch_pp_patch<T, 4, 4, 8, 1, 16, 32, 4>(a, s);
     if (shape == 2 && a.M / 512 >= pp_min) return deep ? launch_pp_patch<T, 8, 4, 4, 2, 32, 16, 6>(a, s) : launch_pp_patch<T, 8, 4, 4, 2, 32, 16, 4>(a, s);
     if (shape >= 3 && (long)(a.M / 256) * (c / 256) >= pp_min) {
@@ -531,8 +711,8 @@ bool conv_try_pp_patch(int dtype, const ConvArgs& a, hipStream_t s) {
     return dtype == AIC_F16 ? try_pp_patch<half_t>(a, s) : try_pp_patch<float>(a, s);
 }
 
-bool conv_pp_patch_shape(int dtype, const ConvArgs& a) {
-    return (dtype == AIC_F16 ? pp_patch_shape<half_t>(a) : pp_patch_shape<float>(a)) != 0;
+int conv_pp_patch_shape(int dtype, const ConvArgs& a) {
+    return dtype == AIC_F16 ? pp_patch_shape<half_t>(a) : pp_patch_shape<float>(a);
 }
 
 // Ping-pong kernels (one block per CU) where the K loop is long enough to amortise the tile's prologue/epilogue:

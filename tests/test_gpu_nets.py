@@ -443,6 +443,27 @@ def test_merged_detect_branch_heads(gpu, engines, tmp_path):
     assert np.array_equal(dfl, dfl_u) and np.array_equal(cls, cls_u)
 
 
+@pytest.mark.parametrize("n_crops", [24, 416])
+def test_downsample_branch_folded_into_last_conv(gpu, engines, tmp_path, n_crops):
+    """ReID layer{2,3,4}.0: the 1x1 / stride-2 downsample conv is read only as the residual of the block's last conv.  The engine folds
+    it into that conv as a SECOND SOURCE (Model::Model fold, ConvArgs::x2): relu(conv3x3(t) + b + ds(x) + b') is one GEMM over
+    K = [window of t | channels of x], three launches fewer, and the branch never exists as a tensor.  Its sum no longer passes through
+    an fp16 rounding, so the embeddings are NOT bit-identical to the unfolded engine (child process, AICAM_NO_DS_FOLD=1): they must
+    agree with it within that rounding, be within the usual fp16 tolerance of the fp32 oracle, and be no further from it than the
+    unfolded engine is.  24 crops: the LDS-DMA implicit GEMMs walk the second source (set_tap / xs); 416: the ping-pong patch kernel's
+    extra step (conv3x3_pp_patch_kernel<..., X2>) -- test_reid_embeddings_do_not_depend_on_the_batch holds the two to the same bits."""
+    x = np.random.default_rng(21).standard_normal((n_crops, 3, 128, 64)).astype(np.float32)
+    (got,), n_f, (unf,), n_u = _run_with_and_without_tail(tmp_path, engines[1], x, n_crops, "reid_infer_np", {"AICAM_NO_DS_FOLD": "1"})
+    assert n_u - n_f == 3, (n_u, n_f)
+    eo = N.EngineOracle(engines[1])
+    k = min(n_crops, 32)
+    ref = eo.run(torch.from_numpy(x[:k]))[eo.outputs[0][0]][:, :, 0, 0].numpy()
+    e_f, e_u, d = np.abs(got[:k] - ref).max(), np.abs(unf[:k] - ref).max(), np.abs(got - unf).max()
+    print(f"downsample fold, {n_crops} crops: conv launches {n_u} -> {n_f}; |folded - oracle| {e_f:.2e}, |unfolded - oracle| {e_u:.2e}, |folded - unfolded| {d:.2e}")
+    assert e_f < 5e-4 and d < 5e-4
+    assert e_f <= e_u + 5e-5
+
+
 def test_fused_tail_wide_patch_and_narrow_tail(gpu, tmp_path):
     """The forms the YOLOv8 engines do not reach: the 8 x 32-tile patch kernel with a tail (map width a multiple of 32), a tail
     with FEWER output channels than its lead (24 of 64: part of the MFMA tiles is padding), SiLU on the tail and fp16 output,

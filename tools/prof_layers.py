@@ -85,6 +85,17 @@ def main(d, frames=16, crops=480, top=30, fused_stem=1, fused_yolo_stem=1, fused
                     continue
             merged.append(L)
         layers = merged
+    if fused_block and not os.environ.get("AICAM_NO_DS_FOLD"):     # a ResNet downsample 1x1 is a second source of the block's last conv (engine.cpp fold): K columns behind the window's
+        merged = []
+        for L in layers:
+            hw = L[2] // crops      # conv_x2_supported: the 512 x 128 tile (32 x 16 maps, Cout 128) and the 256 x 256 tile on 16 x 8 / 8 x 4 maps
+            if merged and L[0] == "reid" and L[1].endswith(".0.conv2") and merged[-1][1] == L[1][:-5] + "ds" and \
+                    ((L[3] == 128 and hw % 512 == 0) or (L[3] % 256 == 0 and hw % 32 == 0)):
+                p = merged.pop()
+                merged.append((L[0], L[1] + "+ds", L[2], L[3], L[4] + p[4]))
+            else:
+                merged.append(L)
+        layers = merged
     per = len(layers)
     # a launch group starts at its (fused) YOLO stem; groups of other sizes (tapered tail of a call: fewer frames, and below
     # the fused-block threshold two more launches) are dropped: keep the groups with `per` conv launches and the modal grid
