@@ -230,6 +230,49 @@ Model::Model(Device& d, const void* blob, size_t nbytes, int dtype_, int max_ite
             bufs[rbuf].p = nullptr;
         }
     }
+    // ---- fold: a 2x nearest-neighbour upsample whose output slice is read by exactly one 1x1 conv, as the FIRST channels of its input
+    // (YOLOv8's neck: up(P5) | P4 -> 12.c2f.cv1, up(12) | P3 -> 15.c2f.cv1), into that conv: it reads those channels from the
+    // half-resolution tensor at (y >> 1, x >> 1) (ConvArgs::xs).  Same values in the same K order: bit-identical
+    // (tests/test_gpu_nets.py::test_upsample_folded_into_its_reader).  AICAM_NO_UP_FOLD=1: off.
+    if (!getenv("AICAM_NO_UP_FOLD") && !getenv("AICAM_NO_FUSE")) {
+        auto overlap = [](int a0, int an, int b0, int bn) { return a0 < b0 + bn && b0 < a0 + an; };
+        for (size_t i = 0; i < ops.size(); ++i) {
+            const int* u = ops[i].v;
+            if (u[0] != OP_UPSAMPLE2X || ops[i].fuse) continue;
+            const int S = u[1], sc = u[2], c = u[3], D = u[4], dc = u[5];
+            size_t j = ops.size();
+            bool clash = false;
+            for (size_t k = 0; k < ops.size(); ++k) {
+                if (k == i || ops[k].fuse == 2) continue;
+                const int* w = ops[k].v;
+                const bool reads = w[1] == D && overlap(w[2], w[0] == OP_CONV && w[3] == 3 ? 8 : w[3], dc, c);
+                if (reads) {
+                    if (j != ops.size() || k < i) clash = true;
+                    j = k;
+                }
+                if (w[0] == OP_CONV && w[14] && w[12] == D && overlap(w[13], w[6], dc, c)) clash = true;
+                if (w[4] == D && overlap(w[5], w[6], dc, c)) clash = true;                      // another writer of the slice
+            }
+            for (auto& o : outs)
+                if (o.v[0] == D || (kind == KIND_YOLO && o.v[1] == D)) clash = true;
+            if (clash || j == ops.size()) continue;
+            int* v = ops[j].v;
+            if (v[0] != OP_CONV || ops[j].fuse || v[2] != dc || v[3] <= c || v[16] != 0 || v[15] >= (int)weights.size()) continue;
+            for (size_t k = i + 1; k <= j; ++k)                                                  // the low-resolution source is still intact at the reader
+                if (ops[k].fuse != 2 && ops[k].v[4] == S && overlap(ops[k].v[5], ops[k].v[6], sc, c)) clash = true;
+            if (clash) continue;
+            const BufDesc& xb = bufs[v[1]];
+            const BufDesc& yb = bufs[v[4]];
+            const ConvWeights& w = weights[v[15]];
+            ConvArgs q{};
+            q.H = xb.h, q.W = xb.w, q.Cin = w.cin_eff, q.Ho = yb.h, q.Wo = yb.w, q.Cout = v[6], q.KH = v[7], q.KW = v[8], q.stride = v[9], q.pad = v[10];
+            q.Kp = w.Kp, q.out_f32 = yb.f32;
+            if (2 * bufs[S].h != xb.h || 2 * bufs[S].w != xb.w || !conv_xs_supported(dtype, q, c)) continue;
+            // a conv that takes the next 1x1 into its epilogue (fuse 3, set below) is launched with a tail: keep such a reader out
+            ops[j].xs_buf = S, ops[j].xs_coff = sc, ops[j].xs_c = c;
+            ops[i].fuse = 2;                            // absorbed: run_range skips it
+        }
+    }
     // ---- merge: two convs that read the SAME tensor slice with the same window, stride, padding and activation and no residual
     // (YOLOv8's detect branches: 22.box{l}.0 and 22.cls{l}.0 both start from the level's feature map) become ONE conv whose output
     // channels are the two sets side by side in one new buffer; their readers take channel slices of it.  The map is read once
@@ -451,6 +494,10 @@ void Model::run_range(size_t op0, size_t op1, int i0, int n, hipStream_t s) {
                 a.res = nullptr, a.r_cs = 0, a.r_coff = 0, a.res_mode = u[14], a.act = u[11];
                 if (u[14]) { a.res = at(bufs[u[12]]), a.r_cs = bufs[u[12]].c, a.r_coff = u[13]; }
                 a.KH = w.kh, a.KW = w.kw, a.stride = u[9], a.pad = u[10];
+                if (ops[k].xs_buf >= 0) {               // folded 2x upsample: the first channels come from the half-resolution tensor
+                    const BufDesc& bs = bufs[ops[k].xs_buf];
+                    a.xs = at(bs), a.xs_cs = bs.c, a.xs_coff = ops[k].xs_coff, a.Hs = bs.h, a.Ws = bs.w, a.Cs = ops[k].xs_c;
+                }
                 if (u[16]) {                            // folded 1x1 second source
                     const BufDesc& b2 = bufs[u[16] - 1];
                     a.x2 = at(b2), a.x2_cs = b2.c, a.x2_coff = u[17], a.H2 = b2.h, a.W2 = b2.w, a.s2 = u[19], a.Cin2 = u[18];

@@ -12,7 +12,8 @@ struct ConvWeights { DevBuf<char> w; DevBuf<float> bias; int cout, cin, cin_eff,
 // fuse: 1 = conv fused with the max-pool that follows, 2 = skipped (absorbed).  v[16..19] (0 in engine files) are set at load time for a
 // conv that took a 1x1 conv of another tensor in as a second source (ConvArgs::x2): v[16] = that tensor's buffer + 1, v[17] = its channel
 // offset, v[18] = its channels, v[19] = the 1x1's stride
-struct OpDesc { int v[20]; int fuse = 0; };
+// xs_*: set at load time for a 1x1 conv whose first xs_c input channels were a 2x upsample's output slice (ConvArgs::xs): that op's source
+struct OpDesc { int v[20]; int fuse = 0; int xs_buf = -1, xs_coff = 0, xs_c = 0; };
 struct OutDesc { int v[8]; };
 
 struct Model {

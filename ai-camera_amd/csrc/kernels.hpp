@@ -41,6 +41,13 @@ struct ConvArgs {
     // by the LDS-DMA implicit-GEMM kernels take it; x2's K-steps come after the window's.  x2 == NULL: none.
     const void* x2;       // NHWC, element type T; output pixel (oh, ow) reads x2 pixel (oh * s2, ow * s2)
     int x2_cs, x2_coff, H2, W2, s2, Cin2;
+    // ---- optional SPLIT SOURCE of a 1x1 / stride 1 conv: its first Cs input channels are not in x but in another tensor of half the
+    // resolution, read at (ih >> 1, iw >> 1) -- a 2x nearest-neighbour upsample that was only ever the first slice of this conv's
+    // concatenated input (YOLOv8's neck: up(P5) | P4 -> C2f.cv1).  The upsample launch, its write and three quarters of this conv's read
+    // of those channels go away; same values, same K order: bit-identical.  x / x_coff address channel 0 of the concat buffer as
+    // before (channels Cs .. Cin-1 are read from it).  xs == NULL: none.
+    const void* xs;
+    int xs_cs, xs_coff, Hs, Ws, Cs;
     // ---- optional 1x1 "tail" conv run in this conv's epilogue (fp16 only; conv_tail_supported()).  This conv's own output
     // (SiLU(acc + bias) rounded to fp16, exactly what it would have stored) never leaves the registers: it is the B operand of
     // the tail's MFMAs.  y / y_cs / y_coff of THIS conv are then unused.  w_tail == NULL: no tail.
@@ -52,6 +59,8 @@ struct ConvArgs {
 // true when launch_conv_igemm can run `lead` with `tail` (a 1x1 / stride 1 / pad 0 conv reading exactly lead's output) in its epilogue:
 // fp16, lead = SiLU without residual with Cout 64 or 80 (a wave then owns every channel of its pixels), tail.Cout <= lead.Cout
 bool conv_tail_supported(int dtype, const ConvArgs& lead, const ConvArgs& tail);
+// true when launch_conv_igemm takes this 1x1 conv with the first cs channels of its input read from a half-resolution tensor (ConvArgs::xs)
+bool conv_xs_supported(int dtype, const ConvArgs& a, int cs);
 // true when launch_conv_igemm takes a conv of this shape (x2 fields ignored) with a second source (ConvArgs::x2) of cin2 channels
 bool conv_x2_supported(int dtype, const ConvArgs& a, int cin2);
 // dtype: AIC_F16 or AIC_F32 (type of x / w / res and, unless out_f32, y)

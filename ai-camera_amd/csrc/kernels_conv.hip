@@ -335,6 +335,16 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const Conv
         int tap = 0, kh = 0, kw = 0, cc = 0;
         const int kord = a.k_order;                 // != 0: K-steps in another order than memory's, source pointers rebuilt every step
         const bool cmaj = kord != 0;
+        // split source (ConvArgs::xs; 1x1 / 1 / 0, memory order only): K-steps 0 .. ssteps - 1 read the half-resolution tensor
+        const int ssteps = (a.xs && !cmaj) ? a.Cs / BKE : 0;
+        auto xs_row = [&](int i) -> const T* {
+            const int m = m0 + r0 + RP * i;
+            if (m >= M) return zero;
+            int img, rem, oh, ow;
+            fast_divmod(m, HoWo, inv_howo, img, rem);
+            fast_divmod(rem, a.Wo, inv_wo, oh, ow);
+            return reinterpret_cast<const T*>(a.xs) + (((long)img * a.Hs + (oh >> 1)) * a.Ws + (ow >> 1)) * a.xs_cs + a.xs_coff + kc * CH;
+        };
         // second source (ConvArgs::x2, chunk-major walks only): its channel chunk e is accumulated right after tap (0, 0) of the window's chunk
         // e + 1 -- the place conv3x3_pp_patch_kernel has for it; every kernel walks the same order.  xs: the step being set up is that chunk, e = cc - 1
         const int csteps2 = (a.x2 && kord == 1) ? a.Cin2 / BKE : 0;
@@ -365,6 +375,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const Conv
             }
         };
         set_tap();
+        if (ssteps) {
+#pragma unroll
+            for (int i = 0; i < A_PER; ++i) { aptr[i] = xs_row(i); ainc[i] = aptr[i] == zero ? 0 : BKE; }
+        }
         auto issue_fast = [&](int stage) {
             char* sbase = sdst + stage * STAGE;
 #pragma unroll
@@ -404,6 +418,13 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const Conv
                 ++tap;
                 if (++kw == a.KW) { kw = 0; ++kh; }
                 set_tap();
+            } else if (cc == ssteps && ssteps) {       // the split source's channels are through: on in the concat buffer, at channel Cs
+#pragma unroll
+                for (int i = 0; i < A_PER; ++i) {
+                    const bool ok = (vmask[i] & 1u) != 0;
+                    aptr[i] = ok ? rowp[i] + kc * CH + cc * BKE : zero;
+                    ainc[i] = ok ? BKE : 0;
+                }
             }
         };
 #pragma unroll
@@ -574,6 +595,17 @@ bool conv_tail_supported(int dtype, const ConvArgs& lead, const ConvArgs& tail) 
     return true;
 }
 
+// A split source is walked by the memory-order fast path of conv_igemm_dma_kernel only: a 1x1 / 1 / 0 conv without tail whose Cout
+// keeps it away from the ping-pong kernels (K of these layers is short anyway) and from the direct kernels.
+bool conv_xs_supported(int dtype, const ConvArgs& a, int cs) {
+    static const bool off = getenv("AICAM_NO_XS") != nullptr;
+    const int bke = dtype == AIC_F16 ? 32 : 16;
+    if (off || conv_impl() != 2) return false;
+    if (a.KH != 1 || a.KW != 1 || a.stride != 1 || a.pad != 0 || a.w_tail || a.x2 || a.Cin % bke || cs <= 0 || cs % bke || cs >= a.Cin) return false;
+    if (a.H % 2 || a.W % 2) return false;
+    return a.Kp < 16 * bke;                                       // (conv_try_pp takes K >= 16 steps: it has no split-source walk)
+}
+
 // A second source rides on the chunk-major walk of conv_igemm_dma_kernel / conv_igemm_pp_kernel: the layer must be one that every
 // batch size sends there in that order -- a ping-pong-patch SHAPE (k_order 1) whose Cout takes the 128-multiple branch of launch_conv_t.
 bool conv_x2_supported(int dtype, const ConvArgs& a, int cin2) {
@@ -611,6 +643,8 @@ void launch_conv_igemm(int dtype, const ConvArgs& a0, hipStream_t s) {
         a.k_order = conv_pp_patch_shape(dtype, a) ? 1 : (c64 ? 2 : 0);
     }
     if (a.x2) AIC_REQUIRE(a.k_order == 1 && a.Cout % 128 == 0 && !a.w_tail, AIC_ERR_INVALID, "conv with a second source: unsupported shape (check conv_x2_supported)");
+    if (a.xs) AIC_REQUIRE(a.k_order == 0 && a.KH == 1 && a.KW == 1 && !a.w_tail && a.Kp < 16 * (dtype == AIC_F16 ? 32 : 16), AIC_ERR_INVALID,
+                          "conv with a split source: unsupported shape (check conv_xs_supported)");
     if (a.w_tail) {
         AIC_REQUIRE(dtype == AIC_F16 && (a.Cout == 64 || a.Cout == 80) && a.act == 1 && a.res_mode == 0, AIC_ERR_INVALID,
                     "conv with a 1x1 tail: unsupported lead (check conv_tail_supported before setting w_tail)");

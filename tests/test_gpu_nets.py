@@ -464,6 +464,20 @@ def test_downsample_branch_folded_into_last_conv(gpu, engines, tmp_path, n_crops
     assert e_f <= e_u + 5e-5
 
 
+@pytest.mark.parametrize("n_img", [4, 48])
+def test_upsample_folded_into_its_reader(gpu, engines, tmp_path, n_img):
+    """YOLOv8's neck: up(P5) | P4 -> 12.c2f.cv1 and up(12) | P3 -> 15.c2f.cv1.  Each 2x upsample writes the first channels of a concat
+    buffer that exactly one 1x1 conv reads; the engine folds it into that conv, which takes those channels from the half-resolution
+    tensor at (y >> 1, x >> 1) (Model::Model fold, ConvArgs::xs, the memory-order walk of conv_igemm_dma_kernel).  Same values in the
+    same K order: the raw head must be BIT-IDENTICAL to the engine loaded with AICAM_NO_UP_FOLD=1 in a child process.  4 images: the
+    small tiles; 48: the tiles of the production batch."""
+    x = np.random.default_rng(13).standard_normal((n_img, 3, 640, 640)).astype(np.float32) * 0.5
+    (dfl, cls), n_f, (dfl_u, cls_u), n_u = _run_with_and_without_tail(tmp_path, engines[0], x, n_img, "yolo_head_np", {"AICAM_NO_UP_FOLD": "1"})
+    assert n_u == n_f                                   # conv launches: the upsample was never one
+    assert np.isfinite(dfl).all() and np.abs(dfl).max() > 0.1 and np.abs(cls).max() > 0.1
+    assert np.array_equal(dfl, dfl_u) and np.array_equal(cls, cls_u)
+
+
 def test_fused_tail_wide_patch_and_narrow_tail(gpu, tmp_path):
     """The forms the YOLOv8 engines do not reach: the 8 x 32-tile patch kernel with a tail (map width a multiple of 32), a tail
     with FEWER output channels than its lead (24 of 64: part of the MFMA tiles is padding), SiLU on the tail and fp16 output,
