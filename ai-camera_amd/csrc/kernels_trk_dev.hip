@@ -827,8 +827,35 @@ __global__ __launch_bounds__(TRK_DEV_TMAX) void trk_epoch_kernel(EpochArgs a) {
         float* c_maha = cost_lds ? L.arena + tn : a.scr.cost + (size_t)TRK_DEV_TMAX * TRK_DEV_NMAX;
         float* c_iou = cost_lds ? L.arena + 2 * tn : a.scr.cost + 2 * (size_t)TRK_DEV_TMAX * TRK_DEV_NMAX;
         const FrameCosts fc{c_app, c_maha, c_iou, cost_lds ? L.arena + 3 * tn : L.arena, cost_lds ? L.arena_floats - 3 * tn : L.arena_floats};
+        // Gate data of a track (innovation covariance, its Cholesky factor, the predicted box) are the same for all its pairs: ONE THREAD per
+        // track works them out -- all tracks at once, 24 floats each in the still unused sub-matrix area -- and the pairs then run one per
+        // thread with their appearance loads in flight.  (Before: one WAVE per track, every lane repeating the track's Cholesky: four
+        // rounds of ~800 instructions at 30 tracks, 16 k of this phase's 20 k shader cycles.)  Same functions, same operations per value.
+        const bool gate_lds = cost_lds && T > 0 && n > 0 && 24 * T <= fc.sub_floats;
+        if (gate_lds) {
+            float* gd = fc.sub_lds;
+            if (tid < T) {
+                const int slot = L.slot[tid];
+                const float* P = kP(slot);
+                const float* m = kM(slot);
+                float S[4][4], Lc[4][4];
+                innovation_cov(P, m[3], S);
+                const bool ok = cholesky<4>(S, Lc);
+                float* g = gd + tid * 24;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) g[4 * i + jj] = Lc[i][jj];
+                const float m0 = m[0], m1 = m[1], m2 = m[2], m3 = m[3];
+                float bw = 0.f, bh = m3;
+                if (bh > 0.f) bw = m2 * bh; else bh = fmaxf(0.f, bh);
+                g[16] = m0, g[17] = m1, g[18] = m2, g[19] = m3;
+                g[20] = bw, g[21] = bh, g[22] = ok ? 1.f : 0.f;
+            }
+            __syncthreads();
+        }
         if (T > 0 && n > 0) {
-            for (int e = tid; e < tn; e += BT) {                   // appearance: one (track, detection) pair per thread, all loads of a pair in flight together
+            for (int e = tid; e < tn; e += BT) {                   // one (track, detection) pair per thread, all loads of a pair in flight together
                 const int t = e / n, j = e - t * n;
                 float v = kInfty;                                  // empty gallery / featureless detection (matching.py:148,175)
                 if (L.glen[t] > 0 && L.dhas[j]) {
@@ -848,7 +875,36 @@ __global__ __launch_bounds__(TRK_DEV_TMAX) void trk_epoch_kernel(EpochArgs a) {
                     v = mn;
                 }
                 c_app[e] = v;
+                if (gate_lds) {                                    // gating distance + IoU of the pair
+                    const float* g = fc.sub_lds + t * 24;
+                    float Lc[4][4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) Lc[i][jj] = g[4 * i + jj];
+                    const float m0 = g[16], m1 = g[17], m2 = g[18], m3 = g[19], bw = g[20], bh = g[21];
+                    const bool ok = g[22] != 0.f;
+                    const float bx = m0 - bw / 2.0f, by = m1 - bh / 2.0f;
+                    const float brx = bx + bw, bry = by + bh;
+                    const float* z = L.xyah + j * 4;
+                    float d[4], y[4];
+                    d[0] = z[0] - m0, d[1] = z[1] - m1, d[2] = z[2] - m2, d[3] = z[3] - m3;
+                    fwd_solve<4>(Lc, d, y);
+                    float acc = y[0] * y[0];
+                    acc = acc + y[1] * y[1];
+                    acc = acc + y[2] * y[2];
+                    acc = acc + y[3] * y[3];
+                    c_maha[e] = ok ? acc : __builtin_inff();
+                    const float* c = L.tlwh + j * 4;
+                    const float crx = c[0] + c[2], cry = c[1] + c[3];
+                    const float iw = fmaxf(0.f, fminf(brx, crx) - fmaxf(bx, c[0]));
+                    const float ih = fmaxf(0.f, fminf(bry, cry) - fmaxf(by, c[1]));
+                    const float inter = iw * ih;
+                    const float uni = bw * bh + c[2] * c[3] - inter;
+                    c_iou[e] = 1.0f - inter / fmaxf(uni, 1e-7f);
+                }
             }
+            if (!gate_lds)
             for (int t = wv; t < T; t += NW) {                     // gating distance + IoU: one wave per track, lanes over the detections
                 const int slot = L.slot[t];
                 const float* P = kP(slot);
