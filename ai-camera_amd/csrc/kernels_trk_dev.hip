@@ -641,6 +641,7 @@ struct EpochArgs {
     EpochScratch scr;
     EpochOut out;
     int lds_bytes;
+    int commit_ext;                        // 1: the appended gallery rows are copied by gallery_commit_kernel after this launch (the list + its count stay in scr.appends)
     long long* prof;                       // AICAM_TRK_PHASES: shader-clock cycles per phase, accumulated by thread 0 (NULL: off)
 };
 
@@ -1132,21 +1133,29 @@ __global__ __launch_bounds__(TRK_DEV_TMAX) void trk_epoch_kernel(EpochArgs a) {
         floatx4* graw = reinterpret_cast<floatx4*>(a.gal_raw);
         floatx4* gn = reinterpret_cast<floatx4*>(a.gal_n);
         const int d4 = dim >> 2;
-        for (int i0 = wv * 4; i0 < na; i0 += NW * 4) {
-            for (int c = lane; c < d4; c += 64) {
-                floatx4 xr[4], xn[4];
-                size_t dst[4];
+        // The copies themselves (480 rows x 4 KB per epoch at 30 detections per frame) are ONE CU's memory bandwidth when this block makes
+        // them -- 125 us of the kernel's 657, whatever the loop's shape (four rows per wave in flight or sixteen loads per thread: the
+        // same) -- so by default a many-block kernel makes them right behind this launch (gallery_commit_kernel) and this block only leaves
+        // the list and its length.
+        if (a.commit_ext) {
+            if (tid == 0) a.scr.appends[3 * TRK_DEV_DNMAX] = na;
+        } else {
+            for (int i0 = wv * 4; i0 < na; i0 += NW * 4) {
+                for (int c = lane; c < d4; c += 64) {
+                    floatx4 xr[4], xn[4];
+                    size_t dst[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int i = min(i0 + u, na - 1);
-                    const int slot = a.scr.appends[i * 3], pos = a.scr.appends[i * 3 + 1], er = a.scr.appends[i * 3 + 2];
-                    dst[u] = ((size_t)slot * gmax + pos) * d4 + c;
-                    xr[u] = fr[(size_t)er * d4 + c];
-                    xn[u] = fn[(size_t)er * d4 + c];
-                }
+                    for (int u = 0; u < 4; ++u) {
+                        const int i = min(i0 + u, na - 1);
+                        const int slot = a.scr.appends[i * 3], pos = a.scr.appends[i * 3 + 1], er = a.scr.appends[i * 3 + 2];
+                        dst[u] = ((size_t)slot * gmax + pos) * d4 + c;
+                        xr[u] = fr[(size_t)er * d4 + c];
+                        xn[u] = fn[(size_t)er * d4 + c];
+                    }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    if (i0 + u < na) { graw[dst[u]] = xr[u]; gn[dst[u]] = xn[u]; }
+                    for (int u = 0; u < 4; ++u) {
+                        if (i0 + u < na) { graw[dst[u]] = xr[u]; gn[dst[u]] = xn[u]; }
+                    }
                 }
             }
         }
@@ -1302,6 +1311,26 @@ void launch_gallery_shard(const DevTrkHdr* hdr, const DevTrack* trk, const float
     KCHECK();
 }
 
+// ------------------------------------------------------------------------------------------------ gallery commit
+// The rows an epoch appended to the galleries (list left by trk_epoch_kernel: slot, ring position, epoch row; length behind the list),
+// raw + unit, one row per block and pass.
+__global__ __launch_bounds__(256) void gallery_commit_kernel(const int* __restrict__ appends, const float* __restrict__ feat, const float* __restrict__ feat_n,
+                                                             int d_begin, int dim, int gmax, float* __restrict__ gal_raw, float* __restrict__ gal_n) {
+    const int na = min(appends[3 * TRK_DEV_DNMAX], TRK_DEV_DNMAX), d4 = dim >> 2;
+    const floatx4* fr = reinterpret_cast<const floatx4*>(feat + (size_t)d_begin * dim);
+    const floatx4* fn = reinterpret_cast<const floatx4*>(feat_n + (size_t)d_begin * dim);
+    floatx4* graw = reinterpret_cast<floatx4*>(gal_raw);
+    floatx4* gn = reinterpret_cast<floatx4*>(gal_n);
+    for (int i = blockIdx.x; i < na; i += gridDim.x) {
+        const int slot = appends[i * 3], pos = appends[i * 3 + 1], er = appends[i * 3 + 2];
+        const size_t dst = ((size_t)slot * gmax + pos) * d4, src = (size_t)er * d4;
+        for (int c = threadIdx.x; c < 2 * d4; c += 256) {
+            if (c < d4) graw[dst + c] = fr[src + c];
+            else gn[dst + c - d4] = fn[src + c - d4];
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ launchers
 static int epoch_lds_bytes() { return 159 * 1024; }
 
@@ -1354,10 +1383,16 @@ void launch_trk_epoch(DevTrkHdr* hdr, DevTrack* trk, int* free_slots, float* mea
     a.hdr = hdr, a.trk = trk, a.free_slots = free_slots, a.mean = mean, a.cov = cov, a.gal_raw = gal_raw, a.gal_n = gal_n;
     a.prm = prm, a.dets = dets, a.f0 = f0, a.k = k, a.d_begin = d_begin, a.dn_pad = dn_pad, a.nmax = std::max(nmax, 1), a.has_sm = has_sm;
     a.scr = scr, a.out = out, a.lds_bytes = epoch_lds_bytes();
+    static const bool commit_inline = getenv("AICAM_TRK_COMMIT_INLINE") != nullptr;       // A/B: the epoch kernel copies its appended rows itself
+    a.commit_ext = (!commit_inline && dets.feat != nullptr && dets.feat_n != nullptr && scr.appends != nullptr && prm.dim % 4 == 0) ? 1 : 0;
     a.prof = g_phase.d;
     g_phase.launches += 1, g_phase.frames += k;
     hipLaunchKernelGGL(trk_epoch_kernel, dim3(1), dim3(TRK_DEV_TMAX), (size_t)epoch_lds_bytes(), s, a);
     KCHECK();
+    if (a.commit_ext) {
+        hipLaunchKernelGGL(gallery_commit_kernel, dim3(256), dim3(256), 0, s, scr.appends, dets.feat, dets.feat_n, d_begin, prm.dim, prm.gmax, gal_raw, gal_n);
+        KCHECK();
+    }
 }
 
 void launch_trk_cascade_test(const TrkDevParams& prm, const EpochScratch& scr, int T, int n, const int* state, const int* tsu,

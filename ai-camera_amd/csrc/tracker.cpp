@@ -525,7 +525,7 @@ void Tracker::run_epochs(const EpochDets& dets, const int* h_n, const int* h_d0,
     prm.no_fast = lsap_fast ? 0 : 1;
     d_costs.ensure((size_t)3 * TRK_DEV_TMAX * TRK_DEV_NMAX);
     d_sub.ensure((size_t)TRK_DEV_TMAX * TRK_DEV_NMAX);
-    d_appends.ensure((size_t)3 * TRK_DEV_DNMAX);
+    d_appends.ensure((size_t)3 * TRK_DEV_DNMAX + 4);          // + the list's length (gallery_commit_kernel)
     d_dbg.ensure(16 + 2 * TRK_DEV_TMAX);
     static const int k_env = [] { const char* e = getenv("AICAM_TRK_K"); return e ? atoi(e) : 16; }();   // frames per epoch (measured: 8 / 16 / 32)
     const int kmax = std::max(1, std::min(std::min(TRK_KMAX, epoch_frames > 0 ? epoch_frames : k_env), gmax));

@@ -69,7 +69,7 @@ struct EpochScratch {
     float* gram;                    // [dn_pad, dn_pad]
     float* cost;                    // 3 x [TRK_DEV_TMAX * TRK_DEV_NMAX] full matrices of the current frame (app, maha, iou)
     float* sub;                     // LSAP sub-matrix when it does not fit the LDS arena
-    int32_t* appends;               // [TRK_DEV_DNMAX, 3] (slot, ring position, epoch row) gallery rows written at the end of the epoch
+    int32_t* appends;               // [TRK_DEV_DNMAX, 3] (slot, ring position, epoch row) gallery rows written at the end of the epoch; [3 * TRK_DEV_DNMAX] = their number
 };
 
 }  // namespace aic
