@@ -853,10 +853,9 @@ __global__ __launch_bounds__(TRK_DEV_TMAX) void trk_epoch_kernel(EpochArgs a) {
                 g[16] = m0, g[17] = m1, g[18] = m2, g[19] = m3;
                 g[20] = bw, g[21] = bh, g[22] = ok ? 1.f : 0.f;
             }
-            __syncthreads();
         }
         if (T > 0 && n > 0) {
-            for (int e = tid; e < tn; e += BT) {                   // one (track, detection) pair per thread, all loads of a pair in flight together
+            for (int e = tid; e < tn; e += BT) {                   // appearance: one (track, detection) pair per thread, all loads of a pair in flight together
                 const int t = e / n, j = e - t * n;
                 float v = kInfty;                                  // empty gallery / featureless detection (matching.py:148,175)
                 if (L.glen[t] > 0 && L.dhas[j]) {
@@ -876,7 +875,12 @@ __global__ __launch_bounds__(TRK_DEV_TMAX) void trk_epoch_kernel(EpochArgs a) {
                     v = mn;
                 }
                 c_app[e] = v;
-                if (gate_lds) {                                    // gating distance + IoU of the pair
+            }
+            if (gate_lds) __syncthreads();                         // the gate data of every track are in LDS (their threads came here through the loop above)
+            if (gate_lds)
+            for (int e = tid; e < tn; e += BT) {                   // gating distance + IoU of the pair
+                const int t = e / n, j = e - t * n;
+                {
                     const float* g = fc.sub_lds + t * 24;
                     float Lc[4][4];
 #pragma unroll
