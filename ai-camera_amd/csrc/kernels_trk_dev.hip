@@ -660,10 +660,16 @@ struct FrameCosts { const float* app; const float* maha; const float* iou; float
 // and those minima sit in distinct places, then sum-of-line-minima is attained, and only by assignments that put each such line
 // on its minimum: SciPy's answer restricted to the accepted pairs is exactly this, its tie rules never come into play.  (The
 // solver's arithmetic is exact here: entries are fp32 values below 1 on a 2^-27 grid, sums of <= 512 of them fit a double.)
+__shared__ long long s_tsub;            // AICAM_TRK_PHASES: sub-phase stamps of the cascade (thread 0)
+#define SUBPH(prof, i) do { if ((prof) && threadIdx.x == 0) { const long long _t = clock64(); atomicAdd((unsigned long long*)&(prof)[8 + (i)], (unsigned long long)(_t - s_tsub)); s_tsub = _t; } } while (0)
 // One ordered scan per line instead of ~R augmenting paths on one wavefront; anything else falls through to the LSAP.
-__device__ bool unique_optimum(const Lds& L, const float* sub, const int* cols, int nr, int nc, float maxd) {
+// by_cols (square problems only): the COLUMNS are the lines.  Both sums of line minima bound a square problem's optimum from below, and
+// rows whose nearest entries coincide often have columns whose nearest rows do not (two tracks that look like one detection, while the
+// second detection looks like only one of them): a second chance before the one-wavefront LSAP (17 % of the bench clip's frames took it,
+// at 56 k shader cycles each).
+__device__ bool unique_optimum(const Lds& L, const float* sub, const int* cols, int nr, int nc, float maxd, bool by_cols = false) {
     const int tid = threadIdx.x;
-    const bool tall = nr > nc;
+    const bool tall = nr > nc || (by_cols && nr == nc);
     const int R = tall ? nc : nr, C = tall ? nr : nc;
     int* cnt = L.pred;                                          // scratch of the LSAP, free here
     for (int c = tid; c < C; c += BT) cnt[c] = 0;
@@ -714,8 +720,10 @@ __device__ void match_block(const Lds& L, const EpochArgs& a, const FrameCosts& 
     }
     __threadfence_block();
     __syncthreads();
-    if (!a.prm.no_fast && unique_optimum(L, sub, cols, nr, nc, maxd)) {
+    SUBPH(a.prof, 2);
+    if (!a.prm.no_fast && (unique_optimum(L, sub, cols, nr, nc, maxd) || (nr == nc && unique_optimum(L, sub, cols, nr, nc, maxd, true)))) {
         if (threadIdx.x == 0) L.wcnt[NW + 1] += 1;
+        SUBPH(a.prof, 3);
         return;
     }
     if (threadIdx.x == 0) L.wcnt[NW + 2] += 1;
@@ -948,6 +956,7 @@ __global__ __launch_bounds__(TRK_DEV_TMAX) void trk_epoch_kernel(EpochArgs a) {
         PHASE(2);
 
         // ---- matching cascade over time_since_update = 1 .. max_age (linear_assignment.py:91-157)
+        if (a.prof && tid == 0) s_tsub = clock64();
         int nund = n;
         if (T > 0 && n > 0) {
             int cur = 0;
@@ -956,13 +965,16 @@ __global__ __launch_bounds__(TRK_DEV_TMAX) void trk_epoch_kernel(EpochArgs a) {
                 const bool conf_t = tid < T && L.state[tid] == 2;
                 const int tv = (conf_t && L.tsu[tid] > cur && L.tsu[tid] <= a.prm.max_age) ? L.tsu[tid] : 0x7fffffff;
                 const int lv = block_min_int(tv, L.wcnt);
+                SUBPH(a.prof, 0);
                 if (lv == 0x7fffffff) break;
                 cur = lv;
                 const int nr = block_compact(conf_t && L.tsu[tid] == lv, tid, L.rows, L.wcnt);
+                SUBPH(a.prof, 1);
                 match_block(L, a, fc, L.und, nr, nund, n, false, &s_err);
                 if (s_err) break;
                 const int dj = tid < nund ? L.und[tid] : -1;
                 nund = block_compact(dj >= 0 && L.mtrk[dj] < 0, dj, L.und, L.wcnt);
+                SUBPH(a.prof, 4);
             }
             PHASE(3);
             // ---- IoU stage: tentative tracks, then confirmed tracks that missed exactly this frame (tracker_core.py:138-166)
@@ -1245,6 +1257,7 @@ __global__ __launch_bounds__(TRK_DEV_TMAX) void trk_epoch_kernel(EpochArgs a) {
         a.hdr->n_tracks = T, a.hdr->next_id = next_id, a.hdr->n_free = nfree;
         a.hdr->err = s_err, a.hdr->err_frame = err_frame, a.hdr->frames_done = fi;
         a.hdr->n_fast += L.wcnt[NW + 1], a.hdr->n_lsap += L.wcnt[NW + 2];
+        if (a.prof) { atomicAdd((unsigned long long*)&a.prof[13], (unsigned long long)L.wcnt[NW + 1]); atomicAdd((unsigned long long*)&a.prof[14], (unsigned long long)L.wcnt[NW + 2]); }
     }
 }
 
@@ -1437,7 +1450,9 @@ struct PhaseProf {
         static const char* nm[8] = {"load table", "dets+predict", "cost rows", "cascade", "IoU stage", "lifecycle+KF update", "outputs+prune", "epoch tail"};
         fprintf(stderr, "[trk_phases] %ld epoch launches, %ld frames; shader cycles per frame:", launches, frames);
         for (int i = 0; i < 8; ++i) fprintf(stderr, " %s %.0f |", nm[i], (double)h[i] / frames);
-        fprintf(stderr, "\n");
+        fprintf(stderr, "\n[trk_phases] inside the cascade: level search %.0f | row list %.0f | sub-matrix %.0f | unique-optimum check %.0f | unmatched list (+ the LSAP when the check fails) %.0f\n",
+                (double)h[8] / frames, (double)h[9] / frames, (double)h[10] / frames, (double)h[11] / frames, (double)h[12] / frames);
+        fprintf(stderr, "[trk_phases] assignment problems: %lld read off as the unique optimum, %lld through the LSAP\n", h[13], h[14]);
     }
 };
 PhaseProf g_phase;
