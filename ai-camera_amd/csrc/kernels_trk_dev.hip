@@ -1420,7 +1420,14 @@ void launch_trk_epoch_prep(const DevTrkHdr* hdr, const DevTrack* trk, const floa
                            int dn, int dn_pad, int k, float* sm, float* gram, hipStream_t s) {
     if (dn <= 0) return;
     const long tasks = ((long)cap + dn_pad / 16) * (dn_pad / 32);
-    const int grid = (int)std::min<long>(512, (tasks + 3) / 4);
+    // Blocks: enough for the tasks the epoch is LIKELY to have (about as many live tracks as detections per frame), nine wave-tasks
+    // each, not one block per four tasks of the worst case (every slot of the table alive).  Every block of this launch has to find
+    // a CU behind the one-block-per-CU conv kernels before the epoch kernel may start; with 512 blocks (225 of them with work at 30
+    // tracks) the tracker chain was what the pipeline waited for in every run of the bench (9 831 frames/s, six runs), with 96 in none
+    // (9 969, five runs), with 32 the launch itself gets too long (9 708).  AICAM_TRK_PREP_GRID=n: exactly n blocks.
+    static const int grid_env = [] { const char* e = getenv("AICAM_TRK_PREP_GRID"); return e ? std::max(1, atoi(e)) : 0; }();
+    const long likely = ((long)dn_pad / std::max(k, 1) + dn_pad / 16) * (dn_pad / 32);
+    const int grid = grid_env ? grid_env : (int)std::min<long>(std::min<long>(512, (tasks + 3) / 4), std::max<long>(64, likely / 9));
     hipLaunchKernelGGL(trk_epoch_prep_kernel, dim3(grid), dim3(256), 0, s, hdr, trk, gal_n, gmax, dim, featn, dn, dn_pad, k, sm, gram);
     KCHECK();
 }
@@ -1474,7 +1481,8 @@ void launch_trk_epoch(DevTrkHdr* hdr, DevTrack* trk, int* free_slots, float* mea
     hipLaunchKernelGGL(trk_epoch_kernel, dim3(1), dim3(TRK_DEV_TMAX), (size_t)epoch_lds_bytes(), s, a);
     KCHECK();
     if (a.commit_ext) {
-        hipLaunchKernelGGL(gallery_commit_kernel, dim3(256), dim3(256), 0, s, scr.appends, dets.feat, dets.feat_n, d_begin, prm.dim, prm.gmax, gal_raw, gal_n);
+        static const int cgrid = [] { const char* e = getenv("AICAM_TRK_COMMIT_GRID"); return e ? std::max(1, atoi(e)) : 256; }();
+        hipLaunchKernelGGL(gallery_commit_kernel, dim3(cgrid), dim3(256), 0, s, scr.appends, dets.feat, dets.feat_n, d_begin, prm.dim, prm.gmax, gal_raw, gal_n);
         KCHECK();
     }
 }
