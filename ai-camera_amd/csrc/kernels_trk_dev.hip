@@ -675,6 +675,34 @@ __device__ bool unique_optimum(const Lds& L, const float* sub, const int* cols, 
     for (int c = tid; c < C; c += BT) cnt[c] = 0;
     float m1 = __builtin_inff(), m2 = __builtin_inff();
     int arg = -1;
+    if (C <= 64) {
+        // a wave per line, a lane per entry: minimum by a DPP reduction on order-preserving keys of the fp32 entries (sign bit flipped,
+        // negative values complemented: smaller value <=> smaller key), strict <=> exactly one lane holds it.  The
+        // thread-per-line scan below is a dependent chain of C compare-selects on one wavefront: 3 k of a frame's 56 k shader cycles at
+        // 30 x 30, twice when the row-wise check fails.
+        const int lane = tid & 63, wv = tid >> 6;
+        int* l_m = L.todo;                                      // line minimum (bits) and its place, or -1 when it is not strict
+        int* l_a = L.pos;
+        const int step = tall ? nc : 1;
+        for (int l = wv; l < R; l += NW) {
+            const float* p = tall ? sub + l : sub + (size_t)l * nc;
+            const unsigned raw = lane < C ? __float_as_uint(p[(size_t)lane * step]) : 0x7f800000u;
+            const unsigned xb = raw ^ ((raw >> 31) ? 0xffffffffu : 0x80000000u);
+            const unsigned mk = wave_umin32(xb);
+            const unsigned long long bal = __ballot(xb == mk);
+            if (lane == 0) {
+                const unsigned mb = mk ^ ((mk >> 31) ? 0x80000000u : 0xffffffffu);
+                l_m[l] = (int)mb; l_a[l] = __popcll(bal) == 1 ? (int)__ffsll((long long)bal) - 1 : -1;
+            }
+        }
+        __syncthreads();
+        if (tid < R) {
+            m1 = __uint_as_float((unsigned)l_m[tid]);
+            arg = l_a[tid];
+            m2 = arg >= 0 ? __builtin_inff() : m1;               // only `m1 < m2` is asked below
+            if (arg < 0) arg = 0;
+        }
+    } else
     if (tid < R) {
         const float* p = tall ? sub + tid : sub + (size_t)tid * nc;
         const int step = tall ? nc : 1;
