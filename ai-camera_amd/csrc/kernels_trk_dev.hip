@@ -823,27 +823,46 @@ __global__ __launch_bounds__(TRK_DEV_TMAX) void trk_epoch_kernel(EpochArgs a) {
     __syncthreads();
     PHASE(0);
 
+    // the detections of a frame are requested one frame ahead (four global loads per detection, a round trip to L2 / HBM under the conv
+    // kernels' traffic: they used to open every frame) and wait in registers
+    int pn = a.dets.frame_n[a.f0], pd0 = a.dets.frame_d0[a.f0];
+    floatx4 pb = {0.f, 0.f, 0.f, 0.f};
+    float pconf = 0.f;
+    int pcls = 0, phas = 0;
+    auto fetch_dets = [&](int n_, int d0_) {
+        if (tid < n_ && n_ <= TRK_DEV_NMAX) {
+            pb = *reinterpret_cast<const floatx4*>(a.dets.tlwh + (size_t)(d0_ + tid) * 4);
+            pconf = a.dets.conf[d0_ + tid];
+            pcls = a.dets.cls[d0_ + tid];
+            phas = (a.dets.feat_n != nullptr && (a.dets.valid == nullptr || a.dets.valid[d0_ + tid] != 0)) ? 1 : 0;
+        }
+    };
+    fetch_dets(pn, pd0);
     int fi = 0, err_frame = -1;
     for (; fi < a.k; ++fi) {
         const int f = a.f0 + fi;
-        const int n = a.dets.frame_n[f], d0 = a.dets.frame_d0[f];
+        const int n = pn, d0 = pd0;
         const int erow0 = d0 - a.d_begin;                        // first epoch row of this frame
         if (n > a.nmax || n > TRK_DEV_NMAX || erow0 + n > a.dn_pad) { if (tid == 0) s_err = 3; }
         __syncthreads();
         if (s_err) { err_frame = f; break; }
         // ---- detections of the frame -> LDS (detection.py:36-47 for xyah); Kalman predict of every track (tracker_core.py:44-49)
         if (tid < n) {
-            const floatx4 b = *reinterpret_cast<const floatx4*>(a.dets.tlwh + (size_t)(d0 + tid) * 4);
+            const floatx4 b = pb;
             L.tlwh[tid * 4] = b[0], L.tlwh[tid * 4 + 1] = b[1], L.tlwh[tid * 4 + 2] = b[2], L.tlwh[tid * 4 + 3] = b[3];
             L.xyah[tid * 4] = b[0] + b[2] / 2.0f;
             L.xyah[tid * 4 + 1] = b[1] + b[3] / 2.0f;
             L.xyah[tid * 4 + 2] = b[3] > 0.f ? b[2] / b[3] : 0.f;
             L.xyah[tid * 4 + 3] = b[3];
-            L.dconf[tid] = a.dets.conf[d0 + tid];
-            L.dcls[tid] = a.dets.cls[d0 + tid];
-            L.dhas[tid] = (a.dets.feat_n != nullptr && (a.dets.valid == nullptr || a.dets.valid[d0 + tid] != 0)) ? 1 : 0;
+            L.dconf[tid] = pconf;
+            L.dcls[tid] = pcls;
+            L.dhas[tid] = phas;
             L.mtrk[tid] = -1;
             L.und[tid] = tid;
+        }
+        if (fi + 1 < a.k) {                                       // the next frame's detections: in flight until the next iteration
+            pn = a.dets.frame_n[f + 1], pd0 = a.dets.frame_d0[f + 1];
+            fetch_dets(pn, pd0);
         }
         if (tid == 0 && a.out.dbg_match && a.out.dbg_stride) a.out.dbg_match[(size_t)f * a.out.dbg_stride] = 0;
         if (tid < T) { L.age[tid] += 1; L.tsu[tid] += 1; L.mdet[tid] = -1; }
