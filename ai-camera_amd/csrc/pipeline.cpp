@@ -85,7 +85,11 @@ struct Pipeline {
     // (lsap_wave64 / lsap_wave_reg<2>, and the unique-optimum check in front of them), else on the host for that launch group.
     // configs[2] (100 x 100, YOLOv8m at 1080p), round 3: 2 205 frames/s on the device, 2 246 on the host -- both bound by the convs; the
     // device path leaves the host 1 us per frame of work instead of 213
-    int assoc_limit = 128;           // auto mode: largest assignment problem side the device takes (aic_pipeline_option("device_assoc_limit"))
+    // auto mode: largest assignment problem side the device takes (aic_pipeline_option("device_assoc_limit")).  192 since the end of round 3:
+    // configs[2] (100 persons: 100 detections, ~105 tracks) runs 2 280 / 2 266 frames/s on the device against 2 255 / 2 257 on the host
+    // chain, which also costs a core 214 us per frame; the 300-detection frames of the own-detections scene stay on the host (3 740
+    // against 6 350 frames/s when forced onto the device: the one-wavefront LSAP over 300 columns).
+    int assoc_limit = 192;
     int dev_assoc = getenv("AICAM_TRK_HOST") ? 0 : (getenv("AICAM_TRK_DEV") ? 2 : 1);
     std::atomic<int> tracks_seen{0};      // live tracks after the most recent launch group
     // `tracks_before`: the track count the decision may use.  It must not depend on timing -- the producer issues group k while the

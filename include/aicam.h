@@ -337,7 +337,7 @@ int aic_pipeline_stats(aic_pipeline* p, double* issue_s, double* wait_s, double*
  * lifecycle in host C++ (csrc/assoc_host.cpp, lsap.cpp), one launch + one sync per frame; 1 (default) = per launch group, on
  * the device while the assignment problems are at most 128 tracks x 128 detections (one or two columns per lane of the wave
  * LSAP; unique optima never reach it), else on the host;
- * a group with a frame of more than 512 detections always takes the host chain ("device_assoc_limit": the 128 of the auto mode).  "device_filter" (inject = 0): 1 (default) = the
+ * a group with a frame of more than 512 detections always takes the host chain ("device_assoc_limit": the 192 of the auto mode).  "device_filter" (inject = 0): 1 (default) = the
  * tracker's confidence / class filter runs on the device and ReID is sized from a device-side count, 0 = filter on the host.
  * Same results in every mode. */
 int aic_pipeline_option(aic_pipeline* p, const char* key, int value);

@@ -429,7 +429,7 @@ def test_more_than_512_detections_in_a_frame_fall_back_to_the_host_chain(gpu, en
 
 
 def test_association_mode_switches_between_launch_groups(gpu, engines):
-    """Auto mode: the association of a launch group runs on the device while its problems are within the limit (default 128 tracks x 128
+    """Auto mode: the association of a launch group runs on the device while its problems are within the limit (default 192 tracks x 192
     detections; 64 here) and in host C++ beyond.  A scene that grows from 40 to 76 persons crosses that line mid-run, so the track table
     travels HBM -> host (and the Kalman state / galleries stay where they are): ids, classes, boxes of every frame and the final
     table must still be the oracle's."""
