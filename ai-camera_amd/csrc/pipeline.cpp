@@ -933,6 +933,7 @@ int aic_pipeline_option(aic_pipeline* p, const char* key, int value) {
         AIC_REQUIRE(p && key, AIC_ERR_INVALID, "NULL argument");
         const std::string k(key);
         if (k == "taper") p->p.taper = value != 0;
+        else if (k == "split_streams") p->p.split_streams = value != 0;
         else if (k == "device_assoc") {
             AIC_REQUIRE(value >= 0 && value <= 2, AIC_ERR_INVALID, "device_assoc: 0 host, 1 auto, 2 always on the device");
             p->p.dev_assoc = value;

@@ -310,6 +310,16 @@ def main():
                 curve[str(g)] = {"fps": round(3 * n_fr / dtg, 1), "latency_ms_p50": pct(gl[full], gf[full], 0.5), "latency_ms_p99": pct(gl[full], gf[full], 0.99)}
             pipe.option("group_frames", 0)
             side["by_launch_group_frames"] = curve
+            # crop + ReID on a stream of their own beside the next group's detector (aic_pipeline_option "split_streams"): more frames/s, but
+            # the two streams' kernels stretch each other -- per-launch durations, and with them the roofline object, stop describing the
+            # kernels -- so it is not the default and not `value`
+            pipe.option("split_streams", 1)
+            pipe.run_raw_from_host_passes(host_frames, 1)
+            t4 = time.perf_counter()
+            pipe.run_raw_from_host_passes(host_frames, args.steps)         # as many passes as the timed region: the same share of pipeline fill
+            L.call("aic_device_sync", dev)
+            side["split_streams_fps"] = round(args.steps * frames_per_step / (time.perf_counter() - t4), 1)
+            pipe.option("split_streams", 0)
         except Exception as e:
             side["error"] = str(e)
 
@@ -412,6 +422,7 @@ def main():
                        "frame_latency_ms(handed to the pipeline -> tuples on host, full launch groups of the timed run)":
                            {"p50": pct(g_lat[full], g_frames[full], 0.5), "p99": pct(g_lat[full], g_frames[full], 0.99)},
                        "by_launch_group_frames(from host, 3 passes each)": side.get("by_launch_group_frames"),
+                       "split_streams_fps (crop + ReID beside the next group's detector, aic_pipeline_option split_streams; from host, as many passes as the timed region, not `value`: per-launch durations stretch)": side.get("split_streams_fps"),
                        "association": association,
                        "gallery_exchange_every_frames": args.gallery_exchange, "gallery_exchanges_done": exchanges,
                        "host_affinity": affinity, "host_clip_page_locked": pinned,

@@ -335,10 +335,12 @@ int aic_pipeline_stats(aic_pipeline* p, double* issue_s, double* wait_s, double*
  * (<= batch; 0 = batch).  "device_assoc": 2 = association on the device, k frames per launch (cascade, LSAP and
  * lifecycle in csrc/kernels_trk_dev.hip, no host round trip per frame); 0 = cost matrices on the device, cascade / LSAP /
  * lifecycle in host C++ (csrc/assoc_host.cpp, lsap.cpp), one launch + one sync per frame; 1 (default) = per launch group, on
- * the device while the assignment problems are at most 128 tracks x 128 detections (one or two columns per lane of the wave
+ * the device while the assignment problems are at most 192 tracks x 192 detections (a few columns per lane of the wave
  * LSAP; unique optima never reach it), else on the host;
  * a group with a frame of more than 512 detections always takes the host chain ("device_assoc_limit": the 192 of the auto mode).  "device_filter" (inject = 0): 1 (default) = the
  * tracker's confidence / class filter runs on the device and ReID is sized from a device-side count, 0 = filter on the host.
+ * "split_streams": 1 = crop + ReID of a launch group on a stream of their own beside the next group's detector (more frames/s; the
+ * kernels of the two streams stretch each other, so per-launch durations no longer describe the kernels), 0 (default) = one stream.
  * Same results in every mode. */
 int aic_pipeline_option(aic_pipeline* p, const char* key, int value);
 /* Launch groups whose crop count outgrew the buffers sized from max_persons (handled, not dropped), and frames
