@@ -843,9 +843,11 @@ __global__ __launch_bounds__(TRK_DEV_TMAX) void trk_epoch_kernel(EpochArgs a) {
         const int f = a.f0 + fi;
         const int n = pn, d0 = pd0;
         const int erow0 = d0 - a.d_begin;                        // first epoch row of this frame
-        if (n > a.nmax || n > TRK_DEV_NMAX || erow0 + n > a.dn_pad) { if (tid == 0) s_err = 3; }
-        __syncthreads();
-        if (s_err) { err_frame = f; break; }
+        if (n > a.nmax || n > TRK_DEV_NMAX || erow0 + n > a.dn_pad) {     // (block-uniform: every thread read the same counts -- no barrier needed,
+            if (tid == 0) s_err = 3;                                      //  and the one that stood here waited for the previous frame's output stores)
+            err_frame = f;
+            break;
+        }
         // ---- detections of the frame -> LDS (detection.py:36-47 for xyah); Kalman predict of every track (tracker_core.py:44-49)
         if (tid < n) {
             const floatx4 b = pb;
