@@ -2,7 +2,8 @@
 """bench.py -- end-to-end frames/sec of the detect+track hot path on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...; launched WITHOUT torchrun,
+     `python bench.py --gpus N` starts exactly that line itself as a child process and forwards its output and exit code)
 
 Workload (BASELINE.json configs[1] / SURVEY.md §8d): one synthetic 1280x720 stream per GPU, 30
 planted persons per frame, YOLOv8n + ReID in fp16 (the reference engines' precision,
@@ -156,14 +157,37 @@ def pct(lat_s, frames, q):
     return round(1e3 * float(np.asarray(lat_s)[order][min(k, len(order) - 1)]), 3)
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` with N > 1 and no torchrun around it: start `python -m torch.distributed.run --nproc-per-node N bench.py
+    <same arguments>` as a CHILD process, forward its output (rank 0's one JSON line) and return its exit code.  This process has made
+    no GPU call (no HIP library loaded, torch not even imported), and it does not exec: it waits for the child."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: what RCCL needs on this pool
+    env.setdefault("OMP_NUM_THREADS", "1")
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in child.stdout:                                # torchrun prefixes nothing on stdout by default: the ranks' lines pass through
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return child.wait()
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args.gpus))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus} "
+                         f"(or without it: bench.py starts the ranks itself)")
     D = importlib.import_module("ai-camera_amd.distributed")
     # Before any GPU call: pin this rank's host threads (producer, tracker/consumer, copy engine submissions) to the cores of
     # the NUMA node its GPU hangs off, so 8 ranks do not share cores and page-locked buffers are allocated node-locally.

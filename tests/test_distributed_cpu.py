@@ -133,6 +133,30 @@ def test_bench_launch_path_gloo_world2():
     assert pr[0]["first_core"] != pr[1]["first_core"]
 
 
+def test_bench_launches_its_own_ranks_gloo_world2():
+    """`python bench.py --gpus 2 --backend gloo --dry-run` WITHOUT torchrun around it: bench.py starts the driver's launch line itself
+    as a child process (no exec, no GPU call in the parent), forwards rank 0's one JSON line and the child's return code.  Same line
+    as `test_bench_launch_path_gloo_world2`."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--backend", "gloo", "--dry-run",
+           "--gallery-exchange", "8"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(env, OMP_NUM_THREADS="1"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["dry_run"] is True
+    assert abs(out["value"] - 2048 * 3 * 2 / 0.26) < 1.0
+    assert out["config"]["gallery_shards_seen"] == 2
+    pr = out["config"]["per_rank"]
+    assert [p["rank"] for p in pr] == [0, 1] and pr[0]["first_core"] != pr[1]["first_core"]
+    # a failing rank's code comes back through the parent
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "no_such_backend", "--dry-run"],
+                         capture_output=True, text=True, timeout=300, env=dict(env, OMP_NUM_THREADS="1"))
+    assert bad.returncode != 0
+
+
 def test_rank_core_binding_is_disjoint():
     import importlib
     D = importlib.import_module("ai-camera_amd.distributed")
