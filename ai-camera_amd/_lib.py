@@ -61,11 +61,13 @@ _SIGS = {
     "aic_yolo_decode": (_I, [_P, _P, _I, _I, _P, _P, _P]),
     "aic_reid_infer": (_I, [_P, _P, _I, _I, _P, _I]),
     "aic_letterbox": (_I, [_I, _P, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "aic_letterbox_image": (_I, [_I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "aic_crop_resize": (_I, [_I, _P, _I, _I, _P, _I, _I, _I, _P, _P]),
     "aic_detect": (_I, [_P, _P, _I, _I, _I, _I, _F, _F, _I, _P, _P, _P, _P]),
     "aic_reid_embed": (_I, [_P, _P, _I, _I, _I, _P, _I, _P, _P]),
     "aic_kf_initiate": (_I, [_I, _P, _I, _P, _P]),
     "aic_kf_predict": (_I, [_I, _P, _P, _I]),
+    "aic_kf_predict_dt": (_I, [_I, _P, _P, _I, _F]),
     "aic_kf_project": (_I, [_I, _P, _P, _I, _P, _P]),
     "aic_kf_update": (_I, [_I, _P, _P, _P, _I]),
     "aic_kf_gating": (_I, [_I, _P, _P, _I, _P, _I, _I, _I, _P]),

@@ -12,8 +12,7 @@ CHI2INV95 = {1: 3.841458820694124, 2: 5.991464547107979, 3: 7.814727903251179, 4
 
 class KalmanFilter:
     def __init__(self, dt: float = 1.0, device: int = 0):
-        if dt != 1.0:
-            raise NotImplementedError("the batched kernels implement dt = 1 (the only value the reference uses)")
+        self.dt = float(np.float32(dt))            # kalman_filter.py:41-44: the motion matrix is fp32
         self.device = device
         self._std_weight_position = 1. / 20
         self._std_weight_velocity = 1. / 160
@@ -27,7 +26,7 @@ class KalmanFilter:
 
     def predict(self, mean, covariance):
         m, c = L.as_f32(mean).reshape(-1, 8).copy(), L.as_f32(covariance).reshape(-1, 8, 8).copy()
-        L.call("aic_kf_predict", self.device, L.ptr(m), L.ptr(c), len(m))
+        L.call("aic_kf_predict_dt", self.device, L.ptr(m), L.ptr(c), len(m), self.dt)
         return (m[0], c[0]) if np.ndim(mean) == 1 else (m, c)
 
     def project(self, mean, covariance):

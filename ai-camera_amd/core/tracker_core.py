@@ -101,7 +101,9 @@ class TrackerCore:
     def update_batch(self, frames, cap_rows=512):
         """k frames in one call, each a predict() + update() (tracker_core.py:44-81), as epochs of the device association
         (aic_tracker_update_batch).  frames: list of (tlwh [N,4], conf [N], class ids [N], feats [N,D] or None, has_feat [N] or None).
-        Returns per frame (rows int32 [K,6], conf [K], matches [(track id, detection index)])."""
+        Returns per frame (rows int32 [K,6], conf [K], matches [(track id, detection index)]).  cap_rows bounds what the call stores per
+        frame; a frame with more output rows or more matches than that raises (the C ABI reports the true counts, nothing is clipped
+        silently here)."""
         k = len(frames)
         counts = np.array([len(f[0]) for f in frames], np.int32)
         tot = int(counts.sum())
@@ -128,6 +130,9 @@ class TrackerCore:
                L.ptr(has), dim, cap_rows, L.ptr(n_out), L.ptr(rows), L.ptr(oc), L.ptr(n_m), L.ptr(m_t), L.ptr(m_d))
         if dim:
             self._dim = dim
+        if k and (int(n_out.max()) > cap_rows or int(n_m.max()) > cap_rows):
+            raise ValueError(f"update_batch: a frame produced {int(n_out.max())} output rows / {int(n_m.max())} matches, cap_rows = {cap_rows} "
+                             f"(the tracker state has advanced; call again with a larger cap_rows only for later frames)")
         return [(rows[f, :min(n_out[f], cap_rows)], oc[f, :min(n_out[f], cap_rows)],
                  list(zip(m_t[f, :n_m[f]].tolist(), m_d[f, :n_m[f]].tolist()))) for f in range(k)]
 

@@ -268,7 +268,8 @@ Model::Model(Device& d, const void* blob, size_t nbytes, int dtype_, int max_ite
             q.H = xb.h, q.W = xb.w, q.Cin = w.cin_eff, q.Ho = yb.h, q.Wo = yb.w, q.Cout = v[6], q.KH = v[7], q.KW = v[8], q.stride = v[9], q.pad = v[10];
             q.Kp = w.Kp, q.out_f32 = yb.f32;
             if (2 * bufs[S].h != xb.h || 2 * bufs[S].w != xb.w || !conv_xs_supported(dtype, q, c)) continue;
-            // a conv that takes the next 1x1 into its epilogue (fuse 3, set below) is launched with a tail: keep such a reader out
+            // (a conv that takes the next 1x1 into its epilogue -- fuse 3, marked below -- is launched with a tail; the marking skips
+            // every conv with a split source, and conv_tail_supported() refuses one as well)
             ops[j].xs_buf = S, ops[j].xs_coff = sc, ops[j].xs_c = c;
             ops[i].fuse = 2;                            // absorbed: run_range skips it
         }
@@ -359,6 +360,9 @@ Model::Model(Device& d, const void* blob, size_t nbytes, int dtype_, int max_ite
             const int* c = ops[i].v;
             const int* p = ops[i + 1].v;
             if (c[0] != OP_CONV || p[0] != OP_CONV || ops[i].fuse || ops[i + 1].fuse) continue;
+            // a lead with a split source (folded upsample) or a second source (folded downsample) has no tail form: the tail kernels would
+            // ignore that source and read channels nobody wrote
+            if (ops[i].xs_buf >= 0 || c[16] != 0) continue;
             const bool lead_ok = (c[6] == 64 || c[6] == 80) && c[11] == 1 && c[14] == 0 && !bufs[c[4]].f32;
             const bool tail_ok = p[7] == 1 && p[8] == 1 && p[9] == 1 && p[10] == 0 && p[14] == 0 && p[1] == c[4] && p[2] == c[5] &&
                                  p[3] == c[6] && p[6] <= c[6];
@@ -801,6 +805,26 @@ int aic_letterbox(int device_id, const uint8_t* frame, int h, int w, int out_h, 
         if (ratio) *ratio = g.ratio;
         if (pad_w) *pad_w = g.pad_w;
         if (pad_h) *pad_h = g.pad_h;
+    });
+}
+
+int aic_letterbox_image(int device_id, const uint8_t* frame, int h, int w, int unpad_h, int unpad_w, int top, int bottom, int left, int right,
+                        int color_b, int color_g, int color_r, uint8_t* out) {
+    return guarded([&] {
+        AIC_REQUIRE(frame && out && h > 0 && w > 0 && unpad_h > 0 && unpad_w > 0, AIC_ERR_INVALID, "bad argument");
+        AIC_REQUIRE(top >= 0 && bottom >= 0 && left >= 0 && right >= 0, AIC_ERR_INVALID, "negative border");   // cv2.copyMakeBorder refuses them too
+        Device& d = device(device_id);
+        hipStream_t s = d.s_main;
+        LetterboxGeom g{};
+        g.src_h = h, g.src_w = w, g.unpad_h = unpad_h, g.unpad_w = unpad_w, g.top = top, g.left = left;
+        g.out_h = unpad_h + top + bottom, g.out_w = unpad_w + left + right;
+        auto u8 = [](int v) { return v < 0 ? 0 : v > 255 ? 255 : v; };
+        const int color[3] = {u8(color_b), u8(color_g), u8(color_r)};
+        DevBuf<uint8_t> df((size_t)h * w * 3), dout((size_t)g.out_h * g.out_w * 3);
+        HIP_CHECK(hipMemcpyAsync(df.p, frame, df.n, hipMemcpyHostToDevice, s));
+        launch_letterbox_u8(df.p, g, color, dout.p, s);
+        HIP_CHECK(hipMemcpyAsync(out, dout.p, dout.n, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
     });
 }
 

@@ -111,6 +111,7 @@ LetterboxGeom letterbox_geometry(int h, int w, int out_h, int out_w);
 // frames u8 [n,h,w,3] BGR (device). mode 0: fp32 NCHW RGB/255 ; mode 1: NHWC8 activation dtype
 void launch_letterbox(const uint8_t* frames, int n, const LetterboxGeom& g, int mode, int dtype, void* out,
                       hipStream_t s);
+void launch_letterbox_u8(const uint8_t* frame, const LetterboxGeom& g, const int color_bgr[3], uint8_t* out, hipStream_t s);
 // boxes [n,4] xyxy (device), frame_of[n] (device, may be NULL = frame 0), frames u8 [*,h,w,3].
 // n_dev (device int, may be NULL) caps the number of live crops. valid[n] written.
 // slack: the caller owns >= 16 readable bytes behind the last frame (12-byte tap loads instead of byte loads; same bytes used)
@@ -159,7 +160,7 @@ void launch_select_sort_nms(const DetArgs& a, hipStream_t s);
 // ------------------------------------------------------------------ tracker (kernels_trk.hip)
 void launch_kf_initiate(const float* z, int n, float* mean, float* cov, const int* slots, hipStream_t s);
 void launch_kf_initiate_idx(const float* z, const int* zidx, int n, float* mean, float* cov, const int* slots, hipStream_t s);
-void launch_kf_predict(float* mean, float* cov, const int* slots, int n, hipStream_t s);
+void launch_kf_predict(float* mean, float* cov, const int* slots, int n, hipStream_t s, float dt = 1.f);
 void launch_kf_project(const float* mean, const float* cov, int n, float* pmean, float* pcov, hipStream_t s);
 void launch_kf_update(float* mean, float* cov, const int* slots, const float* z, const int* zidx, int n,
                       float* out_tlwh, hipStream_t s);

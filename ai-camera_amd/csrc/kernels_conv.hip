@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     const int r0 = t >> 2;       // first tile row this thread stages
     const int m0 = blockIdx.x * BM;
     const int n0 = blockIdx.y * BN;
-    const int M = a.n_dev ? min(a.M, a.n_dev[0] * (a.Ho * a.Wo)) : a.M;
+    const int M = a.n_dev ? min(a.M, min(a.n_dev[0], a.M / (a.Ho * a.Wo)) * (a.Ho * a.Wo)) : a.M;
     if (m0 >= M) return;
 
     const T* __restrict__ xg = reinterpret_cast<const T*>(a.x);
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const Conv
     const int lane = t & 63, wv = t >> 6;
     const int slot = t & 3, r0 = t >> 2;
     const int kc = slot ^ lds_swz(r0);         // K-chunk this thread fetches (source-side swizzle)
-    const int M = a.n_dev ? min(a.M, a.n_dev[0] * (a.Ho * a.Wo)) : a.M;     // device-side item count: the grid was sized for a bound
+    const int M = a.n_dev ? min(a.M, min(a.n_dev[0], a.M / (a.Ho * a.Wo)) * (a.Ho * a.Wo)) : a.M;     // device-side item count: the grid was sized for a bound
     int tbx, tby;
     if (!xcd_tile_xy_live(a.xcd_map, (M + BM - 1) / BM, tbx, tby)) return;
     const int m0 = tbx * BM;
@@ -588,6 +588,7 @@ bool conv_tail_supported(int dtype, const ConvArgs& lead, const ConvArgs& tail) 
     static const bool off = getenv("AICAM_NO_TAIL") != nullptr;
     if (off || dtype != AIC_F16 || conv_impl() != 2) return false;
     if ((lead.Cout != 64 && lead.Cout != 80) || lead.act != 1 || lead.res_mode != 0 || lead.out_f32) return false;
+    if (lead.xs || lead.x2) return false;                          // split / second sources are walked by the plain kernels only
     if (tail.KH != 1 || tail.KW != 1 || tail.stride != 1 || tail.pad != 0 || tail.res_mode != 0) return false;
     if (tail.x != lead.y || tail.x_cs != lead.y_cs || tail.x_coff != lead.y_coff || tail.M != lead.M || tail.Cin != lead.Cout) return false;
     if (tail.Cout > lead.Cout || tail.Kp != 32 * ((lead.Cout + 31) / 32) || tail.cout_pad < lead.Cout) return false;

@@ -151,7 +151,7 @@ static bool try_c16(const ConvArgs& a, hipStream_t s) {
 // L2-resident input and no stores 1275 -- the remaining gap is the 2 GB of output writes, which do not overlap.
 template <int ACT, int RES>
 __global__ __launch_bounds__(512) void conv3x3_c64_resident_kernel(const ConvArgs a, int n_tiles_bound, int tiles_x, int tiles_y, int nblk) {
-    const int n_tiles = a.n_dev ? min(n_tiles_bound, a.n_dev[0] * tiles_x * tiles_y) : n_tiles_bound;   // device-side item count
+    const int n_tiles = a.n_dev ? min(n_tiles_bound, min(a.n_dev[0], n_tiles_bound / (tiles_x * tiles_y)) * tiles_x * tiles_y) : n_tiles_bound;   // device-side item count
     // nblk = gridDim.x as an argument: read through the dispatch packet it is a scalar load inside the tile loop, and a
     // scalar load in flight makes every compiler-made LDS wait an lgkmcnt(0)
     constexpr int TH = 8, TW = 32, PW = TW + 2, PH = TH + 2, NPIX = PW * PH, NPASS = (NPIX + 63) / 64, NPIXP = NPASS * 64;
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(const ConvA
 
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     int bx, tby;
-    if (!xcd_tile_xy_live(a.xcd_map, a.n_dev ? min((int)gridDim.x, a.n_dev[0] * tiles_x * tiles_y) : (int)gridDim.x, bx, tby)) return;   // device-side item count: the grid was sized for a bound
+    if (!xcd_tile_xy_live(a.xcd_map, a.n_dev ? min((int)gridDim.x, min(a.n_dev[0], (int)gridDim.x / (tiles_x * tiles_y)) * tiles_x * tiles_y) : (int)gridDim.x, bx, tby)) return;   // device-side item count: the grid was sized for a bound
     const int tx = bx % tiles_x; bx /= tiles_x;
     const int ty = bx % tiles_y;
     const int img = bx / tiles_y;

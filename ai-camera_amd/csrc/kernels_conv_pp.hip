@@ -45,7 +45,7 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(const ConvArgs a) {
     const int lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
     const int slot = t & 3, r0 = t >> 2;
     const int kc = slot ^ lds_swz(r0);
-    const int M = a.n_dev ? min(a.M, a.n_dev[0] * (a.Ho * a.Wo)) : a.M;     // device-side item count: the grid was sized for a bound
+    const int M = a.n_dev ? min(a.M, min(a.n_dev[0], a.M / (a.Ho * a.Wo)) * (a.Ho * a.Wo)) : a.M;     // device-side item count: the grid was sized for a bound
     int tbx, tby;
     if (!xcd_tile_xy_live(a.xcd_map, (M + BM - 1) / BM, tbx, tby)) return;
     const int m0 = tbx * BM;

@@ -108,6 +108,22 @@ __global__ void letterbox_kernel(const uint8_t* __restrict__ frames, int n, Lett
     }
 }
 
+// letterbox() as an IMAGE (image_processing.py:7-70, every mode: the caller supplies the geometry the mode produces): the resized frame
+// (g.unpad_h x g.unpad_w at (g.top, g.left)) inside a g.out_h x g.out_w canvas of `color`, u8 BGR HWC.
+__global__ void letterbox_u8_kernel(const uint8_t* __restrict__ frame, LetterboxGeom g, int cb, int cg, int cr, uint8_t* __restrict__ out) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)g.out_h * g.out_w) return;
+    const int oy = (int)(idx / g.out_w), ox = (int)(idx - (long)oy * g.out_w);
+    const int y = oy - g.top, x = ox - g.left;
+    int px[3] = {cb, cg, cr};
+    if (y >= 0 && y < g.unpad_h && x >= 0 && x < g.unpad_w) {
+        const double sx = 1.0 / ((double)g.unpad_w / (double)g.src_w);
+        const double sy = 1.0 / ((double)g.unpad_h / (double)g.src_h);
+        sample_px(frame, g.src_w * 3, 0, 0, g.src_w, g.src_h, x, y, g.unpad_w, g.unpad_h, is_area2(g.src_w, g.src_h, g.unpad_w, g.unpad_h), sx, sy, px);
+    }
+    out[idx * 3 + 0] = (uint8_t)px[0]; out[idx * 3 + 1] = (uint8_t)px[1]; out[idx * 3 + 2] = (uint8_t)px[2];
+}
+
 // ------------------------------------------------------------------------------------------------
 // Fused letterbox + YOLOv8 stem (conv 3x3 / stride 2, 3 -> 16, SiLU), fp16.  Unfused, the letterbox writes a
 // 6.5 MB NHWC8 canvas per frame that the stem reads straight back (the two are 6 % of the per-frame GPU time, both
@@ -313,6 +329,13 @@ void launch_letterbox(const uint8_t* frames, int n, const LetterboxGeom& g, int 
     if (tot <= 0) return;
     if (dtype == AIC_F16) hipLaunchKernelGGL(letterbox_kernel<half_t>, dim3(ceil_div(tot, 256)), dim3(256), 0, s, frames, n, g, mode, out);
     else hipLaunchKernelGGL(letterbox_kernel<float>, dim3(ceil_div(tot, 256)), dim3(256), 0, s, frames, n, g, mode, out);
+    KCHECK();
+}
+
+void launch_letterbox_u8(const uint8_t* frame, const LetterboxGeom& g, const int color_bgr[3], uint8_t* out, hipStream_t s) {
+    const long tot = (long)g.out_h * g.out_w;
+    if (tot <= 0) return;
+    hipLaunchKernelGGL(letterbox_u8_kernel, dim3(ceil_div(tot, 256)), dim3(256), 0, s, frame, g, color_bgr[0], color_bgr[1], color_bgr[2], out);
     KCHECK();
 }
 

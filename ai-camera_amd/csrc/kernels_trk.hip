@@ -38,7 +38,8 @@ __global__ void kf_initiate_kernel(const float* __restrict__ z, int n, float* me
     if (j == 0) mean[(size_t)slot * 8 + i] = i < 4 ? zz[i] : 0.f;
 }
 
-__global__ void kf_predict_kernel(float* mean, float* cov, const int* slots, int n) {
+// dt: KalmanFilter(dt) (kalman_filter.py:34-44), fp32 like the reference's motion matrix; x * 1.0f == x, so dt = 1 keeps its bits
+__global__ void kf_predict_kernel(float* mean, float* cov, const int* slots, int n, float dt) {
     const int k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (k >= n) return;
     const int lane = threadIdx.x & 63, i = lane >> 3, j = lane & 7;
@@ -48,16 +49,16 @@ __global__ void kf_predict_kernel(float* mean, float* cov, const int* slots, int
     const float h = m[3];
     // T1 = P F^T ; T2 = F T1   (np.linalg.multi_dot picks F (P F^T) for equal cost)
     float t1 = P[i * 8 + j];
-    if (j < 4) t1 = t1 + P[i * 8 + j + 4];
+    if (j < 4) t1 = t1 + P[i * 8 + j + 4] * dt;
     float t2 = t1;
     if (i < 4) {
         float u = P[(i + 4) * 8 + j];
-        if (j < 4) u = u + P[(i + 4) * 8 + j + 4];
-        t2 = t1 + u;
+        if (j < 4) u = u + P[(i + 4) * 8 + j + 4] * dt;
+        t2 = t1 + u * dt;
     }
     if (i == j) t2 = t2 + q_diag(i, h);
     float mi = 0.f;
-    if (j == 0) { mi = m[i]; if (i < 4) mi = mi + m[i + 4]; }
+    if (j == 0) { mi = m[i]; if (i < 4) mi = mi + m[i + 4] * dt; }
     P[i * 8 + j] = t2;          // same wavefront: every load above has retired before these stores
     if (j == 0) m[i] = mi;
 }
@@ -748,9 +749,9 @@ void launch_kf_initiate_idx(const float* z, const int* zidx, int n, float* mean,
     hipLaunchKernelGGL(kf_initiate_kernel, dim3(ceil_div(n, 4)), dim3(256), 0, s, z, n, mean, cov, slots, zidx);
     KCHECK();
 }
-void launch_kf_predict(float* mean, float* cov, const int* slots, int n, hipStream_t s) {
+void launch_kf_predict(float* mean, float* cov, const int* slots, int n, hipStream_t s, float dt) {
     if (n <= 0) return;
-    hipLaunchKernelGGL(kf_predict_kernel, dim3(ceil_div(n, 4)), dim3(256), 0, s, mean, cov, slots, n);
+    hipLaunchKernelGGL(kf_predict_kernel, dim3(ceil_div(n, 4)), dim3(256), 0, s, mean, cov, slots, n, dt);
     KCHECK();
 }
 void launch_kf_project(const float* mean, const float* cov, int n, float* pmean, float* pcov, hipStream_t s) {

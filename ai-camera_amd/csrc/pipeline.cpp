@@ -36,6 +36,7 @@ struct FrameDets {
 struct Chunk {
     int frames = 0, first_slot = 0, n_crops = 0;
     bool dev_mode = false;           // this group's association runs on the device (decided when the group is issued)
+    bool prev_dev_mode = true;       // ... and the association of the group this context held before (the device filter is chosen from it)
     int tracks_after = 0;            // live tracks when this context's last group was released (or at the start of the call)
     PinBuf<float> h_boxes;
     PinBuf<int> h_frame_of, h_valid;
@@ -81,8 +82,8 @@ struct Pipeline {
     double t_issue = 0, t_wait = 0, t_track = 0;
     long n_frames_done = 0;
     // association on the device, k frames per launch (aic_pipeline_option("device_assoc")): 0 = host C++ cascade / LSAP, one launch +
-    // sync per frame; 2 = always on the device; 1 (default) = on the device while a frame's assignment problems are at most 128 x 128
-    // (lsap_wave64 / lsap_wave_reg<2>, and the unique-optimum check in front of them), else on the host for that launch group.
+    // sync per frame; 2 = always on the device; 1 (default) = on the device while a frame's assignment problems are at most assoc_limit x assoc_limit
+    // (lsap_wave64 / lsap_wave_reg<2>, and the unique-optimum check in front of them; 192 x 192 since the end of round 3, see assoc_limit), else on the host for that launch group.
     // configs[2] (100 x 100, YOLOv8m at 1080p), round 3: 2 205 frames/s on the device, 2 246 on the host -- both bound by the convs; the
     // device path leaves the host 1 us per frame of work instead of 213
     // auto mode: largest assignment problem side the device takes (aic_pipeline_option("device_assoc_limit")).  192 since the end of round 3:
@@ -121,7 +122,8 @@ struct Pipeline {
     bool taper = getenv("AICAM_NO_TAPER") == nullptr;   // aic_pipeline_option("taper")
     // inject = 0: the tracker's confidence / class filter (deepsort_tracker.py:88-101) runs on the device behind NMS and ReID is
     // launched for a bound with the count read on the device -- no host synchronisation between YOLO and ReID.  0 = the filter on
-    // the host (one hipEventSynchronize per launch group on the producer thread).  aic_pipeline_option("device_filter").
+    // the host (one hipEventSynchronize per launch group on the producer thread); 1 = per launch group (see stage_a); 2 = always on the
+    // device.  aic_pipeline_option("device_filter").
     // Needs the fp16 engine's fused crop + stem (the crop list is read where it was written, in HBM); other engines use the host filter.
     int dev_filter = getenv("AICAM_HOST_FILTER") ? 0 : 1;
     std::mutex reid_mu;              // the ReID engine's host-side launch state: producer (stage A) and consumer (overflow rounds)
@@ -270,7 +272,12 @@ struct Pipeline {
         HIP_CHECK(hipMemcpyAsync(c.h_scores.p, yolo->d_out_scores.p, (size_t)frames * prm.max_det * 4, hipMemcpyDeviceToHost, sd));
         HIP_CHECK(hipMemcpyAsync(c.h_labels.p, yolo->d_out_labels.p, (size_t)frames * prm.max_det * 4, hipMemcpyDeviceToHost, sd));
         c.filt_dev = false;
-        if (!prm.inject && dev_filter && !split_streams && reid->dtype == AIC_F16 && getenv("AICAM_NO_FUSE_CROP") == nullptr) {
+        // dev_filter 1 (default): per launch group -- on the device while this context's previous group was associated on the device.  A
+        // group associated on the host needs the detection lists and the crop validity on the host anyway (prepare_b rebuilds them on the
+        // consumer thread, that mode's critical thread), so the stream-ordered filter only saves a round trip where the association stays
+        // on the device too.  The choice reads state the consumer wrote before it released this context: the same frames always take the
+        // same path.  dev_filter 2: always on the device.
+        if (!prm.inject && dev_filter && (dev_filter == 2 || c.prev_dev_mode) && !split_streams && reid->dtype == AIC_F16 && getenv("AICAM_NO_FUSE_CROP") == nullptr) {
             reid->in_pix4 = reid->input_pix4_ok();
             c.filt_dev = reid->in_pix4;
         }
@@ -420,6 +427,9 @@ struct Pipeline {
             Prof pr(*dev, PROF_TRK, s, 0, (double)bound * dim * 8);
             launch_normalize_rows(c.d_emb.p, c.d_emb_n.p, bound, dim, s, c.d_total.p);
         }
+        // crop validity of the round's rows for a group that ends up on the host chain: queued behind the round (61 KB at 15 360 rows), so
+        // that prepare_b has no blocking copy of its own
+        HIP_CHECK(hipMemcpyAsync(c.h_valid.p, c.d_valid.p, (size_t)bound * 4, hipMemcpyDeviceToHost, s));
         if (pipe_times) HIP_CHECK(hipEventRecord(c.t_end, s));
         HIP_CHECK(hipEventRecord(c.done, s));
         n_filter_dev_groups += 1;
@@ -454,6 +464,7 @@ struct Pipeline {
                 reid->crop_src.frames = nullptr;
                 HIP_CHECK(hipMemcpyAsync(c.d_emb.p + (size_t)c0 * dim, reid->embeddings(), (size_t)k * dim * 4, hipMemcpyDeviceToDevice, s));
                 launch_normalize_rows(c.d_emb.p + (size_t)c0 * dim, c.d_emb_n.p + (size_t)c0 * dim, k, dim, s);
+                HIP_CHECK(hipMemcpyAsync(c.h_valid.p + c0, c.d_valid.p + c0, (size_t)k * 4, hipMemcpyDeviceToHost, s));
                 n_overflow_rounds += 1;
             }
             HIP_CHECK(hipEventRecord(c.ev_extra, s));
@@ -469,7 +480,7 @@ struct Pipeline {
                 fd.crop0 = crop0;
                 AIC_REQUIRE(fd.n == n_dev, AIC_ERR_RUNTIME, "detection filter: device and host counts differ");
             }
-            if (total) HIP_CHECK(hipMemcpy(c.h_valid.p, c.d_valid.p, (size_t)total * 4, hipMemcpyDeviceToHost));
+            // (c.h_valid arrived with the ReID rounds, behind `done`)
         }
         t_wait += now() - t0;
     }
@@ -683,6 +694,7 @@ struct Pipeline {
                     if (perr) break;
                 }
                 if (ck[k % NCK].filt_dev) prepare_b(ck[k % NCK]);
+                ck[k % NCK].prev_dev_mode = ck[k % NCK].dev_mode;
                 if (ck[k % NCK].dev_mode) {
                     trk.dev_assoc = true;
                     stage_b_device(ck[k % NCK], goff[k], n_tracks, tracks6, track_conf, n_dets, det_boxes, det_scores, det_labels);
@@ -943,7 +955,7 @@ int aic_pipeline_option(aic_pipeline* p, const char* key, int value) {
             p->p.assoc_limit = value;
         }
         else if (k == "device_filter") {
-            AIC_REQUIRE(value == 0 || value == 1, AIC_ERR_INVALID, "device_filter: 0 host filter, 1 on the device");
+            AIC_REQUIRE(value >= 0 && value <= 2, AIC_ERR_INVALID, "device_filter: 0 host filter, 1 on the device while the association is, 2 always on the device");
             p->p.dev_filter = value;
         }
         else if (k == "group_frames") {

@@ -834,19 +834,22 @@ int aic_kf_initiate(int device_id, const float* z, int n, float* mean, float* co
     });
 }
 
-int aic_kf_predict(int device_id, float* mean, float* cov, int n) {
+int aic_kf_predict_dt(int device_id, float* mean, float* cov, int n, float dt) {
     return guarded([&] {
         AIC_REQUIRE(n >= 0 && (n == 0 || (mean && cov)), AIC_ERR_INVALID, "bad argument");
+        AIC_REQUIRE(dt == dt && dt - dt == 0.f, AIC_ERR_INVALID, "dt must be finite");
         Device& d = device(device_id);
         Tmp t(d);
         float* dm = t.up(mean, (size_t)n * 8);
         float* dc = t.up(cov, (size_t)n * 64);
-        launch_kf_predict(dm, dc, nullptr, n, d.s_trk);
+        launch_kf_predict(dm, dc, nullptr, n, d.s_trk, dt);
         t.down(mean, dm, (size_t)n * 8);
         t.down(cov, dc, (size_t)n * 64);
         t.sync();
     });
 }
+
+int aic_kf_predict(int device_id, float* mean, float* cov, int n) { return aic_kf_predict_dt(device_id, mean, cov, n, 1.f); }
 
 int aic_kf_project(int device_id, const float* mean, const float* cov, int n, float* pmean, float* pcov) {
     return guarded([&] {

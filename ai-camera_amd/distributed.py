@@ -102,8 +102,11 @@ def gpu_numa_node(dev: int):
 
 def bind_rank_to_gpu_numa(local_rank: int, world: int):
     """os.sched_setaffinity for this process (and every thread it starts later): the allowed cores of the GPU's NUMA node,
-    split among the ranks that share the node; without NUMA information an even slice of the allowed cores.  Call before the
-    first GPU call.  Returns a description for the bench line; never raises (a rehearsal on a laptop must still run)."""
+    split among the ranks that share the node; without NUMA information an even slice of the allowed cores.  Call first thing in a
+    rank.  The PCI bus ids come from the HIP runtime's own enumeration (gpu_numa_node -> torch.cuda.get_device_properties), so with
+    world > 1 this call DOES initialise the runtime: its helper threads exist before the affinity is set (they are not on any hot
+    path; every thread started afterwards -- producer, consumer, exchange -- inherits the binding), and NO exec / relaunch may
+    follow it in this process.  Returns a description for the bench line; never raises (a rehearsal on a laptop must still run)."""
     try:
         allowed = sorted(os.sched_getaffinity(0))
     except AttributeError:

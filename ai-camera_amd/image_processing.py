@@ -32,14 +32,47 @@ def preprocess_yolo_input(image_bgr, target_shape=(640, 640), device=0):
     return out, (ratio, ratio), (dw, dh)
 
 
-def letterbox(im, new_shape=(640, 640), color=(114, 114, 114), auto=False, scaleFill=False, scaleup=False, stride=32):
-    """image_processing.py:7-70 for the only mode the hot path uses (auto=False, scaleup=False):
-    returns the padded uint8 BGR image, (r, r), (dw, dh)."""
-    if auto or scaleFill or scaleup or tuple(color) != (114, 114, 114):
-        raise NotImplementedError("only the mode used by preprocess_yolo_input is accelerated")
-    t, ratios, pad = preprocess_yolo_input(im, new_shape)
-    img = np.rint(t[0] * 255.0).astype(np.uint8)[::-1].transpose(1, 2, 0)   # RGB planes -> BGR HWC
-    return np.ascontiguousarray(img), ratios, pad
+def letterbox_geometry(shape, new_shape=(640, 640), auto=True, scaleFill=False, scaleup=True, stride=32):
+    """The integer / float geometry of image_processing.py:33-67 for every mode, in Python arithmetic like the reference's:
+    returns r, (unpad_h, unpad_w), (dw, dh) as the reference returns them, (top, bottom, left, right)."""
+    shape = tuple(int(v) for v in shape[:2])
+    if isinstance(new_shape, int):
+        new_shape = (new_shape, new_shape)
+    r_h = new_shape[0] / shape[0]
+    r_w = new_shape[1] / shape[1]
+    if not scaleup:
+        r_h = min(r_h, 1.0)
+        r_w = min(r_w, 1.0)
+    r = min(r_h, r_w)
+    new_unpad = (int(round(shape[0] * r)), int(round(shape[1] * r)))
+    dw, dh = new_shape[1] - new_unpad[1], new_shape[0] - new_unpad[0]
+    if auto:                                   # :50-51 minimum rectangle
+        dw, dh = np.mod(dw, stride), np.mod(dh, stride)
+    elif scaleFill:                            # :52-54 stretch
+        dw, dh = 0.0, 0.0
+        new_unpad = (new_shape[0], new_shape[1])
+    dw /= 2
+    dh /= 2
+    if shape[::-1] == new_unpad:               # :63 compares (W, H) with (H, W): when it holds the frame is NOT resized
+        new_unpad = shape
+    top, bottom = int(round(dh - 0.1)), int(round(dh + 0.1))
+    left, right = int(round(dw - 0.1)), int(round(dw + 0.1))
+    return r, new_unpad, (dw, dh), (top, bottom, left, right)
+
+
+def letterbox(im, new_shape=(640, 640), color=(114, 114, 114), auto=True, scaleFill=False, scaleup=True, stride=32, device=0):
+    """image_processing.py:7-70, same defaults and every mode: the padded uint8 BGR image, (r, r), (dw, dh).  The geometry is host
+    arithmetic (as in the reference); the resize + border is one HIP launch (aic_letterbox_image)."""
+    f = _frame(im)
+    r, (uh, uw), (dw, dh), (top, bottom, left, right) = letterbox_geometry(f.shape, new_shape, auto, scaleFill, scaleup, stride)
+    if min(uh, uw) <= 0:
+        raise ValueError("letterbox: the resized image would be empty")       # cv2.resize raises on an empty destination
+    if isinstance(color, (int, float)):
+        color = (color, color, color)                                         # cv2 would take a scalar as (v, 0, 0, 0); the reference never passes one
+    c = [int(v) for v in tuple(color)[:3]] + [0] * (3 - len(tuple(color)[:3]))
+    out = np.empty((uh + top + bottom, uw + left + right, 3), np.uint8)
+    L.call("aic_letterbox_image", device, L.ptr(f), f.shape[0], f.shape[1], uh, uw, top, bottom, left, right, c[0], c[1], c[2], L.ptr(out))
+    return out, (r, r), (dw, dh)
 
 
 def preprocess_reid_input(image_crop_bgr, target_shape=(128, 64), device=0):

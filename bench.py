@@ -189,8 +189,9 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus} "
                          f"(or without it: bench.py starts the ranks itself)")
     D = importlib.import_module("ai-camera_amd.distributed")
-    # Before any GPU call: pin this rank's host threads (producer, tracker/consumer, copy engine submissions) to the cores of
-    # the NUMA node its GPU hangs off, so 8 ranks do not share cores and page-locked buffers are allocated node-locally.
+    # First thing in a rank: pin its host threads (producer, tracker/consumer, copy engine submissions) to the cores of the NUMA node
+    # its GPU hangs off, so 8 ranks do not share cores and page-locked buffers are allocated node-locally.  With N > 1 the PCI query
+    # goes through the HIP runtime (it is initialised from here on): nothing below may exec or relaunch this process.
     affinity = D.bind_rank_to_gpu_numa(local_rank, world)
     import torch
     import torch.distributed as dist

@@ -97,6 +97,12 @@ int aic_reid_infer(aic_model* m, const float* crops_nchw, int n, int mem, float*
  * frame -> fp32 NCHW RGB /255, padded with 114; also returns r and (pad_w, pad_h). */
 int aic_letterbox(int device, const uint8_t* frame_bgr, int h, int w, int out_h, int out_w,
                   float* out_nchw, float* ratio, float* pad_w, float* pad_h);
+/* letterbox() itself, any mode (image_processing.py:7-70: auto / scaleFill / scaleup / color): the caller works out the
+ * geometry the mode produces (:33-67, host integer logic) and this resamples the frame to unpad_h x unpad_w (cv2.resize
+ * INTER_LINEAR, :64) and surrounds it with the constant border (cv2.copyMakeBorder, :68).
+ * out: u8 BGR HWC [(unpad_h + top + bottom), (unpad_w + left + right), 3], caller-owned. */
+int aic_letterbox_image(int device, const uint8_t* frame_bgr, int h, int w, int unpad_h, int unpad_w, int top, int bottom,
+                        int left, int right, int color_b, int color_g, int color_r, uint8_t* out_bgr);
 /* _extract_image_crops + preprocess_reid_input (src/tracker/deepsort_tracker.py:143-159,
  * image_processing.py:105-138): int-truncate + clamp boxes, bilinear resize to out_h x out_w,
  * BGR->RGB, (x/255-mean)/std, NCHW. valid[i]=0 for empty crops (their tensor is zero). */
@@ -120,6 +126,9 @@ int aic_reid_embed(aic_model* reid, const uint8_t* frame_bgr, int h, int w, int 
  * filters per launch. mean[n,8], cov[n,8,8], z[n,4] fp32 host arrays. */
 int aic_kf_initiate(int device, const float* z, int n, float* mean, float* cov);
 int aic_kf_predict(int device, float* mean, float* cov, int n);
+/* the same with the time step of KalmanFilter(dt) (kalman_filter.py:34-44: fp32(dt) on the position/velocity diagonal of the
+ * motion matrix); aic_kf_predict is dt = 1, the only value the reference's tracker uses (tracker_core.py:30). */
+int aic_kf_predict_dt(int device, float* mean, float* cov, int n, float dt);
 int aic_kf_project(int device, const float* mean, const float* cov, int n, float* pmean, float* pcov);
 int aic_kf_update(int device, float* mean, float* cov, const float* z, int n);
 /* d2[n,m]: squared Mahalanobis distance of filter i to measurement zs[i*m+j] (shared_z=0) or
@@ -200,7 +209,9 @@ int aic_tracker_update(aic_tracker* t, const float* det_tlwh, const float* conf,
  * 16) -- the pipeline's per-launch-group association with the embeddings supplied by the caller.  counts[k]; the rows of all
  * frames concatenated: det_tlwh[sum,4], conf[sum], class id[sum], feat[sum,dim] (host or device), has_feat[sum] (NULL = all).
  * Per frame (any may be NULL): n_out[k] confirmed tracks updated in the frame (true count), out6[k,cap_rows,6] + out_conf[k,
- * cap_rows] as aic_tracker_outputs; n_match[k], match_track_id / match_det [k,cap_rows] as aic_tracker_last_matches.  Device
+ * cap_rows] as aic_tracker_outputs; n_match[k], match_track_id / match_det [k,cap_rows] as aic_tracker_last_matches.  n_out and
+ * n_match are the TRUE counts: only the first cap_rows rows / matches of a frame are stored, a caller compares the counts with
+ * cap_rows to see a clipped frame.  Device
  * path only (nn_budget > 0, max_tracks <= 512, dim % 4 == 0): AIC_ERR_INVALID otherwise.  Same results as k predict/update calls. */
 int aic_tracker_update_batch(aic_tracker* t, int k, const int32_t* counts, const float* det_tlwh, const float* conf,
                              const int32_t* cls, const float* feat, int feat_mem, const uint8_t* has_feat, int dim,

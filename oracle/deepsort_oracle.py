@@ -65,8 +65,17 @@ def kf_initiate(z):
     return mean, np.diag(np.square(std)).astype(np.float32)
 
 
-def kf_predict(mean, cov):
-    """kalman_filter.py:85-120 -- x<-Fx, P<-F P F^T + Q(h)."""
+def motion_matrix(dt=1.0):
+    """kalman_filter.py:41-44 -- identity with fp32(dt) on the position/velocity diagonal."""
+    f = np.eye(8, dtype=np.float32)
+    for i in range(4):
+        f[i, 4 + i] = dt
+    return f
+
+
+def kf_predict(mean, cov, dt=1.0):
+    """kalman_filter.py:85-120 -- x<-Fx, P<-F P F^T + Q(h); F from KalmanFilter(dt) (:34-44)."""
+    _F = motion_matrix(dt)
     h = mean[3]
     std = [_STD_POS * h, _STD_POS * h, 1e-2, _STD_POS * h,
            _STD_VEL * h, _STD_VEL * h, 1e-5, _STD_VEL * h]

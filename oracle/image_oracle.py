@@ -83,6 +83,35 @@ def letterbox_u8(frame_bgr, new_shape=(640, 640), color=114):
     return out, (r, r), (dw, dh)
 
 
+def letterbox_any(frame_bgr, new_shape=(640, 640), color=(114, 114, 114), auto=True, scaleFill=False, scaleup=True, stride=32):
+    """image_processing.py:7-70 with the reference's own defaults and every mode, followed line by line (:33-70)."""
+    shape = frame_bgr.shape[:2]
+    if isinstance(new_shape, int):
+        new_shape = (new_shape, new_shape)
+    r_h, r_w = new_shape[0] / shape[0], new_shape[1] / shape[1]
+    if not scaleup:
+        r_h, r_w = min(r_h, 1.0), min(r_w, 1.0)
+    r = min(r_h, r_w)
+    new_unpad = (int(round(shape[0] * r)), int(round(shape[1] * r)))
+    dw, dh = new_shape[1] - new_unpad[1], new_shape[0] - new_unpad[0]
+    if auto:
+        dw, dh = np.mod(dw, stride), np.mod(dh, stride)
+    elif scaleFill:
+        dw, dh = 0.0, 0.0
+        new_unpad = (new_shape[0], new_shape[1])
+    dw /= 2
+    dh /= 2
+    im = frame_bgr
+    if tuple(shape[::-1]) != tuple(new_unpad):
+        im = resize_linear_u8(frame_bgr, new_unpad[0], new_unpad[1])
+    top, bottom = int(round(dh - 0.1)), int(round(dh + 0.1))
+    left, right = int(round(dw - 0.1)), int(round(dw + 0.1))
+    out = np.empty((im.shape[0] + top + bottom, im.shape[1] + left + right, 3), np.uint8)
+    out[:] = np.asarray(color, np.uint8)[:3]
+    out[top:top + im.shape[0], left:left + im.shape[1]] = im
+    return out, (r, r), (dw, dh)
+
+
 def preprocess_yolo_input(frame_bgr, target_shape=(640, 640)):
     """image_processing.py:73-102 -> (fp32 [1,3,H,W] RGB /255, ratios, (pad_w, pad_h))."""
     img, ratios, pad = letterbox_u8(frame_bgr, target_shape)

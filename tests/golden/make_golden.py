@@ -22,8 +22,8 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 REF = "/root/reference"
-sys.path.insert(0, ROOT)
-sys.path.insert(1, REF)
+sys.path.insert(0, REF)      # first: `src` must be the REFERENCE's package, not this repo's re-export package of the same name
+sys.path.insert(1, ROOT)
 sys.path.insert(2, HERE)
 
 from oracle import deepsort_oracle as O  # noqa: E402
@@ -36,6 +36,9 @@ from src.tracker.core.detection import Detection  # noqa: E402
 from src.tracker.core.track import Track, TrackState  # noqa: E402
 from src.tracker.core import matching, linear_assignment  # noqa: E402
 from src.tracker.core.tracker_core import TrackerCore  # noqa: E402
+import src.tracker.core.kalman_filter as _kfmod  # noqa: E402
+
+assert os.path.realpath(_kfmod.__file__).startswith(REF + os.sep), _kfmod.__file__
 
 
 def eq(a, b, what):
@@ -105,6 +108,44 @@ def gen_kf():
     out.update(selftest_pred_mean=m, selftest_pred_cov=c, selftest_upd_mean=m2, selftest_upd_cov=c2)
     np.savez_compressed(os.path.join(HERE, "kf.npz"), **out)
     print("kf.npz", {k: v.shape for k, v in out.items()})
+
+
+def gen_kf_dt():
+    """KalmanFilter(dt != 1) (kalman_filter.py:34-44): initiate -> 3 x predict -> update -> 2 x predict for dt in (0.5, 2.0, 1/30)."""
+    rng = np.random.default_rng(202)
+    n = 12
+    z = np.stack([rng.uniform(50, 1200, n), rng.uniform(50, 650, n), rng.uniform(0.25, 0.7, n), rng.uniform(30, 260, n)], 1).astype(np.float32)
+    out = {"z0": z, "dts": np.array([0.5, 2.0, 1.0 / 30.0], np.float64)}
+    for di, dt in enumerate(out["dts"]):
+        kf = KalmanFilter(dt=float(dt))
+        means, covs = zip(*[kf.initiate(z[k]) for k in range(n)])
+        means, covs = list(means), list(covs)
+        # give the velocities something to propagate
+        for k in range(n):
+            means[k] = means[k].copy()
+            means[k][4:] = rng.normal(0, 2, 4).astype(np.float32) * np.array([1, 1, 0.001, 1], np.float32)
+        out[f"start_mean_{di}"] = np.stack(means)
+        out[f"start_cov_{di}"] = np.stack(covs)
+        cm, cc = [], []
+        zu = None
+        for step in range(6):
+            if step == 3:
+                zu = (np.stack(means)[:, :4] + rng.normal(0, 3, (n, 4)).astype(np.float32) * np.array([1, 1, 0.005, 1], np.float32)).astype(np.float32)
+                for k in range(n):
+                    m, c = kf.update(means[k], covs[k], zu[k])
+                    om, oc = O.kf_update(means[k], covs[k], zu[k])
+                    eq(m, om, "upd mean"), eq(c, oc, "upd cov")
+                    means[k], covs[k] = m.astype(np.float32), c.astype(np.float32)
+            else:
+                for k in range(n):
+                    m, c = kf.predict(means[k], covs[k])
+                    om, oc = O.kf_predict(means[k], covs[k], dt=float(dt))
+                    eq(m, om, "pred mean dt"), eq(c, oc, "pred cov dt")
+                    means[k], covs[k] = m, c
+            cm.append(np.stack(means)), cc.append(np.stack(covs))
+        out[f"chain_mean_{di}"], out[f"chain_cov_{di}"], out[f"upd_z_{di}"] = np.stack(cm), np.stack(cc), zu
+    np.savez_compressed(os.path.join(HERE, "kf_dt.npz"), **out)
+    print("kf_dt.npz", {k: v.shape for k, v in out.items()})
 
 
 # ------------------------------------------------------------------------------ G2/G3: costs
@@ -266,6 +307,6 @@ def gen_traj(name):
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["kf", "costs", "assign"] + list(TRAJ)
+    which = sys.argv[1:] or ["kf", "kf_dt", "costs", "assign"] + list(TRAJ)
     for w in which:
-        {"kf": gen_kf, "costs": gen_costs, "assign": gen_assign}.get(w, lambda w=w: gen_traj(w))()
+        {"kf": gen_kf, "kf_dt": gen_kf_dt, "costs": gen_costs, "assign": gen_assign}.get(w, lambda w=w: gen_traj(w))()

@@ -321,7 +321,7 @@ def test_device_filter_equals_host_filter(gpu, engines, assoc):
         frames = sc.render_batch(0, n_frames)
         TP = pkg("pipeline").TrackingPipeline
         out = {}
-        for filt in (1, 0):
+        for filt in (2, 1, 0):                                     # 2: always on the device; 1 (default): while the association is; 0: host
             pipe = TP(engines[0], engines[1], (720, 1280), batch=batch, ring_frames=n_frames, max_persons=64, dtype="fp16", inject=False,
                       min_confidence=0.93, max_tracks=512)
             pipe.option("device_assoc", assoc)
@@ -331,12 +331,16 @@ def test_device_filter_equals_host_filter(gpu, engines, assoc):
             emb, cpf = pipe.group_embeddings()
             c = pipe.counters()
             out[filt] = (tracks, dets, emb.copy(), cpf.copy(), pipe.tracker_core.export_arrays())
-            if filt:
+            if filt == 2 or (filt == 1 and assoc == 2):
                 assert c["filter_device_groups"] >= 3 and c["filter_host_groups"] == 0 and c["reid_overflow_rounds"] == 0, c
+            elif filt == 1:       # association on the host: the two chunk contexts' first groups on the device, then the host filter
+                assert c["filter_device_groups"] == 2 and c["filter_host_groups"] >= 1, c
             else:
                 assert c["filter_host_groups"] >= 3 and c["filter_device_groups"] == 0, c
             pipe.close()
-        (ta, da, ea, ca, xa), (tb, db, eb, cb, xb) = out[1], out[0]
+        for key in (0, 2):
+            assert out[1][0] == out[key][0] and np.array_equal(out[1][2], out[key][2]) and np.array_equal(out[1][3], out[key][3])
+        (ta, da, ea, ca, xa), (tb, db, eb, cb, xb) = out[2], out[0]
         assert sum(len(r) for r in tb) >= 3 and int(cb.sum()) > 0            # the scene confirms tracks and the last group has crops
         for f in range(n_frames):
             assert ta[f] == tb[f], f
@@ -363,7 +367,7 @@ def test_device_filter_crowded_groups_take_extra_reid_rounds(gpu, engines):
         frames = sc.render_batch(0, n_frames)
         TP = pkg("pipeline").TrackingPipeline
         out = {}
-        for filt in (1, 0):
+        for filt in (2, 0):
             reid = HipEngine(engines[1], dtype="fp16", max_items=48, warm_up=False)
             pipe = TP(engines[0], reid, (720, 1280), batch=4, ring_frames=n_frames, max_persons=16, dtype="fp16", inject=False, n_init=2, max_tracks=2048)
             pipe.option("device_filter", filt)
@@ -375,7 +379,7 @@ def test_device_filter_crowded_groups_take_extra_reid_rounds(gpu, engines):
                 assert c["filter_device_groups"] == 2 and c["reid_overflow_rounds"] >= 4, c
             pipe.close()
             reid.close()
-        (na, ra, da, xa), (nb, rb, db, xb) = out[1], out[0]
+        (na, ra, da, xa), (nb, rb, db, xb) = out[2], out[0]
         assert da.min() > 50 and np.array_equal(da, db) and np.array_equal(na, nb) and nb.max() > 16
         for f in range(n_frames):
             assert np.array_equal(ra[f][:min(na[f], 16)], rb[f][:min(nb[f], 16)]), f

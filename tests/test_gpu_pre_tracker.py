@@ -31,6 +31,22 @@ def test_letterbox_other_target(gpu):
     assert r == orr and p == op and np.array_equal(x, ox)
 
 
+@pytest.mark.parametrize("hw", [(720, 1280), (100, 37), (480, 640), (640, 640), (300, 300), (37, 900)])
+@pytest.mark.parametrize("mode", [dict(), dict(auto=False), dict(auto=False, scaleFill=True), dict(auto=False, scaleup=False),
+                                  dict(scaleup=False), dict(auto=True, stride=64, color=(3, 200, 77)), dict(new_shape=(640, 480), auto=False, scaleFill=True),
+                                  dict(new_shape=416)])
+def test_letterbox_every_mode_bit_exact(gpu, hw, mode):
+    """letterbox() with the reference's own defaults (auto=True, scaleup=True) and every other mode (image_processing.py:7-70):
+    image, ratios and paddings against the line-by-line restatement; (480, 640) x scaleFill to (640, 480) is the case where
+    the reference's (W, H) == (H, W) guard (:63) skips the resize."""
+    frame = np.random.default_rng(hw[0] * 11 + hw[1]).integers(0, 256, hw + (3,), dtype=np.uint8)
+    img, ratios, pad = ip.letterbox(frame, **mode)
+    oimg, oratios, opad = I.letterbox_any(frame, **mode)
+    assert ratios == oratios and tuple(pad) == tuple(opad)
+    assert img.shape == oimg.shape and img.dtype == np.uint8
+    assert np.array_equal(img, oimg)
+
+
 def test_crop_resize_bit_exact(gpu):
     sc = syn.Scene(seed=4, n_targets=30)
     frame = sc.render(3)
@@ -88,6 +104,32 @@ def test_kalman_vs_reference_fixture(gpu, golden):
     assert (np.diag(c1) >= np.diag(c0)).all()
     d = kf.gating_distance(m1, c1, np.array([[100, 150, 0.5, 60], [300, 400, 0.6, 80], [101, 151, 0.5, 61]], np.float32))
     assert d[0] < d[2] < d[1] and d[0] < 9.4877
+
+
+def test_kalman_time_step_vs_reference_fixture(gpu, golden):
+    """KalmanFilter(dt) (kalman_filter.py:34-44) for dt = 0.5, 2, 1/30 against states the REFERENCE produced (tests/golden/kf_dt.npz):
+    every predict restarted from the fixture's state.  The reference multiplies by fp32(dt) inside a BLAS sgemm whose use of fused
+    multiply-adds is not specified, so this is a tolerance (one fp32 rounding per product), not a bit pattern; dt = 1 stays exact."""
+    KF = pkg("core.kalman_filter").KalmanFilter
+    g = golden("kf_dt")
+    for di, dt in enumerate(g["dts"]):
+        kf = KF(dt=float(dt))
+        pm, pc = g[f"start_mean_{di}"], g[f"start_cov_{di}"]
+        for step in range(6):
+            em, ec = g[f"chain_mean_{di}"][step], g[f"chain_cov_{di}"][step]
+            if step == 3:
+                m, c = kf.update(pm, pc, g[f"upd_z_{di}"])
+                assert np.allclose(m, em, rtol=1e-5, atol=1e-3) and np.allclose(c, ec, rtol=1e-4, atol=1e-4)
+            else:
+                m, c = kf.predict(pm, pc)
+                assert np.allclose(m, em, rtol=3e-7, atol=0) and np.allclose(c, ec, rtol=1e-6, atol=1e-9), (dt, step, np.abs(c - ec).max())
+            pm, pc = em, ec
+    one = KF(dt=1.0)
+    k = golden("kf")
+    m, c = one.predict(k["init_mean"], k["init_cov"])
+    e = KF()
+    m2, c2 = e.predict(k["init_mean"], k["init_cov"])
+    assert np.array_equal(m, m2) and np.array_equal(c, c2)
 
 
 def test_cost_kernels_vs_reference_fixture(gpu, golden, lib):

@@ -52,3 +52,34 @@ def test_preprocess_shapes_and_normalisation():
     assert np.array_equal(t[0], ref[0])
     s = I.scale_bboxes(np.array([[0, 140, 640, 500], [-10, 100, 700, 600]], np.float32), (720, 1280), (0.5, 0.5), (0.0, 140.0))
     assert np.array_equal(s, np.array([[0, 0, 1280, 720], [0, 0, 1280, 720]], np.float32))
+
+
+def test_letterbox_modes_geometry_and_host_logic_agree():
+    """Every mode of letterbox() (image_processing.py:33-70): the oracle's line-by-line restatement and the product's host-side
+    geometry (ai-camera_amd/image_processing.letterbox_geometry) give the same ratios, paddings, borders and image shape; a few
+    known answers worked out by hand from the reference's formulas."""
+    from conftest import pkg
+    ip = pkg("image_processing")
+    rng = np.random.default_rng(3)
+    modes = [dict(), dict(auto=False), dict(auto=False, scaleFill=True), dict(auto=False, scaleup=False), dict(scaleup=False),
+             dict(auto=True, stride=64), dict(new_shape=(640, 480), auto=False, scaleFill=True), dict(new_shape=416)]
+    for hw in [(720, 1280), (100, 37), (480, 640), (640, 640), (300, 300), (37, 900), (1, 1)]:
+        frame = rng.integers(0, 256, hw + (3,), dtype=np.uint8)
+        for mode in modes:
+            oimg, (r, _), (dw, dh) = I.letterbox_any(frame, **mode)
+            gr, (uh, uw), (gdw, gdh), (top, bottom, left, right) = ip.letterbox_geometry(frame.shape, **{k: v for k, v in mode.items() if k != "color"})
+            assert (gr, gdw, gdh) == (r, dw, dh)
+            assert oimg.shape == (uh + top + bottom, uw + left + right, 3), (hw, mode)
+    # 1280x720, reference defaults (auto=True): r = 0.5, 640x360, dh = (640-360) % 32 / 2 = 12, no width padding
+    img, (r, _), (dw, dh) = I.letterbox_any(np.zeros((720, 1280, 3), np.uint8))
+    assert (r, dw, dh) == (0.5, 0.0, 12.0) and img.shape == (384, 640, 3) and (img[:12] == 114).all() and (img[12:372] == 0).all()
+    # scaleup=True on a small frame: 100x37 -> r = 6.4, 640x237
+    img, (r, _), (dw, dh) = I.letterbox_any(np.zeros((100, 37, 3), np.uint8), auto=False)
+    assert r == 6.4 and img.shape == (640, 640, 3) and (dw, dh) == ((640 - 237) / 2, 0.0)
+    # scaleFill: stretched to the target, no padding, ratio still the aspect-preserving one
+    img, (r, _), pad = I.letterbox_any(np.zeros((720, 1280, 3), np.uint8), auto=False, scaleFill=True)
+    assert img.shape == (640, 640, 3) and tuple(pad) == (0.0, 0.0) and r == 0.5
+    # the (W, H) == (H, W) guard: a 480x640 frame "stretched" to (640, 480) is returned unresized
+    src = rng.integers(0, 256, (480, 640, 3), dtype=np.uint8)
+    img, _, _ = I.letterbox_any(src, new_shape=(640, 480), auto=False, scaleFill=True)
+    assert np.array_equal(img, src)

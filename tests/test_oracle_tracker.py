@@ -25,6 +25,22 @@ def test_known_answers_detection_and_iou(golden):
     assert np.allclose(d, [[0, 1 - 0.70710678], [1, 1 - 0.70710678]], atol=1e-6)
 
 
+def test_kalman_time_step_fixture(golden):
+    """KalmanFilter(dt != 1) (kalman_filter.py:34-44): the oracle reproduces the states the reference produced, bit for bit."""
+    g = golden("kf_dt")
+    for di, dt in enumerate(g["dts"]):
+        for step in range(6):
+            pm = g[f"chain_mean_{di}"][step - 1] if step else g[f"start_mean_{di}"]
+            pc = g[f"chain_cov_{di}"][step - 1] if step else g[f"start_cov_{di}"]
+            for k in range(len(pm)):
+                if step == 3:
+                    m, c = O.kf_update(pm[k], pc[k], g[f"upd_z_{di}"][k])
+                else:
+                    m, c = O.kf_predict(pm[k], pc[k], dt=float(dt))
+                assert np.array_equal(m, g[f"chain_mean_{di}"][step][k]) and np.array_equal(c, g[f"chain_cov_{di}"][step][k])
+    assert np.array_equal(O.motion_matrix(1.0), O._F)
+
+
 def test_kalman_selftest_values(golden):
     # values printed by src/tracker/core/kalman_filter.py:252-340 (SURVEY §4)
     m, c = O.kf_initiate(np.array([100, 150, 0.5, 60], np.float32))
