@@ -125,6 +125,7 @@ _SIGS = {
     "aic_prof_enable": (_I, [_I, _I]),
     "aic_prof_reset": (_I, [_I]),
     "aic_prof_read": (_I, [_I, _I, _P, _P, _P, _P]),
+    "aic_prof_read_union": (_I, [_I, _I, _P]),
 }
 EXPORTS = tuple(_SIGS)
 
@@ -181,5 +182,7 @@ def prof_read(device=0):
     for i, name in enumerate(PROF_CLASSES):
         ms, n, fl, by = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
         call("aic_prof_read", device, i, C.byref(ms), C.byref(n), C.byref(fl), C.byref(by))
-        out[name] = dict(ms=ms.value, launches=n.value, flops=fl.value, bytes=by.value)
+        mu = C.c_double()
+        call("aic_prof_read_union", device, i, C.byref(mu))
+        out[name] = dict(ms=ms.value, launches=n.value, flops=fl.value, bytes=by.value, ms_union=mu.value)
     return out

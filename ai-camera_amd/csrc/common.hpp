@@ -83,6 +83,11 @@ struct Device {
     std::vector<Pair> pool;
     std::mutex prof_mu;            // launches come from two host threads (pipeline producer / tracker)
     double ms[AIC_PROF_CLASSES] = {0};
+    // length of the UNION of a class's bracketed intervals on the device clock (ms): with brackets open on two streams at once
+    // (split_streams: YOLO's convs beside ReID's) the summed durations count the overlap twice and say nothing about the class's
+    // rate; FLOPs / union does.  Equal to ms[] while one stream carries the class.  0 when the cross-stream timestamps are unavailable
+    double ms_union[AIC_PROF_CLASSES] = {0};
+    hipEvent_t prof_ref = nullptr;     // time origin of the intervals, recorded by prof_reset
     int64_t launches[AIC_PROF_CLASSES] = {0};
     double flops[AIC_PROF_CLASSES] = {0};
     double bytes[AIC_PROF_CLASSES] = {0};

@@ -1,6 +1,8 @@
 // runtime.cpp -- device contexts, error state, HIP-event profiling, library-level C ABI.
 #include "common.hpp"
 
+#include <algorithm>
+
 #include <cstdlib>
 
 namespace aic {
@@ -83,19 +85,38 @@ void Device::prof_end(int cls, hipStream_t s) {
 void Device::prof_collect() {
     (void)hipDeviceSynchronize();
     std::lock_guard<std::mutex> lk(prof_mu);
+    std::vector<std::pair<float, float>> iv;
     for (int c = 0; c < AIC_PROF_CLASSES; ++c) {
+        iv.clear();
+        bool stamps = prof_ref != nullptr;
+        const bool any = !pending[c].empty();
         for (auto& p : pending[c]) {
             float t = 0.f;
             if (hipEventElapsedTime(&t, p.a, p.b) == hipSuccess) ms[c] += t;
+            float ta = 0.f, tb = 0.f;
+            if (stamps && hipEventElapsedTime(&ta, prof_ref, p.a) == hipSuccess && hipEventElapsedTime(&tb, prof_ref, p.b) == hipSuccess) iv.emplace_back(ta, tb);
+            else stamps = false;
             pool.push_back(p);
         }
         pending[c].clear();
+        (void)hipGetLastError();
+        if (!stamps) { if (any) ms_union[c] = -1e30; continue; }   // (stays negative: reported as unavailable)
+        // intervals of different collects cannot overlap (each collect follows a device synchronisation): union per collect, summed
+        std::sort(iv.begin(), iv.end());
+        float lo = 0.f, hi = -1.f;
+        for (auto& q : iv) {
+            if (hi < lo || q.first > hi) { if (hi >= lo) ms_union[c] += hi - lo; lo = q.first, hi = q.second; }
+            else if (q.second > hi) hi = q.second;
+        }
+        if (hi >= lo) ms_union[c] += hi - lo;
     }
 }
 
 void Device::prof_reset() {
     prof_collect();
-    for (int c = 0; c < AIC_PROF_CLASSES; ++c) ms[c] = 0, launches[c] = 0, flops[c] = 0, bytes[c] = 0;
+    for (int c = 0; c < AIC_PROF_CLASSES; ++c) ms[c] = 0, ms_union[c] = 0, launches[c] = 0, flops[c] = 0, bytes[c] = 0;
+    if (!prof_ref && hipEventCreate(&prof_ref) != hipSuccess) prof_ref = nullptr;
+    if (prof_ref) { (void)hipEventRecord(prof_ref, s_main); (void)hipEventSynchronize(prof_ref); }
 }
 
 }  // namespace aic
@@ -131,6 +152,15 @@ int aic_prof_enable(int dev, int on) {
 
 int aic_prof_reset(int dev) {
     return guarded([&] { device(dev).prof_reset(); });
+}
+
+int aic_prof_read_union(int dev, int cls, double* ms_union) {
+    return guarded([&] {
+        AIC_REQUIRE(cls >= 0 && cls < AIC_PROF_CLASSES && ms_union, AIC_ERR_INVALID, "bad argument");
+        Device& d = device(dev);
+        d.prof_collect();
+        *ms_union = d.ms_union[cls] < 0 ? -1.0 : d.ms_union[cls];
+    });
 }
 
 int aic_prof_read(int dev, int cls, double* ms, int64_t* launches, double* flops, double* bytes) {

@@ -24,8 +24,9 @@ launch group's frames cross PCIe on a copy stream under the previous group's com
 and throughput for launch groups of 16 / 64 / 128 / 256 / 512 frames.
 
 One JSON line on rank 0.  `roofline`: the dominant kernel class conv_igemm (MFMA implicit GEMM), achieved =
-algorithmic conv FLOPs / its summed launch durations, HIP events on the launch stream, recorded over
-the timed region.  `cpu_baseline`: the oracle chain (torch-CPU fp32 nets + NumPy/SciPy DeepSORT) timed
+algorithmic conv FLOPs / the time during which a conv launch bracket was open on either launch stream (union of
+the brackets' intervals, paired HIP events per stream on the device clock, recorded over the timed region); the
+figure over the SUMMED bracket durations is reported beside it (the two agree with --single-stream).  `cpu_baseline`: the oracle chain (torch-CPU fp32 nets + NumPy/SciPy DeepSORT) timed
 on this box's host cores on a bounded sample of the same workload (rank 0, N=1 only): >= 200 frames on all
 cores with a per-stage split, plus a 1-thread leg.
 """
@@ -65,8 +66,10 @@ def parse(argv=None):
     p.add_argument("--no-prof", action="store_true", help="do not record HIP events in the timed region")
     p.add_argument("--cpu-frames", type=int, default=-1, help="frames of the all-cores CPU baseline leg (-1: 200, 0: skip)")
     p.add_argument("--no-curve", action="store_true", help="skip the launch-group-size curve and the HBM-resident side measurement")
+    p.add_argument("--no-plugin", action="store_true", help="skip the per-frame plugin-loop side leg (YOLODetector.detect + DeepSORT.update one frame at a time)")
     p.add_argument("--no-own", action="store_true", help="skip the own-detections side leg (inject=0: the detector's boxes feed crop / ReID / association)")
     p.add_argument("--resident", action="store_true", help="time the clip resident in HBM instead of streaming it from host memory")
+    p.add_argument("--single-stream", action="store_true", help="detector and crop + ReID of a launch group on ONE stream (rounds 1-3's headline mode) instead of two")
     p.add_argument("--backend", type=str, default="nccl", help="torch.distributed backend (nccl = RCCL over xGMI; gloo for CPU rehearsals)")
     p.add_argument("--gallery-exchange", type=int, default=0, help="configs[4]: all-gather a ReID gallery shard every K frames of stream time (0 = off)")
     p.add_argument("--dry-run", action="store_true", help="no GPU work: rank/affinity/rendezvous/reduction path only (CPU rehearsal of the N > 1 launch)")
@@ -145,6 +148,45 @@ def cpu_baseline(args, ypath, rpath):
             "ms_per_frame_by_stage": stages,
             "one_thread": {"value": round(d1 / s1, 3), "unit": "frames/s", "cores": 1, "sample": f"{d1} frames (bounded at 15 s)",
                            "ms_per_frame_by_stage": stages1}}
+
+
+def plugin_loop(args, ypath, rpath, sc, dev, n_frames=240):
+    """The reference's OWN calling pattern (src/aicamera_tracker.py:169-207): one frame at a time, synchronously, through the plugin
+    classes -- YOLODetector.detect(frame) then DeepSORT.update(boxes, scores, classes, frame) -- each call returning host NumPy / tuples
+    before the next starts.  The detector runs in full on every frame; DeepSORT.update receives the planted boxes (inject, SURVEY D7:
+    seeded weights cannot see the persons) so crop + ReID + association carry the headline's 30-person load.  Frames rendered ahead
+    (cap.read() is outside the reference's FPS span too, :170 vs :175)."""
+    import contextlib
+    import io
+    det_mod = importlib.import_module("ai-camera_amd.detector")
+    ds_mod = importlib.import_module("ai-camera_amd.deepsort_tracker")
+    with contextlib.redirect_stdout(io.StringIO()):                      # the constructors print like the reference's
+        det = det_mod.YOLODetector(engine_path=ypath, device=f"cuda:{dev}", dtype=args.dtype, max_batch=1)
+        trk = ds_mod.DeepSORT(reid_model_path=rpath, device=f"cuda:{dev}", dtype=args.dtype, reid_max_batch=max(32, args.persons))
+    warm = 20
+    frames = sc.render_batch(0, n_frames + warm)
+    lat = []
+    nd_tot, nt_tot = 0, 0
+    t_all = None
+    for f in range(n_frames + warm):
+        if f == warm:
+            t_all = time.perf_counter()
+        boxes, conf, cids, _ = sc.detections(f)
+        t0 = time.perf_counter()
+        d = det.detect(frames[f])
+        out = trk.update(boxes, conf, cids, frames[f])
+        t1 = time.perf_counter()
+        if f >= warm:
+            lat.append(t1 - t0)
+            nd_tot += len(d[0])
+            nt_tot += len(out)
+    wall = time.perf_counter() - t_all
+    lat = np.sort(np.asarray(lat))
+    return {"what": "per-frame plugin loop of src/aicamera_tracker.py:169-207: YOLODetector.detect(frame) + DeepSORT.update(planted boxes, frame), synchronous, "
+                    "host arrays in and out of every call",
+            "frames": n_frames, "fps": round(n_frames / float(lat.sum()), 1), "fps_wall(incl. the loop's own Python)": round(n_frames / wall, 1),
+            "latency_ms_p50": round(1e3 * float(lat[len(lat) // 2]), 3), "latency_ms_p99": round(1e3 * float(lat[min(len(lat) - 1, int(0.99 * len(lat)))]), 3),
+            "detector_boxes_per_frame": round(nd_tot / n_frames, 1), "confirmed_tracks_per_frame": round(nt_tot / n_frames, 1)}
 
 
 def pct(lat_s, frames, q):
@@ -272,6 +314,11 @@ def main():
             return pipe.run_raw_passes(0, frames_per_step, k)
         return pipe.run_raw_from_host_passes(host_frames, k)
 
+    # crop + ReID of a launch group on a stream of their own beside the group's detector (inject = planted: they do not depend on it): the
+    # thin YOLOv8n layers leave CUs idle that the ReID trunk's tiles fill.  Faster in every measurement since round 3; the mode `value` is
+    # quoted on since round 4 (the single-stream rate is the side field config.single_stream_fps)
+    split = not args.single_stream
+    pipe.option("split_streams", 1 if split else 0)
     if args.resident:
         pipe.upload(0, host_frames)
     if args.warmup > 0:
@@ -335,16 +382,14 @@ def main():
                 curve[str(g)] = {"fps": round(3 * n_fr / dtg, 1), "latency_ms_p50": pct(gl[full], gf[full], 0.5), "latency_ms_p99": pct(gl[full], gf[full], 0.99)}
             pipe.option("group_frames", 0)
             side["by_launch_group_frames"] = curve
-            # crop + ReID on a stream of their own beside the next group's detector (aic_pipeline_option "split_streams"): more frames/s, but
-            # the two streams' kernels stretch each other -- per-launch durations, and with them the roofline object, stop describing the
-            # kernels -- so it is not the default and not `value`
-            pipe.option("split_streams", 1)
+            # the other stream arrangement, as many passes as the timed region (the same share of pipeline fill)
+            pipe.option("split_streams", 0 if split else 1)
             pipe.run_raw_from_host_passes(host_frames, 1)
             t4 = time.perf_counter()
-            pipe.run_raw_from_host_passes(host_frames, args.steps)         # as many passes as the timed region: the same share of pipeline fill
+            pipe.run_raw_from_host_passes(host_frames, args.steps)
             L.call("aic_device_sync", dev)
-            side["split_streams_fps"] = round(args.steps * frames_per_step / (time.perf_counter() - t4), 1)
-            pipe.option("split_streams", 0)
+            side["other_streams_fps"] = round(args.steps * frames_per_step / (time.perf_counter() - t4), 1)
+            pipe.option("split_streams", 1 if split else 0)
         except Exception as e:
             side["error"] = str(e)
 
@@ -389,11 +434,40 @@ def main():
                                  "reid_overflow_rounds": c2["reid_overflow_rounds"],
                                  "association_frames(device, host)": [c2["assoc_device_frames"], c2["assoc_host_frames"]]}
                     p2.close()
+                # fp16 (the headline's precision) against the fp32 run of the SAME engine files on the same frames, each on its own detections:
+                # how many of the fp32 run's confirmed-track outputs the fp16 run reproduces and how often a reproduced track changes its
+                # partner id (CLEAR-MOT matching with the fp32 rows as the reference set, ai-camera_amd/mot_metrics.py).  Tracked per round:
+                # on this texture scene the association is near-degenerate, the figure is a property of the scene.
+                if args.dtype == "fp16":
+                    try:
+                        mm = importlib.import_module("ai-camera_amd.mot_metrics")
+                        nfr, rows_by = 256, {}
+                        for dt_name in ("fp32", "fp16"):
+                            p3 = TP(ypath, rpath, (args.height, args.width), batch=32, ring_frames=nfr, max_persons=64, device=dev, dtype=dt_name,
+                                    inject=False, min_confidence=floor, max_tracks=512)
+                            p3.upload(0, host_frames[:nfr])
+                            rows_by[dt_name] = p3.run(0, nfr)[0]
+                            y3, r3 = p3.yolo, p3.reid
+                            p3.close(), y3.close(), r3.close()
+                        ref = [(np.array([r[:4] for r in fr], np.float64).reshape(-1, 4), [r[4] for r in fr]) for fr in rows_by["fp32"]]
+                        ev = mm.evaluate(ref, rows_by["fp16"], iou_thr=0.9)
+                        own["fp16_vs_fp32_same_engine"] = {"frames": nfr, "fp32_track_outputs": ev["gt"], "fp16_track_outputs": ev["outputs"],
+                                                            "reproduced(IoU>=0.9)": ev["matches"], "id_switches": ev["idsw"],
+                                                            "only_in_fp32": ev["fn"], "only_in_fp16": ev["fp"]}
+                    except Exception as e:
+                        own["fp16_vs_fp32_same_engine"] = {"error": str(e)}
             finally:
                 cfg.CLASSES_TO_TRACK.clear()
                 cfg.CLASSES_TO_TRACK.update(old_cls)
         except Exception as e:
             own = {"error": str(e)}
+
+    plug = None
+    if rank == 0 and world == 1 and not args.no_plugin:
+        try:
+            plug = plugin_loop(args, ypath, rpath, sc, dev)
+        except Exception as e:
+            plug = {"error": str(e)}
 
     if rank == 0:
         flops_frame = pipe.yolo.flops_per_item + args.persons * pipe.reid.flops_per_item
@@ -401,7 +475,14 @@ def main():
         roof = None
         if prof and prof["conv_igemm"]["ms"] > 0:
             c = prof["conv_igemm"]
-            ach = c["flops"] / (c["ms"] * 1e-3) / 1e12
+            # denominator: the UNION of the class's bracketed intervals on the device clock (aic_prof_read_union).  With the class on two
+            # streams at once the summed launch durations count every overlapped microsecond twice (and each kernel is stretched by its
+            # neighbour), so they describe neither the kernels nor the class; FLOPs / union is the class's rate over the time any conv ran.
+            # Single stream: union == sum.  Both are in the line.
+            have_union = c.get("ms_union", -1) > 0
+            busy_ms = c["ms_union"] if have_union else c["ms"]
+            ach = c["flops"] / (busy_ms * 1e-3) / 1e12
+            ach_sum = c["flops"] / (c["ms"] * 1e-3) / 1e12
             traffic, tsrc, talg = None, None, None
             default_cfg = (args.dtype == "fp16" and args.model == "n" and args.batch == 512 and args.ring == 1024 and args.persons == 30
                            and args.width == 1280 and args.height == 720)
@@ -421,8 +502,12 @@ def main():
             roof = {"kernel": "conv class = conv_igemm_dma / conv_igemm_pp / conv3x3_pp_patch / conv3x3_patch / conv3x3_c16 / conv3x3_c64_resident / conv3x3_c64_block / c2f16_fused kernels (MFMA implicit GEMM: every conv of YOLOv8 + ReID except the two fused 3-channel stems)",
                     "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                     "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": tsrc, "traffic_algorithmic_same_basis": talg,
-                    "algorithmic_bytes_per_launch": round(c["bytes"] / max(c["launches"], 1)), "launches": c["launches"], "avg_launch_us": round(1e3 * c["ms"] / max(c["launches"], 1), 2),
-                    "kernel_ms_per_step": round(c["ms"] / args.steps, 3),
+                    "denominator": ("union of the conv class's bracketed intervals over both streams (paired HIP events per stream, device clock)" if have_union
+                                    else "summed bracket durations (HIP events; cross-stream timestamps unavailable)"),
+                    "achieved_over_summed_durations": round(ach_sum, 2), "frac_over_summed_durations": round(ach_sum / peak, 4),
+                    "algorithmic_bytes_per_launch": round(c["bytes"] / max(c["launches"], 1)), "launches": c["launches"],
+                    "avg_launch_us": round(1e3 * busy_ms / max(c["launches"], 1), 2), "avg_launch_us_summed": round(1e3 * c["ms"] / max(c["launches"], 1), 2),
+                    "kernel_ms_per_step": round(busy_ms / args.steps, 3), "kernel_ms_per_step_summed": round(c["ms"] / args.steps, 3),
                     "algorithmic_gflop_per_frame": round(flops_frame / 1e9, 3)}
         cpu = None
         if world == 1 and args.cpu_frames != 0:
@@ -447,7 +532,9 @@ def main():
                        "frame_latency_ms(handed to the pipeline -> tuples on host, full launch groups of the timed run)":
                            {"p50": pct(g_lat[full], g_frames[full], 0.5), "p99": pct(g_lat[full], g_frames[full], 0.99)},
                        "by_launch_group_frames(from host, 3 passes each)": side.get("by_launch_group_frames"),
-                       "split_streams_fps (crop + ReID beside the next group's detector, aic_pipeline_option split_streams; from host, as many passes as the timed region, not `value`: per-launch durations stretch)": side.get("split_streams_fps"),
+                       "streams": ("detector on the main stream, crop + ReID of the same launch group beside it on a second stream (aic_pipeline_option split_streams = 1)" if split
+                                   else "one stream: detector, then crop + ReID"),
+                       ("single_stream_fps" if split else "split_streams_fps") + " (the other stream arrangement, from host, as many passes as the timed region, not `value`)": side.get("other_streams_fps"),
                        "association": association,
                        "gallery_exchange_every_frames": args.gallery_exchange, "gallery_exchanges_done": exchanges,
                        "host_affinity": affinity, "host_clip_page_locked": pinned,
@@ -456,6 +543,7 @@ def main():
                        "host_us_per_frame": {"issue_launch_groups(producer thread)": round(1e6 * host["issue_s"] / max(host["frames"], 1), 1),
                                              "wait_for_gpu": round(1e6 * host["wait_s"] / max(host["frames"], 1), 1),
                                              "tracker_chain(host side of the association)": round(1e6 * host["track_s"] / max(host["frames"], 1), 1)},
+                       "plugin_loop": plug,
                        "own_detections(inject=0 side leg, 2 passes, not `value`)": own,
                        "side_error": side.get("error")},
             "roofline": roof, "cpu_baseline": cpu,

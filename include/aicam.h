@@ -389,6 +389,11 @@ int aic_prof_enable(int device, int class_mask);
 int aic_prof_reset(int device);
 /* total ms, launches, algorithmic FLOPs and algorithmic bytes accumulated for a class. */
 int aic_prof_read(int device, int cls, double* ms, int64_t* launches, double* flops, double* bytes);
+/* length (ms, device clock) of the UNION of the class's bracketed intervals since aic_prof_reset: equal to aic_prof_read's ms while
+ * one stream carries the class; with brackets open on two streams at once (aic_pipeline_option "split_streams") the overlap is
+ * counted once.  -1 when cross-stream event timestamps are unavailable.  (bench.py's roofline denominator; no reference counterpart:
+ * the reference times its loop with time.time(), src/aicamera_tracker.py:175,201.) */
+int aic_prof_read_union(int device, int cls, double* ms_union);
 
 #ifdef __cplusplus
 }

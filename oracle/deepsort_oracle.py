@@ -334,12 +334,14 @@ class OracleTracker:
     # deepsort_tracker.py:126-141
     def output_tuples(self):
         out = []
-        for t in self.tracks:
+        self.last_output_float = []            # the four fp32 coordinates BEFORE int(round(.)), same order: what a test needs to tell a
+        for t in self.tracks:                  # legitimate one-pixel flip (coordinate on a rounding edge) from a wrong box
             if t.state == CONFIRMED and t.time_since_update == 0:
                 x1, y1, w, h = t.to_tlwh()
                 w, h = max(0, w), max(0, h)
                 out.append((int(round(x1)), int(round(y1)), int(round(x1 + w)), int(round(y1 + h)),
                             t.track_id, t.class_name, float(t.confidence)))
+                self.last_output_float.append((float(x1), float(y1), float(x1 + w), float(y1 + h)))
         return out
 
 

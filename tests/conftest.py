@@ -47,3 +47,48 @@ def gpu(lib):
     if lib.device_count() < 1:
         pytest.skip("no GPU")
     return 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Integer output rows (deepsort_tracker.py:135-140: int(round(x)) of fp32 coordinates).  The HIP Kalman arithmetic agrees with the
+# reference's to 1e-3 (different summation order inside the 4x4 solves), so a coordinate whose fp32 value lies within that distance of
+# k + 0.5 may legitimately round the other way.  Everything else must be EQUAL: a differing pixel is accepted only if the reference's
+# own pre-rounding coordinate sits on such an edge, and every accepted pixel is counted.
+EDGE_TOL = 2e-3           # |hip - ref| < 1e-3 on the mean (asserted by the callers); a corner is centre -/+ half an extent
+EDGE_STATS = {"coords": 0, "flipped": 0}
+
+
+def assert_rows_equal_or_on_rounding_edge(got, exp, exp_float, where=""):
+    """got / exp: integer [n, 4] pixel boxes; exp_float: the reference's [n, 4] coordinates before rounding."""
+    got, exp = np.asarray(got, np.int64).reshape(-1, 4), np.asarray(exp, np.int64).reshape(-1, 4)
+    ef = np.asarray(exp_float, np.float64).reshape(-1, 4)
+    assert got.shape == exp.shape == ef.shape, (where, got.shape, exp.shape, ef.shape)
+    EDGE_STATS["coords"] += got.size
+    d = got != exp
+    if not d.any():
+        return 0
+    assert (np.abs(got - exp)[d] == 1).all(), (where, got[d], exp[d])
+    edge = np.minimum(got, exp)[d] + 0.5
+    off = np.abs(ef[d] - edge)
+    assert (off <= EDGE_TOL).all(), (where, "pixel differs although the reference coordinate is not on a rounding edge", got[d], exp[d], ef[d])
+    EDGE_STATS["flipped"] += int(d.sum())
+    return int(d.sum())
+
+
+def fixture_float_rows(g, f, oracle):
+    """Pre-rounding coordinates of the reference fixture's output rows of frame f (tests/golden/traj*.npz hold the tracks' means)."""
+    no, nt = int(g["n_out"][f]), int(g["n_tracks"][f])
+    tids = g["tid"][f, :nt].tolist()
+    out = []
+    for k in range(no):
+        m = g["mean"][f, tids.index(int(g["out"][f, k, 4]))]
+        x1, y1, w, h = oracle.mean_to_tlwh(m)
+        w, h = max(0, w), max(0, h)
+        out.append((float(x1), float(y1), float(x1 + w), float(y1 + h)))
+    return np.array(out, np.float64).reshape(-1, 4)
+
+
+def pytest_terminal_summary(terminalreporter):
+    if EDGE_STATS["coords"]:
+        terminalreporter.write_line(f"integer output rows: {EDGE_STATS['coords']} pixel coordinates compared with the reference's, "
+                                    f"{EDGE_STATS['flipped']} differ by one pixel, each within {EDGE_TOL} of a rounding edge; the rest are equal")

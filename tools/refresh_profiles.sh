@@ -8,7 +8,7 @@ R=$PWD
 TAG=${1:-r03}
 O=$R/gpurun_out/refresh_$TAG
 rm -rf $O && mkdir -p $O
-B="--cpu-frames 0 --no-curve --no-own"     # the traces describe the headline workload only
+B="--cpu-frames 0 --no-curve --no-own --no-plugin"     # the traces describe the headline workload only
 cd /tmp && export TMPDIR=/tmp
 # the bench command itself (from-host span) under the kernel trace: its conv durations must agree with the HIP-event figure of the bench line
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py $B > $O/bench_under_rocprof.json 2> $O/trace.log
