@@ -527,7 +527,16 @@ static void launch_dma(const ConvArgs& a, hipStream_t s) {
 template <typename T, int MT, int NT, int WM, int WN>
 static void launch_variant(const ConvArgs& a, hipStream_t s) {
     if (conv_impl() == 2) {
-        launch_dma<T, MT, NT, WM, WN, 4>(a, s);
+        // ring depth by K: a layer whose whole K is 2 .. 6 steps (YOLOv8n's 1x1 convs: K = 64 .. 192) gains nothing from a 4-deep ring, and
+        // the LDS it costs halves the blocks a CU holds (80 KB per 256 x 64 tile: 2 blocks; 2 stages: 40 KB, 4 blocks).  AICAM_DMA_NSTAGE=n
+        // forces a depth (A/B), AICAM_DMA_NS_K=k sets the largest K-step count that takes the shallow ring
+        static const int force = [] { const char* e = getenv("AICAM_DMA_NSTAGE"); return e ? atoi(e) : 0; }();
+        static const int ns_k = [] { const char* e = getenv("AICAM_DMA_NS_K"); return e ? atoi(e) : 0; }();
+        const int nsteps = a.Kp / (sizeof(T) == 2 ? 32 : 16);
+        const int ns = force ? force : (nsteps <= ns_k ? 2 : 4);
+        if (ns == 2) launch_dma<T, MT, NT, WM, WN, 2>(a, s);
+        else if (ns == 3) launch_dma<T, MT, NT, WM, WN, 3>(a, s);
+        else launch_dma<T, MT, NT, WM, WN, 4>(a, s);
         return;
     }
     constexpr int BM = WM * MT * 16, BN = WN * NT * 16;

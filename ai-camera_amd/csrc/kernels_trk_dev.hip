@@ -217,8 +217,10 @@ struct Lds {                        // carved out of the dynamic LDS block by ld
     // track table (SoA), list order
     int *id, *state, *hits, *age, *tsu, *cls, *slot, *glen, *ghead, *sm, *napp, *glen0;
     float* conf;
-    unsigned short* newrow;         // [TMAX][TRK_KMAX] epoch rows appended to the track in this epoch
+    unsigned short* newrow;         // [TMAX][ks] epoch rows appended to the track in this epoch
+    int ks;                         // ... ks = frames of THIS epoch (<= TRK_KMAX): 16 KB instead of 32 at the default epoch length
     int *mdet;                      // [TMAX] matched detection of the frame or -1
+    int *feas;                      // [TMAX] 1: the track has a detection inside both gates in this frame (its row of the cascade's sub-matrix is not all clamp)
     float* tbox;                    // [TMAX][4] tlwh of the updated state (outputs)
     int* free_slots;                // [cap]
     // detections of the frame
@@ -237,19 +239,20 @@ struct Lds {                        // carved out of the dynamic LDS block by ld
 
 constexpr int KF_SLOTS = 96;        // slots are handed out lowest first, so live tracks sit here unless > 96 are alive
 
-__device__ __forceinline__ Lds lds_carve(char* base, int cap, int nmax, int total_bytes) {
+__device__ __forceinline__ Lds lds_carve(char* base, int cap, int nmax, int total_bytes, int ks = TRK_KMAX) {
     Lds L;
     char* p = base;
     auto take = [&](size_t bytes) { char* q = p; p += (bytes + 15) & ~(size_t)15; return q; };
     const size_t tc = (size_t)cap, mx = (size_t)max(cap, nmax);     // table rows; side of the largest assignment problem
     L.u = (double*)take(8 * mx); L.v = (double*)take(8 * mx); L.dist = (double*)take(8 * mx);
-    int** ti[] = {&L.id, &L.state, &L.hits, &L.age, &L.tsu, &L.cls, &L.slot, &L.glen, &L.ghead, &L.sm, &L.napp, &L.glen0, &L.mdet, &L.rows};
+    int** ti[] = {&L.id, &L.state, &L.hits, &L.age, &L.tsu, &L.cls, &L.slot, &L.glen, &L.ghead, &L.sm, &L.napp, &L.glen0, &L.mdet, &L.rows, &L.feas};
     for (auto a : ti) *a = (int*)take(4 * tc);
     int** li[] = {&L.pred, &L.rowof, &L.colof, &L.todo, &L.pos, &L.asg};
     for (auto a : li) *a = (int*)take(4 * mx);
     L.conf = (float*)take(4 * tc);
     L.tbox = (float*)take(16 * tc);
-    L.newrow = (unsigned short*)take(2 * tc * TRK_KMAX);
+    L.ks = ks;
+    L.newrow = (unsigned short*)take(2 * tc * (size_t)ks);
     L.free_slots = (int*)take(4 * tc);
     L.kf = (float*)take(4 * 72 * (size_t)KF_SLOTS);
     L.tlwh = (float*)take(16 * (size_t)nmax); L.xyah = (float*)take(16 * (size_t)nmax); L.dconf = (float*)take(4 * (size_t)nmax);
@@ -340,7 +343,7 @@ __device__ __forceinline__ double wave_min_f64(double x) {
 //   (3) dual update and back-tracking along pred[] in the reference's order and fp64 operation order.
 // cm: nr x nc fp32 (LDS or global), solved transposed when nr > nc (lsap.cpp:113-123).  Result asg[orig row] = orig column or -1.
 // Returns false when no finite completion exists (cannot happen for the clamped matrices of min_cost_matching).
-__device__ bool lsap_wave(const float* cm, int nr, int nc, const Lds& L, int lane) {
+__device__ __noinline__ bool lsap_wave(const float* cm, int nr, int nc, const Lds& L, int lane) {
     const bool tall = nr > nc;
     const int R = tall ? nc : nr, C = tall ? nr : nc;
     const double inf = __longlong_as_double(0x7ff0000000000000ll);
@@ -431,7 +434,8 @@ __device__ __forceinline__ double readlane_f64(double x, int l) {
 // The same algorithm with max(nr, nc) <= 64: lane j IS column j (dist, v, pred, row_of_col, list position in registers), lane i
 // IS row i (u, col_of_row); the list of unscanned columns is only its inverse pos[] (the lane whose pos == p sits at list
 // position p).  LDS is touched for the cost entries alone.
-__device__ bool lsap_wave64(const float* cm, int nr, int nc, const Lds& L, int lane) {
+__device__ __noinline__ bool lsap_wave64(const float* cm, int nr, int nc, const Lds& L, int lane, int ld = 0) {
+    if (ld == 0) ld = nc;                                         // row pitch of cm (the wave cascade pads it to an odd number of words)
     const bool tall = nr > nc;
     const int R = tall ? nc : nr, C = tall ? nr : nc;
     const double inf = __longlong_as_double(0x7ff0000000000000ll);
@@ -446,7 +450,7 @@ __device__ bool lsap_wave64(const float* cm, int nr, int nc, const Lds& L, int l
         while (sink < 0) {
             const double ui = readlane_f64(u, i);
             if (pos >= 0) {
-                const float cij = tall ? cm[lane * nc + i] : cm[i * nc + lane];
+                const float cij = tall ? cm[lane * ld + i] : cm[i * ld + lane];
                 const double red = ((base + (double)cij) - ui) - v;
                 if (red < dist) { dist = red; pred = i; }
             }
@@ -508,7 +512,7 @@ __device__ bool lsap_wave64(const float* cm, int nr, int nc, const Lds& L, int l
 // Register-resident form for up to 64 * CPL columns: lane l holds columns l, l + 64, ... (and rows likewise).  Same algorithm and
 // tie rules as lsap_wave64 (CPL = 1 compiles to it); every register array is indexed by unrolled constants only.
 template <int CPL>
-__device__ bool lsap_wave_reg(const float* cm, int nr, int nc, const Lds& L, int lane) {
+__device__ __noinline__ bool lsap_wave_reg(const float* cm, int nr, int nc, const Lds& L, int lane) {
     const bool tall = nr > nc;
     const int R = tall ? nc : nr, C = tall ? nr : nc;
     const double inf = __longlong_as_double(0x7ff0000000000000ll);
@@ -651,7 +655,14 @@ namespace {
 //   stage 1: sub[r][c] = maha > chi2 ? INFTY : app (linear_assignment.py:187-210), threshold max_cos
 //   stage 2: sub[r][c] = iou, threshold max_iou
 // Matched pairs are entered into mdet / mtrk. *err != 0 on an LSAP failure.
-struct FrameCosts { const float* app; const float* maha; const float* iou; float* sub_lds; int sub_floats; };
+// Two forms.  FULL: the three [T, n] matrices (app, maha, iou).  LEAN (gated != NULL): ONE [T, n] matrix, the appearance cost behind the
+// Mahalanobis gate (maha > chi2 ? INFTY : app -- what stage 1 reads, linear_assignment.py:187-210), and the IoU cost of a pair worked out
+// where stage 2 asks for it (iou_pair: the expressions of the cost phase, so the same bits): a third of the LDS, which is what decides
+// whether a frame's costs stay on the CU at all (T * n <= ~12 k instead of ~3 k entries beside the 512-track table).
+struct FrameCosts { const float* app; const float* maha; const float* iou; float* sub_lds; int sub_floats; const float* gated; const float* mean_hbm; };
+
+// 1 - IoU of track t's predicted box and detection j (matching.py:13-106 with track.py:133-151), as the cost phase computes it
+__device__ __forceinline__ float iou_pair(const Lds& L, const float* mean_hbm, int t, int j);
 
 // The assignment read off the sub-matrix when it is the ONLY optimum (block-wide; true = matches entered, nothing left to do).
 // Take the short side's lines (rows when nr <= nc, else columns): R lines of C entries, every line must be assigned, to distinct
@@ -742,7 +753,9 @@ __device__ void match_block(const Lds& L, const EpochArgs& a, const FrameCosts& 
     for (int e = threadIdx.x; e < nr * nc; e += BT) {
         const int r = e / nc, c = e - r * nc;
         const size_t kk = (size_t)L.rows[r] * n + cols[c];
-        float x = stage2 ? iou[kk] : (maha[kk] > kChi2_4 ? kInfty : app[kk]);
+        float x;
+        if (stage2) x = iou ? iou[kk] : iou_pair(L, fc.mean_hbm, L.rows[r], cols[c]);
+        else x = fc.gated ? fc.gated[kk] : (maha[kk] > kChi2_4 ? kInfty : app[kk]);
         if (x > maxd) x = clamp;                                  // linear_assignment.py:58
         sub[e] = x;
     }
@@ -775,6 +788,161 @@ __device__ void match_block(const Lds& L, const EpochArgs& a, const FrameCosts& 
     __syncthreads();
 }
 
+__device__ __forceinline__ float iou_pair(const Lds& L, const float* mean_hbm, int t, int j) {
+    const int slot = L.slot[t];
+    const float* m = slot < KF_SLOTS ? L.kf + slot * 72 + 64 : mean_hbm + (size_t)slot * 8;
+    const float m0 = m[0], m1 = m[1], m2 = m[2], m3 = m[3];
+    float bw = 0.f, bh = m3;
+    if (bh > 0.f) bw = m2 * bh; else bh = fmaxf(0.f, bh);
+    const float bx = m0 - bw / 2.0f, by = m1 - bh / 2.0f;
+    const float brx = bx + bw, bry = by + bh;
+    const float* c = L.tlwh + j * 4;
+    const float crx = c[0] + c[2], cry = c[1] + c[3];
+    const float iw = fmaxf(0.f, fminf(brx, crx) - fmaxf(bx, c[0]));
+    const float ih = fmaxf(0.f, fminf(bry, cry) - fmaxf(by, c[1]));
+    const float inter = iw * ih;
+    const float uni = bw * bh + c[2] * c[3] - inter;
+    return 1.0f - inter / fmaxf(uni, 1e-7f);
+}
+
+typedef __attribute__((address_space(3))) const float lds_cfloat;
+typedef __attribute__((address_space(3))) float lds_float;
+typedef __attribute__((address_space(3))) const int lds_cint;
+
+// unique_optimum for ONE wavefront, straight off the frame's gated matrix G (LDS, [T, n]): rows = L.rows[0 .. nr), columns =
+// L.und[0 .. nc), both <= 64.  K = 64 / lines lanes (a power of two) share a line: each scans every K-th entry -- smallest entry, its place,
+// the runner-up -- eight entries in flight at a time (one wave: nothing else hides an LDS round trip), and the K partial results meet by
+// xor-shuffles.  "The line's minimum is strict, and it is here" is what the block form's ordered scan answers too.
+__device__ bool unique_wave(const Lds& L, lds_cfloat* G, int n, int nr, int nc, float maxd, float clamp, bool by_cols) {
+    const int lane = threadIdx.x;
+    const bool tall = nr > nc || (by_cols && nr == nc);          // tall: the columns are the lines
+    const int R = tall ? nc : nr, C = tall ? nr : nc;
+    int lgk = 0;
+    while ((R << (lgk + 1)) <= 64) ++lgk;
+    const int K = 1 << lgk, line = lane >> lgk, seg = lane & (K - 1);
+    lds_cint* und = (lds_cint*)L.und;
+    lds_cint* rows = (lds_cint*)L.rows;
+    int* cnt = L.pred;
+    if (lane < C) cnt[lane] = 0;
+    const int ln = min(line, R - 1);
+    const int fixed = tall ? und[ln] : rows[ln] * n;              // the line's column / its row offset
+    float m1 = __builtin_inff(), m2 = __builtin_inff();
+    int arg = 0;
+    for (int c0 = seg; c0 < C; c0 += 8 * K) {
+        int idx[8];
+        float x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) idx[u] = tall ? rows[min(c0 + u * K, C - 1)] : und[min(c0 + u * K, C - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = tall ? G[idx[u] * n + fixed] : G[fixed + idx[u]];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            float xv = x[u];
+            if (xv > maxd) xv = clamp;                            // linear_assignment.py:58
+            if (c0 + u * K >= C) xv = __builtin_inff();
+            if (xv < m1) { m2 = m1; m1 = xv; arg = c0 + u * K; }
+            else if (xv < m2) m2 = xv;
+        }
+    }
+    for (int o = 1; o < K; o <<= 1) {                             // the K lanes of a line are neighbours: both sides end with the same triple
+        const float p1 = __shfl_xor(m1, o), p2 = __shfl_xor(m2, o);
+        const int pa = __shfl_xor(arg, o);
+        if (p1 < m1) { m2 = fminf(m1, p2); m1 = p1; arg = pa; }
+        else m2 = fminf(m2, p1);                                  // (p1 == m1: the minimum is not strict)
+    }
+    wave_lds_sync();
+    const bool live = seg == 0 && line < R && m1 <= maxd;
+    if (live) atomicAdd(&cnt[arg], 1);
+    wave_lds_sync();
+    const bool ok = !live || (m1 < m2 && cnt[arg] == 1);
+    if (__ballot(!ok)) return false;
+    if (live) {
+        const int t = tall ? L.rows[arg] : L.rows[line];
+        const int dj = tall ? fixed : L.und[arg];
+        L.mdet[t] = dj;
+        L.mtrk[dj] = t;
+    }
+    wave_lds_sync();
+    return true;
+}
+
+// The cascade's levels on ONE wavefront (wave 0 of the block; the others wait at the caller's barrier), for frames with at most 64
+// detections whose gated matrix is in LDS: level search, row list, unique-optimum checks straight off the matrix, (rarely) sub-matrix +
+// the one-wavefront LSAP, and the list of unmatched detections -- all without a block barrier.  A level costs the block form eleven of
+// them (~13 k shader cycles whatever its size), and a scene that keeps a hundred stale confirmed tracks alive walks twenty levels per
+// frame.  Same lists in the same order, same entries, same predicate, same LSAP as the block form.  Stops at a level with more than 64
+// tracks (or whose sub-matrix does not fit): the caller's block loop goes on from `cur`.  done = 1: the cascade is through.
+__device__ void cascade_wave(const Lds& L, const EpochArgs& a, const FrameCosts& fc, int T, int n, int& cur, int& nund, int& done, int* err) {
+    const int lane = threadIdx.x;
+    const float maxd = a.prm.max_cos, clamp = a.prm.clamp_cos;
+    lds_cfloat* G = (lds_cfloat*)fc.gated;
+    int ud = lane < nund ? L.und[lane] : 0;
+    done = 0;
+    for (;;) {
+        if (nund == 0) { done = 1; break; }
+        unsigned lvk = 0xffffffffu;
+        for (int t = lane; t < T; t += 64)
+            if (L.state[t] == 2 && L.tsu[t] > cur && L.tsu[t] <= a.prm.max_age && L.feas[t]) lvk = min(lvk, (unsigned)L.tsu[t]);
+        const unsigned lv = wave_umin32(lvk);
+        SUBPH(a.prof, 0);
+        if (lv == 0xffffffffu) { done = 1; break; }
+        int nr = 0, myrow = 0;
+        for (int t0 = 0; t0 < T; t0 += 64) {                       // the level's tracks in list order (block_compact's order)
+            const int t = t0 + lane;
+            const bool fl = t < T && L.state[t] == 2 && L.tsu[t] == (int)lv;
+            const unsigned long long bal = __ballot(fl);
+            if (fl) {
+                const int p = nr + __popcll(bal & ((1ull << lane) - 1ull));
+                if (p < 64) L.rows[p] = t;
+            }
+            nr += __popcll(bal);
+        }
+        const int nc = nund, ld = nc | 1;
+        if (nr > 64 || nr * ld > fc.sub_floats) break;
+        cur = (int)lv;
+        wave_lds_sync();
+        myrow = L.rows[min(lane, nr - 1)];
+        SUBPH(a.prof, 1);
+        const bool solved = !a.prm.no_fast && (unique_wave(L, G, n, nr, nc, maxd, clamp, false) || (nr == nc && unique_wave(L, G, n, nr, nc, maxd, clamp, true)));
+        if (lane == 0) L.wcnt[NW + (solved ? 1 : 2)] += 1;
+        SUBPH(a.prof, 3);
+        if (!solved) {
+            lds_float* sub = (lds_float*)fc.sub_lds;
+            for (int r0 = 0; r0 < nr; r0 += 8) {                    // lane = column; eight rows' entries in flight at a time
+                float x[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) x[u] = G[__builtin_amdgcn_readlane(myrow, min(r0 + u, nr - 1)) * n + ud];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    float xv = x[u];
+                    if (xv > maxd) xv = clamp;                     // linear_assignment.py:58
+                    if (r0 + u < nr && lane < nc) sub[(r0 + u) * ld + lane] = xv;
+                }
+            }
+            wave_lds_sync();
+            SUBPH(a.prof, 2);
+            const bool ok = lsap_wave64(fc.sub_lds, nr, nc, L, lane, ld);
+            if (!ok) { if (lane == 0) *err = 2; break; }
+            if (lane < nr) {
+                const int c = L.asg[lane];
+                if (c >= 0 && fc.sub_lds[lane * ld + c] <= maxd) {   // linear_assignment.py:76
+                    const int dj = L.und[c];
+                    L.mdet[myrow] = dj;
+                    L.mtrk[dj] = myrow;
+                }
+            }
+            wave_lds_sync();
+        }
+        const bool keep = lane < nund && L.mtrk[ud] < 0;           // the detections still unmatched, order kept
+        const unsigned long long bk = __ballot(keep);
+        if (keep) L.und[__popcll(bk & ((1ull << lane) - 1ull))] = ud;
+        nund = __popcll(bk);
+        wave_lds_sync();
+        ud = lane < nund ? L.und[lane] : 0;
+        SUBPH(a.prof, 4);
+    }
+}
+
 // track.py:70-74 as a ring: returns the ring position the new row goes to and advances (glen, ghead)
 __device__ __forceinline__ int ring_push(int& glen, int& ghead, int gmax) {
     int pos;
@@ -797,9 +965,9 @@ __global__ __launch_bounds__(TRK_DEV_TMAX) void trk_epoch_kernel(EpochArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ int s_err;
     long long t_ph = a.prof ? clock64() : 0;
-    const Lds L = lds_carve(smem, a.prm.cap, a.nmax, a.lds_bytes);
+    const Lds L = lds_carve(smem, a.prm.cap, a.nmax, a.lds_bytes, a.k);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int gmax = a.prm.gmax, dim = a.prm.dim;
+    const int gmax = a.prm.gmax, dim = a.prm.dim, KS = L.ks;
     // Kalman state: the low slots live in LDS for the whole epoch, the rest stays in HBM
     auto kP = [&](int slot) -> float* { return slot < KF_SLOTS ? L.kf + slot * 72 : a.cov + (size_t)slot * 64; };
     auto kM = [&](int slot) -> float* { return slot < KF_SLOTS ? L.kf + slot * 72 + 64 : a.mean + (size_t)slot * 8; };
@@ -880,16 +1048,25 @@ __global__ __launch_bounds__(TRK_DEV_TMAX) void trk_epoch_kernel(EpochArgs a) {
         //      min-over-gallery cosine distance (matching.py:144-217) out of the epoch's SM / GRAM tables.
         //      The three [T, n] matrices sit in LDS when they fit beside the assignment sub-matrix, else in HBM scratch.
         const int tn = T * n;
-        const bool cost_lds = !a.out.dbg_tn && 4 * tn <= L.arena_floats;
-        float* c_app = cost_lds ? L.arena : a.scr.cost;
-        float* c_maha = cost_lds ? L.arena + tn : a.scr.cost + (size_t)TRK_DEV_TMAX * TRK_DEV_NMAX;
-        float* c_iou = cost_lds ? L.arena + 2 * tn : a.scr.cost + 2 * (size_t)TRK_DEV_TMAX * TRK_DEV_NMAX;
-        const FrameCosts fc{c_app, c_maha, c_iou, cost_lds ? L.arena + 3 * tn : L.arena, cost_lds ? L.arena_floats - 3 * tn : L.arena_floats};
+        // LEAN form (FrameCosts): one gated [T, n] matrix in LDS, 24 floats of gate data per track beside it while the pairs run, the
+        // assignment sub-matrix in their place afterwards.  Otherwise (debug dumps of the three matrices, or T * n beyond the CU's LDS):
+        // the three full matrices in HBM scratch.
+        const bool cost_lds = !a.out.dbg_tn && T > 0 && n > 0 && tn + 24 * T <= L.arena_floats;
+        float* c_app = cost_lds ? L.arena : a.scr.cost;            // lean: the gated matrix (appearance first, the gate applied in place)
+        float* c_maha = cost_lds ? nullptr : a.scr.cost + (size_t)TRK_DEV_TMAX * TRK_DEV_NMAX;
+        float* c_iou = cost_lds ? nullptr : a.scr.cost + 2 * (size_t)TRK_DEV_TMAX * TRK_DEV_NMAX;
+        const FrameCosts fc{cost_lds ? nullptr : c_app, c_maha, c_iou, cost_lds ? L.arena + tn : L.arena, cost_lds ? L.arena_floats - tn : L.arena_floats,
+                            cost_lds ? c_app : nullptr, a.mean};
         // Gate data of a track (innovation covariance, its Cholesky factor, the predicted box) are the same for all its pairs: ONE THREAD per
         // track works them out -- all tracks at once, 24 floats each in the still unused sub-matrix area -- and the pairs then run one per
         // thread with their appearance loads in flight.  (Before: one WAVE per track, every lane repeating the track's Cholesky: four
         // rounds of ~800 instructions at 30 tracks, 16 k of this phase's 20 k shader cycles.)  Same functions, same operations per value.
-        const bool gate_lds = cost_lds && T > 0 && n > 0 && 24 * T <= fc.sub_floats;
+        const bool gate_lds = cost_lds;
+        // feas[t]: some detection of the frame lies inside both of track t's gates.  A cascade level none of whose tracks has one is a no-op
+        // (every row of its sub-matrix is the clamp value: nothing is accepted at linear_assignment.py:76, the unmatched detections stay as
+        // they are) and is skipped below without its six block barriers; scenes that keep many stale confirmed tracks alive (max_age 70)
+        // walk 20+ such levels per frame.  Set by the pair loop of the gate_lds form; the other form keeps every level (feas = 1).
+        if (tid < T) L.feas[tid] = gate_lds ? 0 : 1;
         if (gate_lds) {
             float* gd = fc.sub_lds;
             if (tid < T) {
@@ -923,7 +1100,7 @@ __global__ __launch_bounds__(TRK_DEV_TMAX) void trk_epoch_kernel(EpochArgs a) {
                     const int erow = erow0 + j;
                     float x[TRK_KMAX + 1];
                     x[TRK_KMAX] = (smr >= 0 && ev < g0) ? a.scr.sm[((size_t)smr * (TRK_KMAX + 1) + ev) * a.dn_pad + erow] : kBig;
-                    const unsigned short* nr_ = L.newrow + t * TRK_KMAX;
+                    const unsigned short* nr_ = L.newrow + t * KS;
 #pragma unroll
                     for (int q = 0; q < TRK_KMAX; ++q) x[q] = q < napp ? a.scr.gram[(size_t)nr_[q] * a.dn_pad + erow] : kBig;
                     float mn = x[TRK_KMAX];
@@ -956,14 +1133,11 @@ __global__ __launch_bounds__(TRK_DEV_TMAX) void trk_epoch_kernel(EpochArgs a) {
                     acc = acc + y[1] * y[1];
                     acc = acc + y[2] * y[2];
                     acc = acc + y[3] * y[3];
-                    c_maha[e] = ok ? acc : __builtin_inff();
-                    const float* c = L.tlwh + j * 4;
-                    const float crx = c[0] + c[2], cry = c[1] + c[3];
-                    const float iw = fmaxf(0.f, fminf(brx, crx) - fmaxf(bx, c[0]));
-                    const float ih = fmaxf(0.f, fminf(bry, cry) - fmaxf(by, c[1]));
-                    const float inter = iw * ih;
-                    const float uni = bw * bh + c[2] * c[3] - inter;
-                    c_iou[e] = 1.0f - inter / fmaxf(uni, 1e-7f);
+                    const float mh = ok ? acc : __builtin_inff();
+                    const float gx = mh > kChi2_4 ? kInfty : c_app[e];     // (this thread wrote c_app[e] above) linear_assignment.py:187-210
+                    c_app[e] = gx;
+                    if (gx <= a.prm.max_cos) L.feas[t] = 1;
+                    (void)bx, (void)by, (void)brx, (void)bry;              // the IoU of a pair is worked out where stage 2 asks for it (iou_pair)
                 }
             }
             if (!gate_lds)
@@ -1009,11 +1183,24 @@ __global__ __launch_bounds__(TRK_DEV_TMAX) void trk_epoch_kernel(EpochArgs a) {
         int nund = n;
         if (T > 0 && n > 0) {
             int cur = 0;
+            bool through = false;
+            if (n <= 64 && fc.gated && !a.prm.no_wave) {           // the levels on one wavefront while they are small (cascade_wave)
+                if (wv == 0) {
+                    int done = 0;
+                    cascade_wave(L, a, fc, T, n, cur, nund, done, &s_err);
+                    if (lane == 0) { L.wcnt[NW + 3] = cur; L.wcnt[NW + 4] = nund; L.wcnt[NW + 5] = done; }
+                }
+                __threadfence_block();
+                __syncthreads();
+                cur = L.wcnt[NW + 3], nund = L.wcnt[NW + 4];
+                through = L.wcnt[NW + 5] != 0 || s_err != 0;
+            }
+            if (!through)
             for (;;) {
                 if (nund == 0) break;
                 const bool conf_t = tid < T && L.state[tid] == 2;
-                const int tv = (conf_t && L.tsu[tid] > cur && L.tsu[tid] <= a.prm.max_age) ? L.tsu[tid] : 0x7fffffff;
-                const int lv = block_min_int(tv, L.wcnt);
+                const int tv = (conf_t && L.tsu[tid] > cur && L.tsu[tid] <= a.prm.max_age && L.feas[tid]) ? L.tsu[tid] : 0x7fffffff;
+                const int lv = block_min_int(tv, L.wcnt);             // the next level that can accept anything
                 SUBPH(a.prof, 0);
                 if (lv == 0x7fffffff) break;
                 cur = lv;
@@ -1051,7 +1238,7 @@ __global__ __launch_bounds__(TRK_DEV_TMAX) void trk_epoch_kernel(EpochArgs a) {
                     L.glen[tid] = gl, L.ghead[tid] = gh;
                     const int na = L.napp[tid];
                     (void)pos;                                     // the ring position is re-derived at the end of the epoch (see there)
-                    L.newrow[tid * TRK_KMAX + na] = (unsigned short)(erow0 + det);
+                    L.newrow[tid * KS + na] = (unsigned short)(erow0 + det);
                     L.napp[tid] = na + 1;
                 }
                 L.hits[tid] += 1;
@@ -1159,7 +1346,7 @@ __global__ __launch_bounds__(TRK_DEV_TMAX) void trk_epoch_kernel(EpochArgs a) {
                 int gl = 0, gh = 0, na = 0;
                 if (L.dhas[det]) {
                     (void)ring_push(gl, gh, gmax);
-                    L.newrow[ti * TRK_KMAX] = (unsigned short)(erow0 + det);
+                    L.newrow[ti * KS] = (unsigned short)(erow0 + det);
                     na = 1;
                 }
                 L.glen[ti] = gl, L.ghead[ti] = gh, L.napp[ti] = na;
@@ -1203,7 +1390,7 @@ __global__ __launch_bounds__(TRK_DEV_TMAX) void trk_epoch_kernel(EpochArgs a) {
                 e_slot = L.slot[s], e_glen = L.glen[s], e_ghead = L.ghead[s], e_sm = L.sm[s], e_napp = L.napp[s], e_g0 = L.glen0[s];
                 e_conf = L.conf[s];
 #pragma unroll
-                for (int q = 0; q < TRK_KMAX; ++q) e_new[q] = L.newrow[s * TRK_KMAX + q];
+                for (int q = 0; q < TRK_KMAX; ++q) e_new[q] = q < KS ? L.newrow[s * KS + q] : (unsigned short)0;
             }
             __syncthreads();
             if (tid < Tk) {
@@ -1211,7 +1398,7 @@ __global__ __launch_bounds__(TRK_DEV_TMAX) void trk_epoch_kernel(EpochArgs a) {
                 L.slot[tid] = e_slot, L.glen[tid] = e_glen, L.ghead[tid] = e_ghead, L.sm[tid] = e_sm, L.napp[tid] = e_napp, L.glen0[tid] = e_g0;
                 L.conf[tid] = e_conf;
 #pragma unroll
-                for (int q = 0; q < TRK_KMAX; ++q) L.newrow[tid * TRK_KMAX + q] = e_new[q];
+                for (int q = 0; q < TRK_KMAX; ++q) if (q < KS) L.newrow[tid * KS + q] = e_new[q];
             }
             T = Tk;
             __syncthreads();
@@ -1252,7 +1439,7 @@ __global__ __launch_bounds__(TRK_DEV_TMAX) void trk_epoch_kernel(EpochArgs a) {
             if (pos >= gmax) pos -= gmax;
             for (int q = 0; q < myn; ++q) {
                 int* e = a.scr.appends + (size_t)(off + q) * 3;
-                e[0] = slot, e[1] = pos, e[2] = L.newrow[tid * TRK_KMAX + q];
+                e[0] = slot, e[1] = pos, e[2] = L.newrow[tid * KS + q];
                 if (++pos == gmax) pos = 0;
             }
         }
@@ -1321,13 +1508,34 @@ __global__ __launch_bounds__(TRK_DEV_TMAX) void trk_cascade_test_kernel(EpochArg
     const int tid = threadIdx.x;
     if (tid == 0) { s_err = 0; L.wcnt[NW + 1] = 0; L.wcnt[NW + 2] = 0; }
     const size_t stride = (size_t)TRK_DEV_TMAX * TRK_DEV_NMAX;
-    const FrameCosts fc{a.scr.cost, a.scr.cost + stride, a.scr.cost + 2 * stride, L.arena, L.arena_floats};
-    if (tid < T) { L.state[tid] = state[tid]; L.tsu[tid] = tsu[tid]; L.mdet[tid] = -1; }
+    // the gated matrix of the epoch kernel's lean form (FrameCosts), built here from the caller's matrices when it fits the LDS, so that
+    // this entry walks the same code as the pipeline: cascade_wave for n <= 64, match_block's gated branch otherwise
+    const int tn = T * n;
+    const bool lean = tn > 0 && tn + 64 * 65 <= L.arena_floats;
+    if (lean)
+        for (int e = tid; e < tn; e += BT) L.arena[e] = a.scr.cost[stride + e] > kChi2_4 ? kInfty : a.scr.cost[e];
+    const FrameCosts fc{a.scr.cost, a.scr.cost + stride, a.scr.cost + 2 * stride, lean ? L.arena + tn : L.arena, lean ? L.arena_floats - tn : L.arena_floats,
+                        lean ? L.arena : nullptr, nullptr};
+    if (tid < T) { L.state[tid] = state[tid]; L.tsu[tid] = tsu[tid]; L.mdet[tid] = -1; L.feas[tid] = 1; }
     if (tid < n) { L.mtrk[tid] = -1; L.und[tid] = tid; }
+    __threadfence_block();
     __syncthreads();
     int nund = n;
     if (T > 0 && n > 0) {
         int cur = 0;
+        bool through = false;
+        if (n <= 64 && fc.gated && !a.prm.no_wave) {               // as in the epoch kernel: the small levels on one wavefront
+            if (tid < 64) {
+                int done = 0;
+                cascade_wave(L, a, fc, T, n, cur, nund, done, &s_err);
+                if (tid == 0) { L.wcnt[NW + 3] = cur; L.wcnt[NW + 4] = nund; L.wcnt[NW + 5] = done; }
+            }
+            __threadfence_block();
+            __syncthreads();
+            cur = L.wcnt[NW + 3], nund = L.wcnt[NW + 4];
+            through = L.wcnt[NW + 5] != 0 || s_err != 0;
+        }
+        if (!through)
         for (;;) {
             if (nund == 0) break;
             const bool conf_t = tid < T && L.state[tid] == 2;

@@ -523,6 +523,7 @@ void Tracker::run_epochs(const EpochDets& dets, const int* h_n, const int* h_d0,
     prm.max_iou = (float)this->prm.max_iou_distance, prm.clamp_iou = (float)(this->prm.max_iou_distance + 1e-5);
     prm.max_age = this->prm.max_age, prm.n_init = this->prm.n_init, prm.gmax = gmax, prm.dim = dim, prm.cap = cap;
     prm.no_fast = lsap_fast ? 0 : 1;
+    prm.no_wave = wave_cascade ? 0 : 1;
     d_costs.ensure((size_t)3 * TRK_DEV_TMAX * TRK_DEV_NMAX);
     d_sub.ensure((size_t)TRK_DEV_TMAX * TRK_DEV_NMAX);
     d_appends.ensure((size_t)3 * TRK_DEV_DNMAX + 4);          // + the list's length (gallery_commit_kernel)
@@ -964,10 +965,12 @@ int aic_tracker_option(aic_tracker* t, const char* key, int value) {
                         "device association needs nn_budget > 0, max_tracks <= 512 and a feature dimension divisible by 4");
             if (!value) t->t.to_host();
             t->t.dev_assoc = value != 0;
+        } else if (k == "wave_cascade") {
+            t->t.wave_cascade = value != 0;
         } else if (k == "lsap_fast") {
             t->t.lsap_fast = value != 0;
         } else if (k == "epoch_frames") {
-            AIC_REQUIRE(value >= 0 && value <= TRK_KMAX, AIC_ERR_INVALID, "epoch_frames must be in 0..32 (0 = default)");
+            AIC_REQUIRE(value >= 0 && value <= TRK_KMAX, AIC_ERR_INVALID, "epoch_frames must be in 0..16 (0 = default)");
             t->t.epoch_frames = value;
         } else AIC_REQUIRE(false, AIC_ERR_INVALID, "unknown tracker option: " + k);
     });
@@ -999,6 +1002,7 @@ int aic_match_cascade_device(int device_id, const float* app, const float* maha,
         prm.max_iou = (float)max_iou_distance, prm.clamp_iou = (float)(max_iou_distance + 1e-5);
         prm.max_age = max_age, prm.n_init = 3, prm.gmax = 1, prm.dim = 0, prm.cap = TRK_DEV_TMAX;
         prm.no_fast = (flags & 2) ? 1 : 0;
+        prm.no_wave = (flags & 4) ? 1 : 0;
         EpochScratch scr{nullptr, nullptr, costs.p, sub.p, nullptr};
         launch_trk_cascade_test(prm, scr, t, n, st.p, ts.p, md.p, md.p + t, flags & 1, s);
         std::vector<int> out(t + 3);

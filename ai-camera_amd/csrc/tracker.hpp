@@ -61,6 +61,7 @@ struct Tracker {
     // ---- association on the device, k frames per launch (kernels_trk_dev.hip): the track table lives in HBM between launches
     bool dev_assoc = false;            // aic_tracker_option("device_assoc"); the pipeline turns it on when dev_capable()
     bool on_device = false;            // the HBM table is the current one; `tracks` / `free_slots` / `next_id` are stale
+    bool wave_cascade = getenv("AICAM_TRK_NOWAVE") == nullptr;  // aic_tracker_option("wave_cascade"): kernels_trk_dev.hip::cascade_wave
     bool lsap_fast = getenv("AICAM_TRK_NOFAST") == nullptr;   // aic_tracker_option("lsap_fast"): unique optima skip the LSAP (kernels_trk_dev.hip::unique_optimum)
     int dev_predicts = 0;              // predict() calls not yet consumed by an update (device path: the epoch kernel predicts)
     DevBuf<char> d_tbl;                // DevTrkHdr | DevTrack[cap] | int free_slots[cap]

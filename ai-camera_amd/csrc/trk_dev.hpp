@@ -2,7 +2,7 @@
 // tracker.cpp / pipeline.cpp (host).  SURVEY.md §8(f)-4; what it replaces per frame: one launch + one stream sync + the host
 // cascade/LSAP/lifecycle of Tracker::update (src/tracker/core/tracker_core.py:51-81,83-177, linear_assignment.py:19-157).
 //
-// An EPOCH is k <= TRK_KMAX (32) consecutive frames of one video stream.  Per epoch two launches, no host round trip:
+// An EPOCH is k <= TRK_KMAX (16) consecutive frames of one video stream.  Per epoch two launches, no host round trip:
 //   trk_epoch_prep_kernel   (many blocks)  every cosine distance the k frames can need, in bulk on the matrix cores:
 //                           SM[t][e][d]  = min over the rows of track t's gallery that are still alive after e evictions
 //                                          (suffix minima in FIFO order) of max(0, 1 - <row, det d>),
@@ -16,7 +16,8 @@
 
 namespace aic {
 
-constexpr int TRK_KMAX = 32;        // frames per epoch (also <= gallery budget: rows appended in an epoch are never evicted in it)
+constexpr int TRK_KMAX = 16;        // frames per epoch (also <= gallery budget: rows appended in an epoch are never evicted in it).  32 until round 4: measured slower than 16
+                                    // at every load, and every per-pair loop of the epoch kernel is unrolled to it (33 loads and registers per pair)
 constexpr int TRK_DEV_TMAX = 512;   // tracks the single-block kernel handles (= its thread count)
 constexpr int TRK_DEV_NMAX = 512;   // detections per frame
 constexpr int TRK_DEV_DNMAX = 2048; // detections per epoch
@@ -40,6 +41,7 @@ struct TrkDevParams {
     float max_cos, clamp_cos, max_iou, clamp_iou;   // fp32 thresholds and clamp values of linear_assignment.py:55-58,76
     int32_t max_age, n_init, gmax, dim, cap;
     int32_t no_fast;                // 1: every assignment problem goes through the LSAP (tests / A-B); 0: unique optima are read off directly
+    int32_t no_wave;                // 1: every cascade level goes through the block-wide form (tests / A-B); 0: frames with <= 64 detections walk their levels on one wavefront
 };
 
 struct EpochDets {                  // detection arrays of one launch group, device memory, rows = crops in frame order

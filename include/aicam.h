@@ -196,7 +196,7 @@ int aic_tracker_destroy(aic_tracker* t);
  * the track table stays in HBM between calls (what the pipeline does k frames per launch); 0 (default for this entry
  * point): cost matrices on the device, cascade/LSAP/lifecycle in host C++.  Same results either way.
  * "lsap_fast" = 0: every assignment problem of the device path goes through the wave LSAP (default 1: unique optima are read
- * off the matrix).  "epoch_frames" = 1..32: frames per epoch launch of the device path (0 = default 16). */
+ * off the matrix).  "epoch_frames" = 1..16: frames per epoch launch of the device path (0 = default 16). */
 int aic_tracker_option(aic_tracker* t, const char* key, int value);
 /* TrackerCore.predict (tracker_core.py:44-49). */
 int aic_tracker_predict(aic_tracker* t);

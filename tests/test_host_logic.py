@@ -172,6 +172,10 @@ def test_no_conv_kernel_spills():
     # epilogue -- are tolerated: the 512 x 128 ping-pong patch kernel sits exactly at its 256-register cap; anything inside a loop shows up as far more)
     bad = {k: r for k, r in hot.items() if r["scratch"] > 16 or r["vgpr_spills"] > 4}
     assert not bad, bad
-    # the rest of the library: only the single-block association kernel holds a small private array
-    others = {k: r["scratch"] for k, r in tab.items() if k not in hot and (r["scratch"] > 64 or r["vgpr_spills"])}
+    # the rest of the library: no spilled registers anywhere.  Scratch: the single-block association kernels call the LSAP variants out of
+    # line (kernels_trk_dev.hip: inlined twice each they pushed the kernel past its 256 registers and every phase ran 2x slower on spills) --
+    # their 400 bytes are the callees' frames and the table handle passed by reference on the rare path, not spills
+    spilled = {k: r["vgpr_spills"] for k, r in tab.items() if k not in hot and r["vgpr_spills"]}
+    assert not spilled, spilled
+    others = {k: r["scratch"] for k, r in tab.items() if k not in hot and r["scratch"] > (512 if re.search(r"trk_epoch_kernel|trk_cascade_test", k) else 64)}
     assert not others, others

@@ -48,13 +48,7 @@ def graph(H, W, cin, cout, k, reps, res, stride=1):
     return g
 
 
-def main():
-    H, W, cin, cout, k = (int(v) for v in sys.argv[1:6])
-    items = int(sys.argv[6]) if len(sys.argv) > 6 else 960
-    reps = int(sys.argv[7]) if len(sys.argv) > 7 else 8
-    res = int(sys.argv[8]) if len(sys.argv) > 8 else 0
-    stride = int(sys.argv[9]) if len(sys.argv) > 9 else 1
-    g = graph(H, W, cin, cout, k, reps, res, stride)
+def conv_ms(g, items, H, W):
     path = f"/tmp/convbench_{os.getpid()}.aicw"
     ef.write_engine(path, g)
     eng = he.HipEngine(path, dtype=os.environ.get("DTYPE", "fp16"), max_items=items, warm_up=False)
@@ -67,11 +61,29 @@ def main():
         eng.reid_infer_np(x)
     dt = time.perf_counter() - t0
     p = L.prof_read(0)["conv_igemm"]
-    n_conv = sum(1 for o in g.ops if o[0] == 1)
-    us = p["ms"] * 1e3 / 5 / n_conv
-    print(f"H{H} W{W} cin{cin} cout{cout} k{k} s{stride} items{items} res{res}: M={items*(H//stride)*(W//stride)} K={cin*k*k}  "
-          f"{p['flops'] / p['ms'] / 1e9:7.1f} TF  (~{us:.1f} us per conv, wall {dt/5*1e3:.2f} ms/iter) env={ {k_: v for k_, v in os.environ.items() if k_.startswith('AICAM')} }")
+    L.call("aic_prof_enable", 0, 0)
+    eng.close()
     os.remove(path)
+    return p["ms"] / 5, p["flops"] / 5, dt / 5
+
+
+def main():
+    H, W, cin, cout, k = (int(v) for v in sys.argv[1:6])
+    items = int(sys.argv[6]) if len(sys.argv) > 6 else 960
+    reps = int(sys.argv[7]) if len(sys.argv) > 7 else 8
+    res = int(sys.argv[8]) if len(sys.argv) > 8 else 0
+    stride = int(sys.argv[9]) if len(sys.argv) > 9 else 1
+    g = graph(H, W, cin, cout, k, reps, res, stride)
+    n_conv = sum(1 for o in g.ops if o[0] == 1)
+    ms, fl, wall = conv_ms(g, items, H, W)
+    us = ms * 1e3 / n_conv
+    extra = ""
+    if os.environ.get("CB_NET"):            # the layer alone: the same graph without the test convs (stem only) subtracted
+        ms0, fl0, _ = conv_ms(graph(H, W, cin, cout, k, 0, 0, stride), items, H, W)
+        n_t = n_conv - 1
+        extra = f"  NET {1e3 * (ms - ms0) / max(n_t, 1):8.1f} us per conv = {(fl - fl0) / max(ms - ms0, 1e-9) / 1e9:7.1f} TF"
+    print(f"H{H} W{W} cin{cin} cout{cout} k{k} s{stride} items{items} res{res}: M={items*(H//stride)*(W//stride)} K={cin*k*k}  "
+          f"{fl / ms / 1e9:7.1f} TF  (~{us:.1f} us per conv, wall {wall*1e3:.2f} ms/iter){extra} env={ {k_: v for k_, v in os.environ.items() if k_.startswith('AICAM')} }")
 
 
 if __name__ == "__main__":
