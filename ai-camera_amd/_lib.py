@@ -120,6 +120,7 @@ _SIGS = {
     "aic_pipeline_counters": (_I, [_P, _P, _P]),
     "aic_pipeline_assoc_frames": (_I, [_P, _P, _P]),
     "aic_pipeline_filter_counters": (_I, [_P, _P, _P, _P]),
+    "aic_pipeline_lane_groups": (_I, [_P, _P]),
     "aic_pipeline_group_embeddings": (_I, [_P, _P, _I, _P, _I, _P, _P, _P]),
     "aic_overlay": (_I, [_I, _P, _I, _I, _I, _P, _I, _P, _I]),
     "aic_prof_enable": (_I, [_I, _I]),

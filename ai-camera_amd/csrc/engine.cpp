@@ -59,6 +59,7 @@ Model::Model(Device& d, const void* blob, size_t nbytes, int dtype_, int max_ite
     AIC_REQUIRE(dtype == AIC_F16 || dtype == AIC_F32, AIC_ERR_INVALID, "dtype must be AIC_F16 or AIC_F32");
     AIC_REQUIRE(max_items > 0, AIC_ERR_INVALID, "max_items must be positive");
     d.use();
+    blob_copy = std::make_shared<const std::vector<char>>(reinterpret_cast<const char*>(blob), reinterpret_cast<const char*>(blob) + nbytes);
     Reader rd{reinterpret_cast<const char*>(blob), nbytes};
     const uint32_t* head = rd.take<uint32_t>(2);
     AIC_REQUIRE(head[0] == 0x57434941u && head[1] == 1u, AIC_ERR_FORMAT, "not an AICW v1 engine file");

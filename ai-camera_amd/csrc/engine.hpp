@@ -2,6 +2,9 @@
 #pragma once
 #include "kernels.hpp"
 
+#include <memory>
+#include <vector>
+
 namespace aic {
 
 enum { OP_CONV = 1, OP_SPPF_POOL = 2, OP_UPSAMPLE2X = 3, OP_MAXPOOL3S2 = 4, OP_AVGPOOL = 5, OP_L2NORM = 6 };
@@ -39,6 +42,9 @@ struct Model {
     DevBuf<int> d_valid;
     DevBuf<char> d_zero;   // zero page for the conv kernel's LDS-DMA
 
+    // the engine file's bytes, kept: the pipeline builds a second instance of the engine (own activation arena, own detector workspace)
+    // for its second lane (pipeline.cpp: small launch groups of two chunk contexts run side by side)
+    std::shared_ptr<const std::vector<char>> blob_copy;
     Model(Device& d, const void* blob, size_t nbytes, int dtype_, int max_items_);
     void* input() { return bufs[0].p; }
     // fp16 ReID engines with the fused stem take NHWC4 crops (8 bytes per pixel: half the crop traffic); whoever fills

@@ -33,7 +33,14 @@ struct FrameDets {
     std::vector<int32_t> cls;
 };
 
+// A LANE = one instance of each engine (activation arena, detector workspace) + the three streams a launch group is issued on.  Lane 0:
+// the caller's engines and the device's streams.  Lane 1 (built on first use): second instances for SMALL launch groups, so that the
+// groups of the two chunk contexts run side by side on the GPU -- a 16-frame group is a chain of ~60 dependent 25-us kernels that keeps
+// the chip 40 % busy; two chains fill the gaps (aic_pipeline_option "dual_lane_frames": largest group that may take lane 1, 0 = off).
+struct Lane { Model* yolo = nullptr; Model* reid = nullptr; hipStream_t s_main = nullptr, s_det = nullptr, s_reid = nullptr; };
+
 struct Chunk {
+    Lane* ln = nullptr;              // the lane this context's current group was issued on
     int frames = 0, first_slot = 0, n_crops = 0;
     bool dev_mode = false;           // this group's association runs on the device (decided when the group is issued)
     bool prev_dev_mode = true;       // ... and the association of the group this context held before (the device filter is chosen from it)
@@ -73,11 +80,18 @@ struct Pipeline {
     DevBuf<uint8_t> ring;
     std::vector<int> inj_count, inj_cls;
     std::vector<float> inj_boxes, inj_conf;
+    Lane lane[2];
+    std::unique_ptr<Model> yolo2, reid2;
+    int dual_max = [] { const char* e = getenv("AICAM_DUAL_MAX"); return e ? atoi(e) : 128; }();   // aic_pipeline_option("dual_lane_frames")
+    long n_lane1_groups = 0;
     static constexpr int NCK = 2;   // launch groups in flight. 4 was measured: the GPU never idles, but the tracker chain then queues behind more conv work (84 -> 106 us/frame) and becomes the bound
     Chunk ck[NCK];
     int dim;
     std::vector<float> last_emb;
     int last_emb_n = 0;
+    bool final_group = true;         // the group being walked is the last one of the call: its last frame's embeddings are read back
+                                     // (aic_pipeline_last_embeddings).  Every group did that until round 4 -- a BLOCKING copy on the consumer
+                                     // thread, queued behind the copy engine's 44 MB frame uploads: ~1.8 ms per 16-frame group
     // host-side wall time (seconds): issuing launch groups, waiting for a group, walking frames through the tracker
     double t_issue = 0, t_wait = 0, t_track = 0;
     long n_frames_done = 0;
@@ -168,6 +182,8 @@ struct Pipeline {
         AIC_REQUIRE(p.batch <= y->max_items, AIC_ERR_CAPACITY, "batch exceeds the YOLO engine's max_items");
         AIC_REQUIRE(p.max_det > 0 && p.max_det <= y->max_det_cap, AIC_ERR_CAPACITY, "max_det out of range");
         dev->use();
+        lane[0] = Lane{y, r, dev->s_main, dev->s_det, dev->s_reid};
+        for (Chunk& c : ck) c.ln = &lane[0];
         geom = letterbox_geometry(p.frame_h, p.frame_w, y->in_h, y->in_w);
         frame_bytes = (size_t)p.frame_h * p.frame_w * 3;
         ring.alloc(frame_bytes * p.ring_frames + 64);     // + slack: the crop kernel's 12-byte tap loads may run past the last frame's last byte
@@ -194,6 +210,7 @@ struct Pipeline {
         }
     }
     ~Pipeline() {
+        for (hipStream_t st : {lane[1].s_main, lane[1].s_det, lane[1].s_reid}) if (st) (void)hipStreamDestroy(st);
         for (auto& e : ev_copy) if (e) (void)hipEventDestroy(e);
         if (s_copy) (void)hipStreamDestroy(s_copy);
         for (Chunk& c : ck) {
@@ -247,39 +264,57 @@ struct Pipeline {
     }
     int cur_group = 0;
 
-    void stage_a(Chunk& c, int slot, int frames, int group_index = 0) {
+    // second instances of both engines + their streams (first small group of a call; the producer thread has not started yet)
+    void ensure_lane1() {
+        if (lane[1].yolo) return;
+        dev->use();
+        const int yi = std::min(yolo->max_items, std::max(dual_max, 1));
+        const int ri = std::min(reid->max_items, std::max(yi * prm.max_persons, 64));
+        yolo2.reset(new Model(*dev, yolo->blob_copy->data(), yolo->blob_copy->size(), yolo->dtype, yi));
+        reid2.reset(new Model(*dev, reid->blob_copy->data(), reid->blob_copy->size(), reid->dtype, ri));
+        Lane l{yolo2.get(), reid2.get(), nullptr, nullptr, nullptr};
+        HIP_CHECK(hipStreamCreateWithFlags(&l.s_main, hipStreamNonBlocking));
+        HIP_CHECK(hipStreamCreateWithFlags(&l.s_det, hipStreamNonBlocking));
+        HIP_CHECK(hipStreamCreateWithFlags(&l.s_reid, hipStreamNonBlocking));
+        HIP_CHECK(hipDeviceSynchronize());                        // (the new arenas' memsets ran on the device's main stream)
+        lane[1] = l;
+    }
+
+    void stage_a(Chunk& c, int slot, int frames, int group_index = 0, int lane_index = 0) {
+        c.ln = &lane[lane_index];
+        if (lane_index) n_lane1_groups += 1;
         cur_group = group_index;
         const double t0 = now();
-        hipStream_t s = dev->s_main;
+        hipStream_t s = c.ln->s_main;
         c.frames = frames, c.first_slot = slot;
         if (host_frames) {   // the reference's span: H2D of the group's frames on the copy stream, under the previous groups' compute
             issue_copies(group_index + COPY_AHEAD);
             HIP_CHECK(hipStreamWaitEvent(s, ev_copy[group_index % NCOPY], 0));
-            if (split_streams) HIP_CHECK(hipStreamWaitEvent(dev->s_reid, ev_copy[group_index % NCOPY], 0));
+            if (split_streams) HIP_CHECK(hipStreamWaitEvent(c.ln->s_reid, ev_copy[group_index % NCOPY], 0));
         }
         const uint8_t* f0 = ring.p + (size_t)slot * frame_bytes;
         if (pipe_times) HIP_CHECK(hipEventRecord(c.t_begin, s));
-        yolo->run_frames(f0, frames, geom, s);
+        c.ln->yolo->run_frames(f0, frames, geom, s);
         // decode + NMS + read-back on the side stream: a few latency-bound blocks that overlap the
         // (CU-filling) ReID launch group instead of serialising the main stream
-        hipStream_t sd = dev->s_det;
+        hipStream_t sd = c.ln->s_det;
         if (pipe_times) HIP_CHECK(hipEventRecord(c.t_yolo, s));
         HIP_CHECK(hipEventRecord(c.ev_yolo, s));
         HIP_CHECK(hipStreamWaitEvent(sd, c.ev_yolo, 0));
-        yolo->decode_nms(frames, prm.conf_thresh, prm.iou_thresh, prm.max_det, &geom, sd);
-        HIP_CHECK(hipMemcpyAsync(c.h_numdets.p, yolo->d_numdets.p, (size_t)frames * 4, hipMemcpyDeviceToHost, sd));
-        HIP_CHECK(hipMemcpyAsync(c.h_detboxes.p, yolo->d_out_boxes_orig.p, (size_t)frames * prm.max_det * 16, hipMemcpyDeviceToHost, sd));
-        HIP_CHECK(hipMemcpyAsync(c.h_scores.p, yolo->d_out_scores.p, (size_t)frames * prm.max_det * 4, hipMemcpyDeviceToHost, sd));
-        HIP_CHECK(hipMemcpyAsync(c.h_labels.p, yolo->d_out_labels.p, (size_t)frames * prm.max_det * 4, hipMemcpyDeviceToHost, sd));
+        c.ln->yolo->decode_nms(frames, prm.conf_thresh, prm.iou_thresh, prm.max_det, &geom, sd);
+        HIP_CHECK(hipMemcpyAsync(c.h_numdets.p, c.ln->yolo->d_numdets.p, (size_t)frames * 4, hipMemcpyDeviceToHost, sd));
+        HIP_CHECK(hipMemcpyAsync(c.h_detboxes.p, c.ln->yolo->d_out_boxes_orig.p, (size_t)frames * prm.max_det * 16, hipMemcpyDeviceToHost, sd));
+        HIP_CHECK(hipMemcpyAsync(c.h_scores.p, c.ln->yolo->d_out_scores.p, (size_t)frames * prm.max_det * 4, hipMemcpyDeviceToHost, sd));
+        HIP_CHECK(hipMemcpyAsync(c.h_labels.p, c.ln->yolo->d_out_labels.p, (size_t)frames * prm.max_det * 4, hipMemcpyDeviceToHost, sd));
         c.filt_dev = false;
         // dev_filter 1 (default): per launch group -- on the device while this context's previous group was associated on the device.  A
         // group associated on the host needs the detection lists and the crop validity on the host anyway (prepare_b rebuilds them on the
         // consumer thread, that mode's critical thread), so the stream-ordered filter only saves a round trip where the association stays
         // on the device too.  The choice reads state the consumer wrote before it released this context: the same frames always take the
         // same path.  dev_filter 2: always on the device.
-        if (!prm.inject && dev_filter && (dev_filter == 2 || c.prev_dev_mode) && !split_streams && reid->dtype == AIC_F16 && getenv("AICAM_NO_FUSE_CROP") == nullptr) {
-            reid->in_pix4 = reid->input_pix4_ok();
-            c.filt_dev = reid->in_pix4;
+        if (!prm.inject && dev_filter && (dev_filter == 2 || c.prev_dev_mode) && !split_streams && c.ln->reid->dtype == AIC_F16 && getenv("AICAM_NO_FUSE_CROP") == nullptr) {
+            c.ln->reid->in_pix4 = c.ln->reid->input_pix4_ok();
+            c.filt_dev = c.ln->reid->in_pix4;
         }
         if (c.filt_dev) {
             stage_a_device_filter(c, f0, frames, s, sd);
@@ -344,25 +379,25 @@ struct Pipeline {
         }
         // crop + ReID on their own stream: in inject mode they do not depend on the detector, and their CU-filling
         // launches backfill the CUs that YOLO's thin layers (50-400 blocks per launch) leave idle
-        hipStream_t sr = split_streams ? dev->s_reid : s;
+        hipStream_t sr = split_streams ? c.ln->s_reid : s;
         if (nc) {
             HIP_CHECK(hipMemcpyAsync(c.d_boxes.p, c.h_boxes.p, (size_t)nc * 16, hipMemcpyHostToDevice, sr));
             HIP_CHECK(hipMemcpyAsync(c.d_frame_of.p, c.h_frame_of.p, (size_t)nc * 4, hipMemcpyHostToDevice, sr));
-            reid->in_pix4 = reid->input_pix4_ok();
+            c.ln->reid->in_pix4 = c.ln->reid->input_pix4_ok();
             static const bool fuse_crop = getenv("AICAM_NO_FUSE_CROP") == nullptr;
-            for (int c0 = 0; c0 < nc; c0 += reid->max_items) {   // more crops than the ReID arena holds: several launch groups, nothing dropped
-                const int k = std::min(reid->max_items, nc - c0);
-                if (fuse_crop && reid->in_pix4) {
+            for (int c0 = 0; c0 < nc; c0 += c.ln->reid->max_items) {   // more crops than the ReID arena holds: several launch groups, nothing dropped
+                const int k = std::min(c.ln->reid->max_items, nc - c0);
+                if (fuse_crop && c.ln->reid->in_pix4) {
                     // crop + resize + normalise inside the ReID stem kernel: the crop tensor (1 GB per 15 360 crops) never exists
-                    reid->crop_src = CropSrc{f0, prm.frame_h, prm.frame_w, c.d_boxes.p + (size_t)c0 * 4, c.d_frame_of.p + c0, c.d_valid.p + c0};
+                    c.ln->reid->crop_src = CropSrc{f0, prm.frame_h, prm.frame_w, c.d_boxes.p + (size_t)c0 * 4, c.d_frame_of.p + c0, c.d_valid.p + c0};
                 } else {
-                    Prof pr(*dev, PROF_CROP, sr, 0, (double)k * reid->in_h * reid->in_w * 19);
-                    launch_crop_resize(f0, prm.frame_h, prm.frame_w, c.d_boxes.p + (size_t)c0 * 4, c.d_frame_of.p + c0, k, nullptr, reid->in_h,
-                                       reid->in_w, reid->in_pix4 ? 2 : 1, reid->dtype, reid->input(), c.d_valid.p + c0, sr, true);
+                    Prof pr(*dev, PROF_CROP, sr, 0, (double)k * c.ln->reid->in_h * c.ln->reid->in_w * 19);
+                    launch_crop_resize(f0, prm.frame_h, prm.frame_w, c.d_boxes.p + (size_t)c0 * 4, c.d_frame_of.p + c0, k, nullptr, c.ln->reid->in_h,
+                                       c.ln->reid->in_w, c.ln->reid->in_pix4 ? 2 : 1, c.ln->reid->dtype, c.ln->reid->input(), c.d_valid.p + c0, sr, true);
                 }
-                reid->run(k, sr);
-                reid->crop_src.frames = nullptr;
-                HIP_CHECK(hipMemcpyAsync(c.d_emb.p + (size_t)c0 * dim, reid->embeddings(), (size_t)k * dim * 4, hipMemcpyDeviceToDevice, sr));
+                c.ln->reid->run(k, sr);
+                c.ln->reid->crop_src.frames = nullptr;
+                HIP_CHECK(hipMemcpyAsync(c.d_emb.p + (size_t)c0 * dim, c.ln->reid->embeddings(), (size_t)k * dim * 4, hipMemcpyDeviceToDevice, sr));
             }
             {   // matching.py:126-130 for every detection of the launch group at once
                 Prof pr(*dev, PROF_TRK, sr, 0, (double)nc * dim * 8);
@@ -397,7 +432,7 @@ struct Pipeline {
             c.f_cap = cap;
         }
         DetFilterArgs fa{};
-        fa.num_dets = yolo->d_numdets.p, fa.boxes = yolo->d_out_boxes_orig.p, fa.scores = yolo->d_out_scores.p, fa.labels = yolo->d_out_labels.p;
+        fa.num_dets = c.ln->yolo->d_numdets.p, fa.boxes = c.ln->yolo->d_out_boxes_orig.p, fa.scores = c.ln->yolo->d_out_scores.p, fa.labels = c.ln->yolo->d_out_labels.p;
         fa.batch = frames, fa.max_det = prm.max_det, fa.min_conf = prm.min_confidence;
         fa.mask[0] = prm.track_class_mask[0], fa.mask[1] = prm.track_class_mask[1];
         fa.cap = c.f_cap, fa.rank = c.d_rank.p, fa.frame_n = c.d_fn.p, fa.frame_d0 = c.d_fd0.p, fa.total = c.d_total.p;
@@ -411,17 +446,17 @@ struct Pipeline {
         HIP_CHECK(hipMemcpyAsync(c.h_total.p, c.d_total.p, 8, hipMemcpyDeviceToHost, sd));
         HIP_CHECK(hipEventRecord(c.ev_det, sd));
         HIP_CHECK(hipStreamWaitEvent(s, c.ev_det, 0));     // the crop list is in HBM: a stream dependency, not a host wait
-        const int bound = std::min(reid->max_items, frames * prm.max_det);
+        const int bound = std::min(c.ln->reid->max_items, frames * prm.max_det);
         c.reid_rows = bound;
         {
             std::lock_guard<std::mutex> lk(reid_mu);
-            reid->in_pix4 = true;
-            reid->crop_src = CropSrc{f0, prm.frame_h, prm.frame_w, c.d_boxes.p, c.d_frame_of.p, c.d_valid.p};
-            reid->n_items_dev = c.d_total.p;
-            reid->run(bound, s);
-            reid->crop_src.frames = nullptr;
-            reid->n_items_dev = nullptr;
-            HIP_CHECK(hipMemcpyAsync(c.d_emb.p, reid->embeddings(), (size_t)bound * dim * 4, hipMemcpyDeviceToDevice, s));
+            c.ln->reid->in_pix4 = true;
+            c.ln->reid->crop_src = CropSrc{f0, prm.frame_h, prm.frame_w, c.d_boxes.p, c.d_frame_of.p, c.d_valid.p};
+            c.ln->reid->n_items_dev = c.d_total.p;
+            c.ln->reid->run(bound, s);
+            c.ln->reid->crop_src.frames = nullptr;
+            c.ln->reid->n_items_dev = nullptr;
+            HIP_CHECK(hipMemcpyAsync(c.d_emb.p, c.ln->reid->embeddings(), (size_t)bound * dim * 4, hipMemcpyDeviceToDevice, s));
         }
         {
             Prof pr(*dev, PROF_TRK, s, 0, (double)bound * dim * 8);
@@ -452,17 +487,17 @@ struct Pipeline {
         }
         c.dev_mode = use_device(n_max, c.tracks_after);
         if (total > c.reid_rows) {             // a crowded group: every surviving detection is embedded (deepsort_tracker.py:104-113), in further rounds
-            hipStream_t s = dev->s_main;
+            hipStream_t s = c.ln->s_main;
             const uint8_t* f0 = ring.p + (size_t)c.first_slot * frame_bytes;
             std::lock_guard<std::mutex> lk(reid_mu);
             dev->use();
-            for (int c0 = c.reid_rows; c0 < total; c0 += reid->max_items) {
-                const int k = std::min(reid->max_items, total - c0);
-                reid->in_pix4 = true;
-                reid->crop_src = CropSrc{f0, prm.frame_h, prm.frame_w, c.d_boxes.p + (size_t)c0 * 4, c.d_frame_of.p + c0, c.d_valid.p + c0};
-                reid->run(k, s);
-                reid->crop_src.frames = nullptr;
-                HIP_CHECK(hipMemcpyAsync(c.d_emb.p + (size_t)c0 * dim, reid->embeddings(), (size_t)k * dim * 4, hipMemcpyDeviceToDevice, s));
+            for (int c0 = c.reid_rows; c0 < total; c0 += c.ln->reid->max_items) {
+                const int k = std::min(c.ln->reid->max_items, total - c0);
+                c.ln->reid->in_pix4 = true;
+                c.ln->reid->crop_src = CropSrc{f0, prm.frame_h, prm.frame_w, c.d_boxes.p + (size_t)c0 * 4, c.d_frame_of.p + c0, c.d_valid.p + c0};
+                c.ln->reid->run(k, s);
+                c.ln->reid->crop_src.frames = nullptr;
+                HIP_CHECK(hipMemcpyAsync(c.d_emb.p + (size_t)c0 * dim, c.ln->reid->embeddings(), (size_t)k * dim * 4, hipMemcpyDeviceToDevice, s));
                 launch_normalize_rows(c.d_emb.p + (size_t)c0 * dim, c.d_emb_n.p + (size_t)c0 * dim, k, dim, s);
                 HIP_CHECK(hipMemcpyAsync(c.h_valid.p + c0, c.d_valid.p + c0, (size_t)k * 4, hipMemcpyDeviceToHost, s));
                 n_overflow_rounds += 1;
@@ -545,10 +580,12 @@ struct Pipeline {
             if (f == c.frames - 1) {
                 trk.finish_outputs();          // also fences the chunk's embedding buffers before the producer reuses them
                 emit(o);
-                last_emb_n = fd.n;
-                last_emb.resize((size_t)fd.n * dim);
-                if (fd.n) {
-                    HIP_CHECK(hipMemcpy(last_emb.data(), c.d_emb.p + (size_t)fd.crop0 * dim, last_emb.size() * 4, hipMemcpyDeviceToHost));
+                if (final_group) {
+                    last_emb_n = fd.n;
+                    last_emb.resize((size_t)fd.n * dim);
+                    if (fd.n) {
+                        HIP_CHECK(hipMemcpy(last_emb.data(), c.d_emb.p + (size_t)fd.crop0 * dim, last_emb.size() * 4, hipMemcpyDeviceToHost));
+                    }
                 }
             }
         }
@@ -613,9 +650,11 @@ struct Pipeline {
             if (det_labels) std::copy(c.h_labels.p + f * md, c.h_labels.p + (f + 1) * md, det_labels + (size_t)o * md);
         }
         const FrameDets& fl = c.dets[c.frames - 1];
-        last_emb_n = fl.n;
-        last_emb.resize((size_t)fl.n * dim);
-        if (fl.n) HIP_CHECK(hipMemcpy(last_emb.data(), c.d_emb.p + (size_t)fl.crop0 * dim, last_emb.size() * 4, hipMemcpyDeviceToHost));
+        if (final_group) {
+            last_emb_n = fl.n;
+            last_emb.resize((size_t)fl.n * dim);
+            if (fl.n) HIP_CHECK(hipMemcpy(last_emb.data(), c.d_emb.p + (size_t)fl.crop0 * dim, last_emb.size() * 4, hipMemcpyDeviceToHost));
+        }
         last_chunk = (int)(&c - &ck[0]);
         t_track += now() - t2;
         n_frames_done += c.frames;
@@ -652,6 +691,17 @@ struct Pipeline {
             }
         }
         const int nchunks = (int)goff.size();
+        // lane of every group: odd groups that are small enough take lane 1 (their context's previous group has been released, and the
+        // other context's group -- on lane 0 or busy elsewhere -- does not share a buffer or a stream with them)
+        std::vector<int> glane(nchunks, 0);
+        if (dual_max > 0 && yolo->blob_copy && reid->blob_copy) {
+            bool any = false;
+            for (int k = 0; k < nchunks; ++k)
+                if ((k & 1) && glen[k] <= std::min(dual_max, yolo->max_items) && glen[k] * prm.max_persons <= reid->max_items) { glane[k] = 1; any = true; }
+            if (any) ensure_lane1();
+            for (int k = 0; k < nchunks; ++k)
+                if (glane[k] && (glen[k] > yolo2->max_items)) glane[k] = 0;
+        }
         group_times.clear();
         submit_t.assign(nchunks, 0.0);
         plan_off = goff, plan_len = glen, plan_slot = slot, copies_issued = 0;
@@ -671,7 +721,7 @@ struct Pipeline {
                         cv.wait(lk, [&] { return k < consumed + NCK; });
                     }
                     submit_t[k] = now();
-                    stage_a(ck[k % NCK], slot + goff[k], glen[k], k);
+                    stage_a(ck[k % NCK], slot + goff[k], glen[k], k, glane[k]);
                     {
                         std::lock_guard<std::mutex> lk(mu);
                         issued = k + 1;
@@ -693,6 +743,7 @@ struct Pipeline {
                     cv.wait(lk, [&] { return issued > k; });
                     if (perr) break;
                 }
+                final_group = k == nchunks - 1;
                 if (ck[k % NCK].filt_dev) prepare_b(ck[k % NCK]);
                 ck[k % NCK].prev_dev_mode = ck[k % NCK].dev_mode;
                 if (ck[k % NCK].dev_mode) {
@@ -958,6 +1009,11 @@ int aic_pipeline_option(aic_pipeline* p, const char* key, int value) {
             AIC_REQUIRE(value >= 0 && value <= 2, AIC_ERR_INVALID, "device_filter: 0 host filter, 1 on the device while the association is, 2 always on the device");
             p->p.dev_filter = value;
         }
+        else if (k == "dual_lane_frames") {
+            AIC_REQUIRE(value >= 0 && value <= 4096, AIC_ERR_INVALID, "dual_lane_frames must be in 0..4096 (0 = one lane; clamped to the engines' max_items)");
+            AIC_REQUIRE(!p->p.lane[1].yolo || value <= p->p.yolo2->max_items, AIC_ERR_INVALID, "dual_lane_frames: the second lane already exists with a smaller arena");
+            p->p.dual_max = value;
+        }
         else if (k == "group_frames") {
             AIC_REQUIRE(value >= 0 && value <= p->p.prm.batch, AIC_ERR_INVALID, "group_frames must be in 0..batch");
             p->p.group_frames = value;
@@ -971,6 +1027,13 @@ int aic_pipeline_counters(aic_pipeline* p, int64_t* grown_groups, int64_t* clipp
         AIC_REQUIRE(p, AIC_ERR_INVALID, "NULL pipeline");
         if (grown_groups) *grown_groups = p->p.n_grow;
         if (clipped_frames) *clipped_frames = p->p.n_rows_clipped;
+    });
+}
+
+int aic_pipeline_lane_groups(aic_pipeline* p, int64_t* lane1_groups) {
+    return guarded([&] {
+        AIC_REQUIRE(p && lane1_groups, AIC_ERR_INVALID, "NULL argument");
+        *lane1_groups = p->p.n_lane1_groups;
     });
 }
 

@@ -228,8 +228,10 @@ class TrackingPipeline:
         L.call("aic_pipeline_assoc_frames", self._h, C.byref(d), C.byref(h))
         fd, fh, fo = C.c_int64(), C.c_int64(), C.c_int64()
         L.call("aic_pipeline_filter_counters", self._h, C.byref(fd), C.byref(fh), C.byref(fo))
+        l1 = C.c_int64()
+        L.call("aic_pipeline_lane_groups", self._h, C.byref(l1))
         return dict(grown_groups=a.value, clipped_frames=b.value, assoc_device_frames=d.value, assoc_host_frames=h.value,
-                    filter_device_groups=fd.value, filter_host_groups=fh.value, reid_overflow_rounds=fo.value)
+                    filter_device_groups=fd.value, filter_host_groups=fh.value, reid_overflow_rounds=fo.value, lane1_groups=l1.value)
 
     def group_embeddings(self):
         """Embeddings of every crop of the most recently finished launch group: (emb [rows, dim], crops_per_frame [frames])."""

@@ -352,8 +352,13 @@ int aic_pipeline_stats(aic_pipeline* p, double* issue_s, double* wait_s, double*
  * tracker's confidence / class filter runs on the device and ReID is sized from a device-side count, 0 = filter on the host.
  * "split_streams": 1 = crop + ReID of a launch group on a stream of their own beside the next group's detector (more frames/s; the
  * kernels of the two streams stretch each other, so per-launch durations no longer describe the kernels), 0 (default) = one stream.
+ * "dual_lane_frames" (default 128): launch groups of at most that many frames alternate between TWO instances of each engine (the second
+ * one built on first use: own activation arena, detector workspace and streams), so that the groups of the two chunk contexts run
+ * side by side -- a small group is a chain of ~60 short dependent kernels that leaves most of the chip idle; 0 = one lane.
  * Same results in every mode. */
 int aic_pipeline_option(aic_pipeline* p, const char* key, int value);
+/* launch groups issued on the second lane since the pipeline was created */
+int aic_pipeline_lane_groups(aic_pipeline* p, int64_t* lane1_groups);
 /* Launch groups whose crop count outgrew the buffers sized from max_persons (handled, not dropped), and frames
  * whose confirmed tracks outnumbered the caller's max_persons rows (n_tracks reports the true count). */
 int aic_pipeline_counters(aic_pipeline* p, int64_t* grown_groups, int64_t* clipped_frames);

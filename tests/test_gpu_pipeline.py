@@ -475,3 +475,47 @@ def test_association_mode_switches_between_launch_groups(gpu, engines):
     a = pipe.tracker_core.export_arrays()
     assert a["track_id"].tolist() == [t.track_id for t in otrk.tracks] and a["hits"].tolist() == [t.hits for t in otrk.tracks]
     pipe.close()
+
+
+@pytest.mark.parametrize("inject", [True, False], ids=["planted", "own_detections"])
+def test_two_lanes_give_the_rows_of_one(gpu, engines, inject):
+    """Small launch groups alternate between two instances of each engine (pipeline.cpp: Lane; aic_pipeline_option "dual_lane_frames"),
+    so that the groups of the two chunk contexts overlap on the GPU.  The second instances are built from the same engine bytes: every
+    output -- track rows, true counts, detector outputs of every frame, the last group's embeddings, the final table -- must equal the
+    one-lane run's bit for bit, with planted boxes and with the detector's own (device filter, bounded ReID round)."""
+    old = set(config.CLASSES_TO_TRACK)
+    if not inject:
+        config.CLASSES_TO_TRACK.clear()
+        config.CLASSES_TO_TRACK.update(config.CLASSES)
+    try:
+        n_frames, batch = 88, 16                                  # five full groups and a tapered tail
+        sc = syn.Scene(seed=17, n_targets=14, gaps=[(3, 20, 33)], births={9: 12})
+        frames = sc.render_batch(0, n_frames)
+        TP = pkg("pipeline").TrackingPipeline
+        out = {}
+        for lanes in (0, 128):
+            pipe = TP(engines[0], engines[1], (720, 1280), batch=batch, ring_frames=n_frames, max_persons=32, dtype="fp16", inject=inject,
+                      **({} if inject else dict(min_confidence=0.93, max_tracks=512)))
+            pipe.option("dual_lane_frames", lanes)
+            pipe.option("split_streams", 1 if inject else 0)
+            pipe.upload(0, frames)
+            if inject:
+                pipe.inject(0, [sc.detections(f)[:3] for f in range(n_frames)])
+            tracks, dets = pipe.run(0, n_frames, want_dets=True)
+            emb, cpf = pipe.group_embeddings()
+            c = pipe.counters()
+            assert (c["lane1_groups"] >= 2) if lanes else (c["lane1_groups"] == 0), c
+            out[lanes] = (tracks, dets, emb.copy(), cpf.copy(), pipe.tracker_core.export_arrays())
+            pipe.close()
+        (ta, da, ea, ca, xa), (tb, db, eb, cb, xb) = out[128], out[0]
+        assert sum(len(r) for r in tb) > 0
+        for f in range(n_frames):
+            assert ta[f] == tb[f], f
+            for u, v in zip(da[f], db[f]):
+                assert np.array_equal(u, v), f
+        assert np.array_equal(ca, cb) and np.array_equal(ea, eb)
+        for key in ("track_id", "state", "hits", "age", "time_since_update", "gallery_len", "mean", "cov"):
+            assert np.array_equal(xa[key], xb[key]), key
+    finally:
+        config.CLASSES_TO_TRACK.clear()
+        config.CLASSES_TO_TRACK.update(old)
