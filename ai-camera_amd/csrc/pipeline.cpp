@@ -134,6 +134,7 @@ struct Pipeline {
         x_cv.notify_all();
     }
     bool taper = getenv("AICAM_NO_TAPER") == nullptr;   // aic_pipeline_option("taper")
+    bool head_ramp = getenv("AICAM_NO_TAPER") == nullptr && getenv("AICAM_NO_RAMP") == nullptr;   // aic_pipeline_option("head_ramp")
     // inject = 0: the tracker's confidence / class filter (deepsort_tracker.py:88-101) runs on the device behind NMS and ReID is
     // launched for a bound with the count read on the device -- no host synchronisation between YOLO and ReID.  0 = the filter on
     // the host (one hipEventSynchronize per launch group on the producer thread); 1 = per launch group (see stage_a); 2 = always on the
@@ -680,6 +681,12 @@ struct Pipeline {
             for (int pass = 0; pass < passes; ++pass) {
                 const bool last = pass == passes - 1;
                 int done = 0;
+                // frames coming from host memory: the call's FIRST group cannot start before its frames have crossed PCIe (512 frames:
+                // 1.4 GB, 25 ms at the 57 GB/s of this pool -- 3 % of a four-step bench call with nothing to hide it under).  The call
+                // therefore opens with a ramp of small groups (gf/16, gf/8, ... gf/2): compute starts after the first 32 frames' copy and
+                // every later copy runs under the group before it.  aic_pipeline_option("head_ramp", 0): off.
+                if (pass == 0 && host_frames && head_ramp && gf >= 64)
+                    for (int g = std::max(16, gf / 16); g < gf && count - done > g + gf; g *= 2) { goff.push_back(done); glen.push_back(g); done += g; }
                 while (count - done > gf) { goff.push_back(done); glen.push_back(gf); done += gf; }
                 int rem = count - done;
                 while (taper && last && rem > 16) {
@@ -1008,6 +1015,9 @@ int aic_pipeline_option(aic_pipeline* p, const char* key, int value) {
         else if (k == "device_filter") {
             AIC_REQUIRE(value >= 0 && value <= 2, AIC_ERR_INVALID, "device_filter: 0 host filter, 1 on the device while the association is, 2 always on the device");
             p->p.dev_filter = value;
+        }
+        else if (k == "head_ramp") {
+            p->p.head_ramp = value != 0;
         }
         else if (k == "dual_lane_frames") {
             AIC_REQUIRE(value >= 0 && value <= 4096, AIC_ERR_INVALID, "dual_lane_frames must be in 0..4096 (0 = one lane; clamped to the engines' max_items)");

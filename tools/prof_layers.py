@@ -35,6 +35,31 @@ def main(d, frames=16, crops=480, top=30, fused_stem=1, fused_yolo_stem=1, fused
     for n, (c, us) in sorted(tot.items(), key=lambda kv: -kv[1][1])[:24]:
         print(f"{n[:42]:42s} {c:7d} {us / 1e3:9.2f} {100 * us / all_us:6.1f} {us / c:8.1f}")
     conv = [r for r in rows if any(k in r["Kernel_Name"] for k in ("conv_igemm", "conv3x3_patch", "conv3x3_pp_patch", "conv3x3_c16", "conv3x3_c64_resident", "conv3x3_c64_block", "c2f16_fused"))]
+    # the conv class over the steady-state middle of the trace: summed kernel durations against the UNION of their intervals (with the class
+    # on two streams -- bench.py's default since round 4 -- the sum counts every overlapped microsecond twice; bench.py's roofline uses
+    # the union, from paired HIP events per stream), and the class's rate over each, from the full launch groups that START in the window
+    if conv:
+        t_lo, t_hi = int(rows[0]["Start_Timestamp"]), max(int(r["End_Timestamp"]) for r in rows)
+        a_, b_ = t_lo + 0.25 * (t_hi - t_lo), t_lo + 0.85 * (t_hi - t_lo)
+        win = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in conv if a_ <= int(r["Start_Timestamp"]) < b_)
+        stems = [r for r in rows if "yolo_stem_fused" in r["Kernel_Name"] and a_ <= int(r["Start_Timestamp"]) < b_]
+        full = max((int(r.get("Grid_Size_X", r.get("Grid_Size", 0))) for r in stems), default=0)
+        n_full = sum(1 for r in stems if int(r.get("Grid_Size_X", r.get("Grid_Size", 0))) == full)
+        if win and n_full:
+            summed = sum(e - b for b, e in win) / 1e3
+            union, lo, hi = 0.0, win[0][0], win[0][1]
+            for b, e in win[1:]:
+                if b > hi:
+                    union += hi - lo
+                    lo, hi = b, e
+                else:
+                    hi = max(hi, e)
+            union = (union + hi - lo) / 1e3
+            gf = 76.046 - 0.088 - 30 * 0.0283      # conv-class GFLOP per frame at the headline configuration (SURVEY 8d minus the two fused 3-channel stems)
+            print(f"\nconv class, middle 60 % of the trace ({n_full} full launch groups of {frames} frames start in it): summed kernel time {summed / 1e3:.1f} ms, "
+                  f"union of the kernels' intervals {union / 1e3:.1f} ms (= {100 * union * 1e3 / (b_ - a_):.1f} % of the window); "
+                  f"per group {summed / n_full / 1e3:.2f} / {union / n_full / 1e3:.2f} ms; class rate over the union ~{n_full * frames * gf / union / 1e3:.0f} TFLOP/s "
+                  f"(over the sum ~{n_full * frames * gf / summed / 1e3:.0f})")
     layers = []
     for name, g, n in (("yolo", ef.build_yolov8("n", calibrate=False), frames), ("reid", ef.build_reid(calibrate=False), crops)):
         for o in g.ops:
