@@ -43,8 +43,10 @@ def main(d, frames=16, crops=480, top=30, fused_stem=1, fused_yolo_stem=1, fused
         a_, b_ = t_lo + 0.25 * (t_hi - t_lo), t_lo + 0.85 * (t_hi - t_lo)
         win = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in conv if a_ <= int(r["Start_Timestamp"]) < b_)
         stems = [r for r in rows if "yolo_stem_fused" in r["Kernel_Name"] and a_ <= int(r["Start_Timestamp"]) < b_]
-        full = max((int(r.get("Grid_Size_X", r.get("Grid_Size", 0))) for r in stems), default=0)
-        n_full = sum(1 for r in stems if int(r.get("Grid_Size_X", r.get("Grid_Size", 0))) == full)
+        grid = lambda r: int(r.get("Grid_Size_X", r.get("Grid_Size", 0)))
+        full = max((grid(r) for r in stems), default=0)
+        n_full = sum(1 for r in stems if grid(r) == full)
+        n_frames = sum(grid(r) for r in stems) * frames / max(full, 1)          # every group that starts in the window, ramp and tail groups too
         if win and n_full:
             summed = sum(e - b for b, e in win) / 1e3
             union, lo, hi = 0.0, win[0][0], win[0][1]
@@ -54,12 +56,11 @@ def main(d, frames=16, crops=480, top=30, fused_stem=1, fused_yolo_stem=1, fused
                     lo, hi = b, e
                 else:
                     hi = max(hi, e)
-            union = (union + hi - lo) / 1e3
+            union = (union + hi - lo) / 1e3                                    # microseconds
             gf = 76.046 - 0.088 - 30 * 0.0283      # conv-class GFLOP per frame at the headline configuration (SURVEY 8d minus the two fused 3-channel stems)
-            print(f"\nconv class, middle 60 % of the trace ({n_full} full launch groups of {frames} frames start in it): summed kernel time {summed / 1e3:.1f} ms, "
-                  f"union of the kernels' intervals {union / 1e3:.1f} ms (= {100 * union * 1e3 / (b_ - a_):.1f} % of the window); "
-                  f"per group {summed / n_full / 1e3:.2f} / {union / n_full / 1e3:.2f} ms; class rate over the union ~{n_full * frames * gf / union / 1e3:.0f} TFLOP/s "
-                  f"(over the sum ~{n_full * frames * gf / summed / 1e3:.0f})")
+            print(f"\nconv class, middle 60 % of the trace (launch groups of {n_frames:.0f} frames start in it, {n_full} of them full {frames}-frame groups): "
+                  f"summed kernel time {summed / 1e3:.1f} ms, union of the kernels' intervals {union / 1e3:.1f} ms; per {frames} frames {summed * frames / n_frames / 1e3:.2f} / "
+                  f"{union * frames / n_frames / 1e3:.2f} ms; class rate over the union ~{n_frames * gf * 1e3 / union:.0f} TFLOP/s (over the sum ~{n_frames * gf * 1e3 / summed:.0f})")
     layers = []
     for name, g, n in (("yolo", ef.build_yolov8("n", calibrate=False), frames), ("reid", ef.build_reid(calibrate=False), crops)):
         for o in g.ops:
