@@ -54,6 +54,7 @@ _SIGS = {
     "aic_device_sync": (_I, [_I]),
     "aic_model_load": (_I, [C.c_char_p, _I, _I, _I, _P]),
     "aic_model_load_mem": (_I, [_P, C.c_size_t, _I, _I, _I, _P]),
+    "aic_model_read_buffer": (_I, [_P, _I, _P, C.c_size_t]),
     "aic_model_destroy": (_I, [_P]),
     "aic_model_info": (_I, [_P, _P, _P, _P, _P, _P, _P, _P]),
     "aic_yolo_infer": (_I, [_P, _P, _I, _I, _F, _F, _I, _P, _P, _P, _P]),

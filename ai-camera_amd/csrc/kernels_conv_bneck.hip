@@ -1,0 +1,231 @@
+// kernels_conv_bneck.hip -- a C2f BOTTLENECK with 32 channels (Ultralytics yolov8.yaml: Bottleneck(c, c, shortcut, k = (3, 3), e = 1.0) inside
+// YOLOv8n's 80 x 80 C2f blocks, layers 4 and 15: m.cv1 3x3 32 -> 32, m.cv2 3x3 32 -> 32, + its input) as ONE kernel:
+//     y = x + SiLU(conv3x3(SiLU(conv3x3(x; W1) + b1); W2) + b2),   fp16 in / fp32 accumulate / fp16 out,
+// x and y channel slices of the C2f's concat buffer (src/trt_utils/trt_engine.py:151-203 executes this inside the TensorRT engine).
+//
+// Why: as two launches the 32-channel intermediate (80 x 80 x 32 x 2 B = 410 KB per frame) goes out to HBM and comes back, and the second
+// conv re-reads the block's input as its residual: 2.05 MB per frame for 0.47 GFLOP, 158 + 202 us per 512-frame launch group at
+// 300-380 TFLOP/s (profiles/r04_conv_layers.txt: 4.c2f.m0 / m1, 15.c2f.m0 -- 1.0 ms per group for the three pairs).  Fused, a block
+// reads its input tile once (halo 2) and writes its output once: 0.82 MB per frame + the halo; the intermediate never leaves the CU.
+//
+// A block (4 waves) owns TH x TW = 8 x 40 output pixels of one image.  LDS, every tensor as PLANES of 8 channels ([plane][pixel] x 16
+// bytes, pixels row-major over the region, plane pitch a multiple of 256 bytes: the layout rule of kernels_conv_c2f.hip):
+//   X  4 planes [12 x 44]  the input tile with halo 2, zeros outside the image
+//   T  4 planes [10 x 42]  m.cv1's output with halo 1, ZERO outside the image (what m.cv2's zero padding sees)
+// 61.4 KB: two blocks per CU.  Weights are A operands held in registers, 18 fragments per conv (9 taps x 2 channel tiles), both convs' sets
+// requested up front.  Pixels are B operands: one aligned 16-byte ds_read per lane and tap, a region's
+// pixels taken 16 at a time in row-major order (a tile of 16 may wrap to the next row: every lane has its own address).
+// K order and bias placement are those of the unfused kernels (conv3x3_patch_kernel, KORD 0: taps in memory order, one 32-channel
+// K-step per tap, bias added after the accumulation, SiLU, fp16 rounding; the shortcut added after the activation,
+// engine_file.RES_ACT_THEN_ADD) and the channel permutation is perm_ch<2>: a lane owns 8 consecutive channels of its pixel.  Measured
+// against the two launches on identical inputs: ~0.1 % of the fp16 outputs one ulp apart (tests/test_gpu_nets.py::test_fused_bottleneck32;
+// AICAM_BNECK_DBG_T=1 also writes the intermediate where the unfused pair keeps it, AICAM_BNECK_MODE=1/2 fuses only the pairs with /
+// without a shortcut).
+#include "conv_common.hpp"
+
+namespace aic {
+
+namespace {
+
+template <int TW> struct BnGeom {
+    static constexpr int TH = 8;
+    static constexpr int XR = TH + 4, XC = TW + 4, TR = TH + 2, TC = TW + 2;
+    static constexpr int PX = (XR * XC * 16 + 255) / 256 * 256, PT = (TR * TC * 16 + 255) / 256 * 256;
+    static constexpr int LDS_X = 0, LDS_T = 4 * PX, LDS_BYTES = LDS_T + 4 * PT;
+    static constexpr int NT_MID = (TR * TC + 15) / 16, NT_OUT = (TH * TW) / 16;
+    static_assert((TH * TW) % 16 == 0, "whole MFMA tiles of output pixels");
+};
+
+}  // namespace
+
+struct BneckArgs {
+    const half_t* x; half_t* y;
+    const half_t *w1, *w2;
+    const float *b1, *b2;
+    int x_cs, x_coff, y_cs, y_coff, H, W, n_img, xcd_map;
+    half_t* dbg_t; int t_cs, t_coff;   // debugging (AICAM_BNECK_DBG_T): the intermediate is ALSO written where the unfused pair keeps it
+    int shortcut;                    // 1: + the block's input after the activation (Bottleneck(shortcut=True): the backbone's C2f blocks); 0: the neck's
+};
+
+template <int TW, bool LEAN>
+__global__ __launch_bounds__(256) void bneck32_fused_kernel(const BneckArgs a, int tiles_x, int tiles_y) {
+    using G = BnGeom<TW>;
+    constexpr int TH = G::TH, XR = G::XR, XC = G::XC, TR = G::TR, TC = G::TC, PX = G::PX, PT = G::PT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, r = lane & 15, q = lane >> 4;
+    int bx = xcd_tile((int)blockIdx.x, (int)gridDim.x, a.xcd_map);
+    const int tx = bx % tiles_x; bx /= tiles_x;
+    const int ty = bx % tiles_y;
+    const int img = bx / tiles_y;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const half_t* xg = a.x + (size_t)img * a.H * a.W * a.x_cs + a.x_coff;
+
+    // ---- S1: input tile with halo 2 -> LDS (four 16-byte channel groups per pixel: consecutive lanes read one pixel's 64 bytes)
+    for (int idx = t; idx < XR * XC * 4; idx += 256) {
+        const int g = idx & 3, p = idx >> 2;
+        const int pr = p / XC, pc = p - pr * XC;
+        const int iy = oy0 - 2 + pr, ix = ox0 - 2 + pc;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
+            v = *reinterpret_cast<const uint4*>(xg + ((size_t)iy * a.W + ix) * a.x_cs + g * 8);
+        *reinterpret_cast<uint4*>(smem + G::LDS_X + g * PX + p * 16) = v;
+    }
+    // weights as A fragments: tap s, channel tile ct -> row perm_row<2>(ct, r), K elements 32 s + 8 q .. + 7 (Kp = 288).  LEAN: one set of
+    // 18 fragments, conv 2's loaded into conv 1's place between the phases (128 registers: four blocks per CU where the LDS allows);
+    // else both sets up front (one L2 round trip under the patch's, 240 registers: two blocks per CU)
+    half8 wf1[9][2], wf2[LEAN ? 1 : 9][2];
+    floatx4 bi1[2], bi2[2];
+    auto load_w = [&](const half_t* w, const float* b, half8 (&wf)[9][2], floatx4 (&bi)[2]) {
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            const size_t ro = (size_t)perm_row<2>(ct, r) * 288 + 8 * q;
+#pragma unroll
+            for (int s = 0; s < 9; ++s) wf[s][ct] = *reinterpret_cast<const half8*>(w + ro + 32 * s);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bi[ct][e] = b[perm_ch<2>(ct, q, e)];
+        }
+    };
+    load_w(a.w1, a.b1, wf1, bi1);
+    if constexpr (!LEAN) load_w(a.w2, a.b2, reinterpret_cast<half8(&)[9][2]>(wf2), bi2);
+    __syncthreads();
+
+    // one 16-pixel tile of a 3x3 conv over a region of row pitch RC (in pixels): nine taps, two channel tiles.  Two tiles are walked
+    // together (four independent accumulator chains: a lone chain of nine dependent MFMAs leaves the matrix pipe idle between links)
+    auto conv2 = [&](const half8 (&wf)[9][2], const char* b0, const char* b1, int RC, floatx4 (&acc)[2][2]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 9; ++s) {
+            const int off = ((s / 3) * RC + s % 3) * 16;
+            const half8 x0 = *reinterpret_cast<const half8*>(b0 + off), x1 = *reinterpret_cast<const half8*>(b1 + off);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[s][0], x0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[s][1], x0, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[s][0], x1, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[s][1], x1, acc[1][1], 0, 0, 0);
+        }
+    };
+
+    // ---- S2: m.cv1 on the (TH + 2) x (TW + 2) region: T = SiLU(W1 * X + b1), zero outside the image
+    for (int t0 = 2 * wv; t0 < G::NT_MID; t0 += 8) {
+        int p[2], pr[2], pc[2];
+        const char* base[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            p[i] = min((t0 + i) * 16 + r, TR * TC - 1);
+            pr[i] = p[i] / TC, pc[i] = p[i] - pr[i] * TC;
+            base[i] = smem + G::LDS_X + q * PX + (pr[i] * XC + pc[i]) * 16;        // top-left tap of this output pixel, plane q
+        }
+        floatx4 acc[2][2];
+        conv2(wf1, base[0], base[1], XC, acc);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const bool inside = (unsigned)(oy0 - 1 + pr[i]) < (unsigned)a.H && (unsigned)(ox0 - 1 + pc[i]) < (unsigned)a.W;
+            half8 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                o[e] = inside ? (half_t)act_fast<1>(acc[i][0][e] + bi1[0][e]) : (half_t)0.f;
+                o[4 + e] = inside ? (half_t)act_fast<1>(acc[i][1][e] + bi1[1][e]) : (half_t)0.f;
+            }
+            const bool live = t0 + i < G::NT_MID && (t0 + i) * 16 + r < TR * TC;
+            if (live) *reinterpret_cast<half8*>(smem + G::LDS_T + q * PT + p[i] * 16) = o;       // perm_ch<2>: channels 8q .. 8q + 7 = plane q
+            if (a.dbg_t && live && inside && pr[i] >= 1 && pr[i] <= TH && pc[i] >= 1 && pc[i] <= TW)
+                *reinterpret_cast<half8*>(a.dbg_t + (((size_t)img * a.H + oy0 - 1 + pr[i]) * a.W + ox0 - 1 + pc[i]) * a.t_cs + a.t_coff + 8 * q) = o;
+        }
+    }
+    if constexpr (LEAN) load_w(a.w2, a.b2, wf1, bi2);               // (conv 1's fragments are dead: same registers)
+    __syncthreads();
+
+    // ---- S3: m.cv2 on the TH x TW outputs (+ the block's input, the shortcut): y = SiLU(W2 * T + b2) (+ x)
+    half_t* yg = a.y + (size_t)img * a.H * a.W * a.y_cs + a.y_coff;
+    for (int t0 = 2 * wv; t0 < G::NT_OUT; t0 += 8) {
+        int p[2], pr[2], pc[2];
+        const char* base[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            p[i] = min((t0 + i) * 16 + r, TH * TW - 1);
+            pr[i] = p[i] / TW, pc[i] = p[i] - pr[i] * TW;
+            base[i] = smem + G::LDS_T + q * PT + (pr[i] * TC + pc[i]) * 16;
+        }
+        floatx4 acc[2][2];
+        if constexpr (LEAN) conv2(wf1, base[0], base[1], TC, acc);
+        else conv2(reinterpret_cast<const half8(&)[9][2]>(wf2), base[0], base[1], TC, acc);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const half8 res = *reinterpret_cast<const half8*>(smem + G::LDS_X + q * PX + ((pr[i] + 2) * XC + pc[i] + 2) * 16);
+            half8 o;
+            if (a.shortcut) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o[e] = (half_t)(act_fast<1>(acc[i][0][e] + bi2[0][e]) + (float)res[e]);
+                    o[4 + e] = (half_t)(act_fast<1>(acc[i][1][e] + bi2[1][e]) + (float)res[4 + e]);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o[e] = (half_t)act_fast<1>(acc[i][0][e] + bi2[0][e]);
+                    o[4 + e] = (half_t)act_fast<1>(acc[i][1][e] + bi2[1][e]);
+                }
+            }
+            if (t0 + i < G::NT_OUT) *reinterpret_cast<half8*>(yg + ((size_t)(oy0 + pr[i]) * a.W + ox0 + pc[i]) * a.y_cs + 8 * q) = o;
+        }
+    }
+}
+
+template <int TW, bool LEAN = false>
+static void launch_bneck32(const BneckArgs& a, hipStream_t s) {
+    using G = BnGeom<TW>;
+    auto kfn = bneck32_fused_kernel<TW, LEAN>;
+    static bool attr = false;
+    if (!attr && G::LDS_BYTES > 64 * 1024) {
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
+        attr = true;
+    }
+    const int tiles_x = a.W / TW, tiles_y = a.H / G::TH;
+    hipLaunchKernelGGL(kfn, dim3(a.n_img * tiles_x * tiles_y), dim3(256), (size_t)G::LDS_BYTES, s, a, tiles_x, tiles_y);
+    KCHECK();
+}
+
+// m.cv1 -> m.cv2 (+ shortcut) of a 32-channel bottleneck wired as engine_file.py's c2f() wires it (c1 reads a slice of the concat buffer,
+// c2 reads c1's output -- nobody else does, the caller checked --, adds c1's input after its activation and writes another slice);
+// false = pattern / geometry not supported, nothing launched.
+bool conv_try_bneck32(const ConvArgs& c1, const ConvArgs& c2, hipStream_t s) {
+    if (getenv("AICAM_NO_BNECK") != nullptr) return false;            // (read per call: a test flips it inside one process)
+    auto three = [](const ConvArgs& c) {
+        return c.KH == 3 && c.KW == 3 && c.stride == 1 && c.pad == 1 && c.Cin == 32 && c.Cout == 32 && c.Kp == 288 && c.act == 1 && !c.out_f32 &&
+               !c.xs && !c.x2 && !c.w_tail && !c.n_dev && !c.bias_init && c.k_order == 0;
+    };
+    if (!three(c1) || !three(c2) || c1.res_mode != 0 || (c2.res_mode != 2 && c2.res_mode != 0)) return false;
+    const int H = c1.H, W = c1.W;
+    for (const ConvArgs* c : {&c1, &c2})
+        if (c->H != H || c->W != W || c->Ho != H || c->Wo != W || c->M != c1.M) return false;
+    if (c2.x != c1.y || c2.x_coff != c1.y_coff || c2.x_cs != c1.y_cs) return false;                   // c2 reads what c1 writes
+    if (c2.res_mode == 2 && (c2.res != c1.x || c2.r_coff != c1.x_coff || c2.r_cs != c1.x_cs)) return false;   // the shortcut is c1's input
+    if (c2.y == c1.y) return false;                                                                    // (the intermediate is never written: it must not be the output)
+    if ((c1.x_cs | c1.x_coff | c2.y_cs | c2.y_coff) % 8) return false;
+    // the output slice must not overlap the input slice: blocks read their neighbours' input pixels (halo) while others already write
+    if (c2.y == c1.x && c2.y_coff < c1.x_coff + 32 && c1.x_coff < c2.y_coff + 32) return false;
+    if (H % 8) return false;
+    BneckArgs a{};
+    a.x = reinterpret_cast<const half_t*>(c1.x), a.y = reinterpret_cast<half_t*>(c2.y);
+    a.w1 = reinterpret_cast<const half_t*>(c1.w), a.w2 = reinterpret_cast<const half_t*>(c2.w);
+    a.b1 = c1.bias, a.b2 = c2.bias;
+    a.x_cs = c1.x_cs, a.x_coff = c1.x_coff, a.y_cs = c2.y_cs, a.y_coff = c2.y_coff, a.H = H, a.W = W;
+    a.n_img = c1.M / (H * W), a.xcd_map = xcd_map_on(), a.shortcut = c2.res_mode == 2 ? 1 : 0;
+    if (getenv("AICAM_BNECK_DBG_T")) { a.dbg_t = reinterpret_cast<half_t*>(c1.y); a.t_cs = c1.y_cs; a.t_coff = c1.y_coff; }
+    if (const char* e = getenv("AICAM_BNECK_MODE")) {                 // debugging: 1 = only the pairs with a shortcut, 2 = only those without
+        if ((atoi(e) == 1 && !a.shortcut) || (atoi(e) == 2 && a.shortcut)) return false;
+    }
+    // Measured (tools/yolo_trace.sh, 512 frames at 80 x 80): 8 x 40 tiles 194-198 us per pair against 2 x 116 us for the two launches; 8 x 20 and
+    // 8 x 16 tiles, the 144-register LEAN form (three blocks per CU) and one tile at a time all land within 2 % of that or worse: the
+    // kernel is bound by instruction issue -- SiLU of 23.7 k activations per block (two 8-cycle transcendentals each) beside 846 MFMAs and
+    // 440 ds_read_b128 -- not by residency, and the fusion's HBM saving buys 17 %, not the 2x the byte count suggests.
+    if (W % 40 == 0) launch_bneck32<40>(a, s);
+    else if (W % 32 == 0) launch_bneck32<32>(a, s);
+    else if (W % 16 == 0) launch_bneck32<16>(a, s);
+    else return false;
+    return true;
+}
+
+}  // namespace aic

@@ -66,6 +66,10 @@ int aic_device_sync(int device);
 int aic_model_load(const char* path, int device, int dtype, int max_items, aic_model** out);
 int aic_model_load_mem(const void* blob, size_t nbytes, int device, int dtype, int max_items,
                        aic_model** out);
+/* debugging / tests: the first `bytes` bytes of activation buffer `buf` (engine-file buffer index; NHWC, the engine's activation dtype,
+ * items of the last run first) -- what a TensorRT user gets by marking a layer as an output (src/trt_utils/trt_engine.py:62-120 lists
+ * only the marked I/O tensors). */
+int aic_model_read_buffer(aic_model* m, int buf, void* out, size_t bytes);
 int aic_model_destroy(aic_model* m);
 /* kind, input H/W, classes (YOLO) or feature dim (ReID), anchors per image, conv FLOPs per item */
 int aic_model_info(const aic_model* m, int* kind, int* in_h, int* in_w, int* out_dim,

@@ -1,0 +1,8 @@
+#!/bin/bash
+# interleaved A/B of the headline bench under an environment switch: tools/ab_env.sh "AICAM_NO_BNECK=1" [rounds]
+B="--no-curve --no-own --no-plugin --cpu-frames 0"
+for i in $(seq 1 ${2:-3}); do
+for cfg in "X=1" "$1"; do
+  env $cfg python bench.py $B 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$cfg', d['value'], d['roofline']['frac'], d['roofline']['kernel_ms_per_step'])"
+done
+done
