@@ -380,7 +380,7 @@ Model::Model(Device& d, const void* blob, size_t nbytes, int dtype_, int max_ite
     // blocks) as ONE kernel that never writes the intermediate (kernels_conv_bneck.hip).  Marked here when the value the first conv
     // writes has no reader but the second: the bottlenecks of a C2f share one intermediate buffer, each pair rewriting it, so "no other
     // reader of the BUFFER" would refuse them all -- what must hold is that nobody reads it between this pair and its next full rewrite.
-    if (dtype == AIC_F16 && !getenv("AICAM_NO_FUSE") && !getenv("AICAM_NO_BNECK")) {
+    if (dtype == AIC_F16 && !getenv("AICAM_NO_FUSE")) {                 // (conv_try_bneck32 itself is opt-in: AICAM_BNECK=1)
         auto overlap = [](int a0, int an, int b0, int bn) { return a0 < b0 + bn && b0 < a0 + an; };
         for (size_t i = 0; i + 1 < ops.size(); ++i) {
             const int* c = ops[i].v;

@@ -89,7 +89,7 @@ def main(d, frames=16, crops=480, top=30, fused_stem=1, fused_yolo_stem=1, fused
                 merged.append(L)
                 i += 1
         layers = merged
-    if fused_block and not os.environ.get("AICAM_NO_BNECK"):     # a 32-channel C2f bottleneck (m.cv1 + m.cv2, 3x3 32 -> 32 each) is ONE launch of bneck32_fused_kernel
+    if fused_block and os.environ.get("AICAM_BNECK"):     # a 32-channel C2f bottleneck (m.cv1 + m.cv2, 3x3 32 -> 32 each) is ONE launch of bneck32_fused_kernel
         merged = []
         for L in layers:
             if merged and L[0] == "yolo" and L[1].endswith(".cv2") and ".m" in L[1] and merged[-1][1] == L[1][:-1] + "1" and L[3] == 32 and L[4] == 288 and merged[-1][3] == 32:
