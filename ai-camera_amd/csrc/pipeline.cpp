@@ -411,9 +411,18 @@ struct Pipeline {
             HIP_CHECK(hipEventRecord(c.ev_reid, sr));
             HIP_CHECK(hipStreamWaitEvent(s, c.ev_reid, 0));
         }
-        HIP_CHECK(hipStreamWaitEvent(s, c.ev_det, 0));   // join: the next chunk's YOLO reuses the head buffers
-        if (pipe_times) HIP_CHECK(hipEventRecord(c.t_end, s));
-        HIP_CHECK(hipEventRecord(c.done, s));
+        if (prm.inject) {
+            // planted detections: the association needs this group's embeddings (and the detector to be through with the frames), not the
+            // detector's OUTPUTS, which are only returned to the caller -- `done` does not wait for decode + NMS + their read-back on the
+            // side stream (0.45 ms of a 16-frame group's 4.5 ms chain); stage B waits for ev_det on the host where it copies them out
+            if (pipe_times) HIP_CHECK(hipEventRecord(c.t_end, s));
+            HIP_CHECK(hipEventRecord(c.done, s));
+            HIP_CHECK(hipStreamWaitEvent(s, c.ev_det, 0));   // join: this lane's next group reuses the head buffers
+        } else {
+            HIP_CHECK(hipStreamWaitEvent(s, c.ev_det, 0));   // join: the next chunk's YOLO reuses the head buffers
+            if (pipe_times) HIP_CHECK(hipEventRecord(c.t_end, s));
+            HIP_CHECK(hipEventRecord(c.done, s));
+        }
         t_issue += now() - t0;
     }
 
@@ -526,6 +535,7 @@ struct Pipeline {
         const double t0 = now();
         n_assoc_host += c.frames;
         HIP_CHECK(hipEventSynchronize(c.done));
+        HIP_CHECK(hipEventSynchronize(c.ev_det));              // (inject: `done` does not cover the detector's read-back)
         if (pipe_times) {
             float a = 0, b = 0, g = 0;
             (void)hipEventElapsedTime(&a, c.t_begin, c.t_yolo);
@@ -629,6 +639,7 @@ struct Pipeline {
         const double t1 = now();
         t_track += t1 - t0;                                    // host time of the association: planning + launches
         HIP_CHECK(hipStreamSynchronize(s));
+        HIP_CHECK(hipEventSynchronize(c.ev_det));              // the detector's outputs of the group are on the host (inject: `done` did not cover them)
         trk.check_epochs();
         tracks_seen = reinterpret_cast<const DevTrkHdr*>(trk.h_tbl.p)->n_tracks;
         c.tracks_after = tracks_seen;
