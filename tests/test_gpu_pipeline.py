@@ -519,3 +519,40 @@ def test_two_lanes_give_the_rows_of_one(gpu, engines, inject):
     finally:
         config.CLASSES_TO_TRACK.clear()
         config.CLASSES_TO_TRACK.update(old)
+
+
+def test_head_ramp_and_conv_union(gpu, engines):
+    """A from-host call opens with a ramp of small launch groups (pipeline.cpp, aic_pipeline_option "head_ramp"): different launch grouping,
+    same stream -- the rows, counts and detector outputs must be those of the run without the ramp, bit for bit.  Beside it, the profiler's
+    two denominators (aic_prof_read / aic_prof_read_union, bench.py's roofline): with the conv class on two streams the union of its
+    bracketed intervals is shorter than their sum and at least the longest single bracket; on one stream the two agree."""
+    L = pkg("_lib")
+    n_frames, batch = 160, 64
+    sc = syn.Scene(seed=23, n_targets=10)
+    frames = np.ascontiguousarray(sc.render_batch(0, n_frames))
+    TP = pkg("pipeline").TrackingPipeline
+    dets = [sc.detections(f)[:3] for f in range(n_frames)]
+    out, prof = {}, {}
+    for ramp, split in ((1, 1), (0, 1), (0, 0)):
+        pipe = TP(engines[0], engines[1], (720, 1280), batch=batch, ring_frames=n_frames, max_persons=16, dtype="fp16", inject=True)
+        pipe.inject(0, dets)
+        pipe.option("head_ramp", ramp)
+        pipe.option("split_streams", split)
+        pipe.option("dual_lane_frames", 0)
+        L.call("aic_prof_reset", 0)
+        L.call("aic_prof_enable", 0, 1)
+        nt, rows, nd = (x.copy() for x in pipe.run_raw_from_host(frames))
+        prof[(ramp, split)] = L.prof_read(0)["conv_igemm"]
+        L.call("aic_prof_enable", 0, 0)
+        gf, _ = pipe.group_times()
+        out[(ramp, split)] = (nt, rows, nd, gf.tolist())
+        pipe.close()
+    assert out[(1, 1)][3][:2] == [16, 32] and out[(0, 1)][3][0] == batch, (out[(1, 1)][3], out[(0, 1)][3])     # 64 / 16 = 4 -> 16: the ramp's first groups
+    for key in ((0, 1), (0, 0)):
+        for i in range(3):
+            assert np.array_equal(out[(1, 1)][i], out[key][i]), (key, i)
+    assert out[(1, 1)][0].sum() > 0
+    two, one = prof[(0, 1)], prof[(0, 0)]
+    assert 0 < two["ms_union"] <= two["ms"] * 1.0001 and one["ms_union"] > 0
+    assert abs(one["ms_union"] - one["ms"]) <= 0.02 * one["ms"] + 0.05, one           # one stream: brackets do not overlap
+    assert two["flops"] == one["flops"]
