@@ -170,6 +170,10 @@ template <int NT> __device__ __forceinline__ int perm_ch(int j, int q, int e) {
 }
 template <int NT> __device__ __forceinline__ int perm_row(int j, int r) { return perm_ch<NT>(j, r >> 2, r & 3); }
 
+// compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N-1>{})
+template <typename F, int... I> __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
 // fp16 output of whole tile pairs in PHASES, four or eight vectors at a time: their residual vectors are requested first (independent 16-byte
 // loads), then the eight output vectors are formed, then all eight are stored.  Written tile by tile (load -> add -> activate -> store) the compiler reuses
 // one set of data registers for every store and one for every residual and fences each reuse with s_waitcnt vmcnt(0) (stores count
@@ -196,17 +200,37 @@ __device__ __forceinline__ void epilogue_wide_phased(const ConvArgs& a, floatx4 
     }
     const int n_odd = n_base + 16 * (NT - 1) + 4 * q;                       // the odd last tile keeps the identity map: 4 channels per lane
     if constexpr (ODD) b4[NT - 1] = *reinterpret_cast<const floatx4*>(bias + n_odd);
+    // With a residual the passes are software-pipelined: the residual vectors of pass k + 1 are requested BEFORE the stores of pass k are
+    // issued.  Requested after them (the form before), their s_waitcnt had the four stores in front of it in the in-order vmcnt queue: every
+    // pass paid a store acknowledge plus a load round trip, ~2 us x 4 passes -- the 8.4 us a 512 x 128 tile spent here even with its residual
+    // already in the L2 (AICAM_PP_TIMES, conv3x3_pp_patch_kernel's prefetch), against 3.9 us without a residual.
+    half8 rq[2][MC][NP > 0 ? NP : 1];
+    half4 rq4[2][MC];
+    auto request = [&](int i0, auto setc) {                // rows past the end / channels past Cout read a valid address (row 0; the pixel's
+        constexpr int S = decltype(setc)::value;           // last channels) and are never stored
 #pragma unroll
-    for (int i0 = 0; i0 < MT; i0 += MC) {
+        for (int i = 0; i < MC; ++i) {
+            const size_t rbase = (size_t)max(mrow[i0 + i], 0) * a.r_cs + a.r_coff;
+#pragma unroll
+            for (int p = 0; p < NP; ++p) rq[S][i][p] = *reinterpret_cast<const half8*>(rg + rbase + min(n_base + 32 * p + 8 * q, a.Cout - 8));
+            if constexpr (ODD) rq4[S][i] = *reinterpret_cast<const half4*>(rg + rbase + min(n_odd, a.Cout - 4));
+        }
+    };
+    if constexpr (RES != 0) request(0, std::integral_constant<int, 0>{});
+    static_for<MT / MC>([&](auto passc) {
+        constexpr int PASS = decltype(passc)::value, i0 = PASS * MC, S = PASS & 1;
         half8 o[MC][NP > 0 ? NP : 1];
         half4 o4[MC];
-        if constexpr (RES != 0) {                          // rows past the end / channels past Cout read a valid address (row 0; the pixel's
-#pragma unroll                                             // last channels) and are never stored
-            for (int i = 0; i < MC; ++i) {
-                const size_t rbase = (size_t)max(mrow[i0 + i], 0) * a.r_cs + a.r_coff;
+        if constexpr (RES != 0) {
+            if constexpr (PASS + 1 < MT / MC) {
+                request(i0 + MC, std::integral_constant<int, S ^ 1>{});
+                __builtin_amdgcn_sched_barrier(0);         // (the requests stay in front of this pass's arithmetic and stores)
+            }
 #pragma unroll
-                for (int p = 0; p < NP; ++p) o[i][p] = *reinterpret_cast<const half8*>(rg + rbase + min(n_base + 32 * p + 8 * q, a.Cout - 8));
-                if constexpr (ODD) o4[i] = *reinterpret_cast<const half4*>(rg + rbase + min(n_odd, a.Cout - 4));
+            for (int i = 0; i < MC; ++i) {
+#pragma unroll
+                for (int p = 0; p < NP; ++p) o[i][p] = rq[S][i][p];
+                if constexpr (ODD) o4[i] = rq4[S][i];
             }
         }
 #pragma unroll
@@ -260,7 +284,7 @@ __device__ __forceinline__ void epilogue_wide_phased(const ConvArgs& a, floatx4 
                 if (m >= 0 && n_odd < a.Cout) *reinterpret_cast<half4*>(yg + ybase + n_odd) = o4[i];
             }
         }
-    }
+    });
 }
 
 // PHASED: only the 8-wave kernels ask for it.  They run one block per CU whatever their register count; in the 4-wave kernels the
@@ -478,9 +502,6 @@ __device__ __forceinline__ void tail_1x1(const ConvArgs& a, floatx4 (&acc)[MT][N
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-// compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N-1>{})
-template <typename F, int... I> __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
-template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 // Workgroups go to the 8 XCDs round-robin (block b -> XCD b % 8), each with its own L2.  Tiles that are neighbours in the
 // image share halo rows and weights: this bijection gives XCD x one contiguous run of tiles, so a halo fetched by one block is an

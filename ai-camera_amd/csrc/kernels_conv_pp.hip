@@ -330,7 +330,7 @@ __device__ __forceinline__ int lane_here() {
 }
 
 template <typename T, int MT, int NT, int WM, int WN, int TH, int TW, int NSTAGE, bool X2 = false>
-__global__ __launch_bounds__(512) void conv3x3_pp_patch_kernel(const ConvArgs a, int tiles_x, int tiles_y, int ny, int run) {
+__global__ __launch_bounds__(512) void conv3x3_pp_patch_kernel(const ConvArgs a, int tiles_x, int tiles_y, int ny, int run, int pf) {
     constexpr int CH = 16 / (int)sizeof(T);
     constexpr int BKE = 4 * CH;
     constexpr int RP = 128;
@@ -399,6 +399,29 @@ __global__ __launch_bounds__(512) void conv3x3_pp_patch_kernel(const ConvArgs a,
         const T* z = zero;
         asm volatile("" : "+s"(z));                 // the address is copied from its scalar registers here: a vector copy carried through the loop was spilled
         const T* src = z;
+        asm volatile("" : "+v"(src));
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + 2 * PBUF + wv * 1024), 16, 0, 0);
+    };
+    // A residual tile is 128 KB that the epilogue pulls from HBM with nothing left to hide it behind.  Optional (pf != 0, see launch_pp_patch:
+    // measured, no net gain, off): the spare LDS-DMA slots of the tile's LAST chunk (bit `tap` of pf) carry it towards the L2 a few K-steps
+    // ahead: pass k, thread t touches 128-byte line k * 512 + t of the tile's rows, the 16 bytes land in the dummy slot and are never read.
+    // Same instruction count per segment: the counted waits do not change.
+    constexpr int LPP = BN * (int)sizeof(T) / 128 > 0 ? BN * (int)sizeof(T) / 128 : 1, NRP = BM * LPP / 512;
+    auto issue_res = [&](int k) {
+        const int L = k * 512 + wv * 64 + lane_here();
+        const int m = L / LPP, part = L - m * LPP;
+        int il, ly, lx;
+        if constexpr (G == 1) {
+            il = m / TPIX;
+            const int rem = m - il * TPIX;
+            ly = rem / TW, lx = rem - ly * TW;
+        } else {
+            const int tl = m >> 4, rr = m & 15;
+            il = (tl / TH) * G + rr / TW, ly = tl % TH, lx = rr % TW;
+        }
+        const int img = img0 + il;
+        const T* src = (k < NRP && m < BM && img < n_img) ? reinterpret_cast<const T*>(a.res) + (((img * a.Ho + oy0 + ly) * a.Wo + ox0 + lx) * a.r_cs + a.r_coff + n0 + part * (128 / (int)sizeof(T)))
+                                                          : zero;
         asm volatile("" : "+v"(src));
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + 2 * PBUF + wv * 1024), 16, 0, 0);
     };
@@ -557,7 +580,10 @@ __global__ __launch_bounds__(512) void conv3x3_pp_patch_kernel(const ConvArgs a,
             __builtin_amdgcn_sched_barrier(0);
             issue_w();
             if (tap >= 1 && tap <= NPASS && more) issue_patch(tap >= 1 && tap <= NPASS ? tap - 1 : 0, BUF ^ 1, noff, p_im, p_oy, p_ox);
-            else if constexpr (!EP) issue_dummy();
+            else if constexpr (!EP) {
+                if (!X2 && !inner && ((pf >> tap) & 1)) issue_res(__builtin_popcount(pf & ((1 << tap) - 1)));
+                else issue_dummy();
+            }
             if constexpr (EP) {
                 if constexpr (NE == 4) {
                     if (tap == 6) { issue_e(0, c, c < ns2); issue_e(1, c, c < ns2); } else issue_e(tap - 5, c, c < ns2);
@@ -656,8 +682,15 @@ static bool launch_pp_patch(const ConvArgs& a, hipStream_t s) {
         const int on = 1;
         HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_pp_times_on), &on, sizeof(int)));
     }
+    // residual prefetch: taps of the last chunk whose spare LDS-DMA slot carries a pass of the residual tile (AICAM_PPP_PF=0xC0: taps 6 and 7).
+    // OFF by default: measured on the 512 x 128 tile (AICAM_PP_TIMES, one tile per block) it takes 2 us off the epilogue (9.2 -> 7.2 us) and puts
+    // 2.5 us onto the K loop (27.6 -> 30.3 us) -- the pass is a load from HBM in the in-order vmcnt queue, and the next segment's counted wait
+    // stands behind it where it used to stand behind a zero-page hit; layer2 / 3 / 4 conv2 alone: 2 432 / 2 021 / 1 894 us off, 2 452 / 2 019 / 1 889 on
+    static const int pf_env = [] { const char* e = getenv("AICAM_PPP_PF"); return e ? (int)strtol(e, nullptr, 0) : 0; }();
+    constexpr int NPASS_ = NPASS;
+    const int pf = (!X2 && a.res_mode != 0 && a.res && sizeof(T) == 2 && BN * sizeof(T) % 128 == 0) ? (pf_env & 0x1ff & ~(((1 << NPASS_) - 1) << 1)) : 0;
     const int nblk = (int)ceil_div(ntiles, (long)run);
-    hipLaunchKernelGGL(kfn, dim3(nblk), dim3(512), lds, s, a, tiles_x, tiles_y, ny, run);
+    hipLaunchKernelGGL(kfn, dim3(nblk), dim3(512), lds, s, a, tiles_x, tiles_y, ny, run, pf);
     if (times) { KCHECK(); pp_times_report(s, nblk); }
     KCHECK();
     return true;
