@@ -690,7 +690,7 @@ void load_input_nchw(Model& m, const float* images, int n, int mem, hipStream_t 
 
 const uint8_t* stage_frames(Model& m, const uint8_t* frames, size_t bytes, int mem, hipStream_t s) {
     if (mem == AIC_DEVICE) return frames;
-    m.d_frames.ensure(bytes);
+    m.d_frames.ensure(bytes + 16);           // (slack: the fused crop reads aligned 12-byte groups that may end past the last pixel)
     HIP_CHECK(hipMemcpyAsync(m.d_frames.p, frames, bytes, hipMemcpyHostToDevice, s));
     return m.d_frames.p;
 }
@@ -941,12 +941,19 @@ int aic_reid_embed(aic_model* mm, const uint8_t* frame, int h, int w, int mem, c
         m.in_pix4 = m.input_pix4_ok();
         for (int c0 = 0; c0 < n; c0 += m.max_items) {   // launch groups of max_items: every detection is embedded (deepsort_tracker.py:104-113)
             const int k = std::min(m.max_items, n - c0);
-            {
+            static const bool fuse_crop = getenv("AICAM_NO_FUSE_CROP") == nullptr;
+            if (fuse_crop && m.in_pix4 && m.in_h <= 192 && mem != AIC_DEVICE) {
+                // crop + resize + normalise inside the stem kernel, as the pipeline does it (same arithmetic, pixel for pixel): one launch fewer
+                // per call of the per-frame plugin loop, and no crop tensor.  (A caller's own device buffer keeps the separate crop kernel:
+                // the fused form's aligned 12-byte reads want 16 bytes of slack behind the frame, which only our staging buffer promises.)
+                m.crop_src = CropSrc{df, h, w, m.d_crop_boxes.p + (size_t)c0 * 4, nullptr, m.d_valid.p + c0};
+            } else {
                 Prof pr(*m.dev, PROF_CROP, s, 0, (double)k * m.in_h * m.in_w * 19);
                 launch_crop_resize(df, h, w, m.d_crop_boxes.p + (size_t)c0 * 4, nullptr, k, nullptr, m.in_h, m.in_w, m.in_pix4 ? 2 : 1, m.dtype,
                                    m.input(), m.d_valid.p + c0, s);
             }
             m.run(k, s);
+            m.crop_src.frames = nullptr;
             copy_out(emb + (size_t)c0 * m.out_dim, m.embeddings(), (size_t)k * m.out_dim * 4, AIC_HOST, s);
         }
         if (valid) HIP_CHECK(hipMemcpyAsync(valid, m.d_valid.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));

@@ -637,6 +637,7 @@ struct StemArgs {
     // (_extract_image_crops + preprocess_reid_input, deepsort_tracker.py:143-159 / image_processing.py:105-138) instead of reading x
     const uint8_t* frames; int fh, fw; const float* boxes; const int* frame_of; int* valid;
     const int* n_dev;                // optional device-side crop count (n is then the bound the grid was sized for)
+    int dbg;                         // AICAM_STEM_DBG (timing only, wrong outputs): 1 = leave after the patch is built, 2 = do not build it
 };
 
 __global__ __launch_bounds__(256) void reid_stem_pool_kernel(const StemArgs a) {
@@ -729,7 +730,7 @@ __global__ __launch_bounds__(256) void reid_stem_pool_kernel(const StemArgs a) {
 //    patch pixels per lane, tap 8 = a second one with zero weights outside (q = 0, j < 3): the im2col fragment is
 //    3 ds_read_b64, no scalar gathers (the first form spent 71 VALU per MFMA on them).  [v_mfma_f32_16x16x16_f16
 //    for tap 8 returned stale accumulator halves under hipcc 7.2: the first two results were read too early];
-//  * the bias rides in as the accumulator's initial value, ReLU is a packed fp16 max after the conversion;
+//  * the bias rides in as the accumulator's initial value, ReLU is one packed max on the POOLED vector;
 //  * the 3x3/2 max-pool never touches LDS: vertical max of three conv rows in registers (v_pk_max_f16),
 //    horizontal max over lane neighbours by DPP row shifts inside the 16-pixel tile (lane 0 takes pixel 15 of
 //    the tile to its left by row_ror), out-of-image taps are 0 = the identity of max over post-ReLU values;
@@ -749,7 +750,8 @@ template <int CTRL, bool BOUND> __device__ __forceinline__ unsigned dpp(unsigned
 }
 struct Row8 { unsigned u[8]; };   // one pixel's 16 output channels x 2 tile pairs, packed fp16: u[4p + i]
 
-__global__ __launch_bounds__(512) void reid_stem_pool2_kernel(const StemArgs a) {
+// (two blocks per CU = four waves per SIMD: 128 registers.  A build that took 132 ran one block per CU and 28 % slower)
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void reid_stem_pool2_kernel(const StemArgs a) {
     constexpr int CW = 64, PW = CW + 2, NTX = CW / 16;
     constexpr int ROW_SHL1 = 0x101, ROW_SHR1 = 0x111, ROW_ROR1 = 0x121;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -761,7 +763,8 @@ __global__ __launch_bounds__(512) void reid_stem_pool2_kernel(const StemArgs a) 
     if (a.n_dev && img >= a.n_dev[0]) return;               // device-side crop count: the grid was sized for a bound
     const half_t* xg = reinterpret_cast<const half_t*>(a.x) + (size_t)img * H * CW * a.in_stride;
 
-    if (a.frames == nullptr) {
+    if (a.dbg == 2) {
+    } else if (a.frames == nullptr) {
         for (int idx = t; idx < (H + 2) * PW; idx += 512) {
             const int iy = idx / PW, ix = idx - iy * PW;
             const int gy = iy - 1, gx = ix - 1;
@@ -797,42 +800,63 @@ __global__ __launch_bounds__(512) void reid_stem_pool2_kernel(const StemArgs a) 
         __syncthreads();
         const uint8_t* f = a.frames + (size_t)(a.frame_of ? a.frame_of[img] : 0) * a.fh * a.fw * 3;
         const int pitch = a.fw * 3;
-        for (int idx = t; idx < (H + 2) * PW; idx += 512) {
-            const int iy = idx / PW, ix = idx - iy * PW;
-            const int oy = iy - 1, ox = ix - 1;
-            uint2 v = make_uint2(0u, 0u);                      // the convolution's zero padding; an empty crop is all zeros
-            if (ok && (unsigned)oy < (unsigned)H && (unsigned)ox < (unsigned)CW) {
+        // the convolution's zero padding: rows -1 and H, columns -1 and CW of the patch
+        for (int idx = t; idx < 2 * PW + 2 * H; idx += 512) {
+            const int e = idx < 2 * PW ? (idx < PW ? idx : (H + 1) * PW + idx - PW) : (1 + ((idx - 2 * PW) >> 1)) * PW + ((idx & 1) ? PW - 1 : 0);
+            patch[e] = make_uint2(0u, 0u);
+        }
+        // A thread keeps ONE column (ox = t & 63: its horizontal taps, byte offset and weights are loop constants) and walks the rows
+        // wv, wv + 8, ...: a wave is one row, so the vertical taps are wave-uniform.  (The form before walked the patch linearly, halo
+        // included: a division by 66, two tap-table reads and the 64-bit address arithmetic per pixel -- 150 VALU instructions of which
+        // 60 are left; same loads, same integer arithmetic, same table: same bits.)
+        const int ox = t & 63;
+        const uintptr_t fb = reinterpret_cast<uintptr_t>(f);
+        const uint8_t* fa = reinterpret_cast<const uint8_t*>(fb & ~(uintptr_t)3);           // frame base rounded down to 4 bytes ...
+        const unsigned fd = (unsigned)(fb & 3);                                               // ... and what was cut off
+        if (!ok) {
+            for (int oy = wv; oy < H; oy += 8) patch[(oy + 1) * PW + ox + 1] = make_uint2(0u, 0u);          // an empty crop is all zeros
+        } else if (area2) {
+            const unsigned c0 = (unsigned)(x1 + 2 * ox) * 3u + fd;
+#pragma unroll 2
+            for (int oy = wv; oy < H; oy += 8) {
+                const uint8_t* p0 = fa + ((unsigned)(y1 + 2 * oy) * (unsigned)pitch + c0);
+                const uint8_t* p1 = p0 + pitch;
                 int px[3];
-                if (area2) {
-                    const uint8_t* p0 = f + (size_t)(y1 + 2 * oy) * pitch + (size_t)(x1 + 2 * ox) * 3;
-                    const uint8_t* p1 = p0 + pitch;
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) px[c] = ((int)p0[c] + (int)p0[3 + c] + (int)p1[c] + (int)p1[3 + c] + 2) >> 2;
-                } else {
+                for (int c = 0; c < 3; ++c) px[c] = ((int)p0[c] + (int)p0[3 + c] + (int)p1[c] + (int)p1[3 + c] + 2) >> 2;
+                const half4 hv = {(half_t)lut[0][px[2]], (half_t)lut[1][px[1]], (half_t)lut[2][px[0]], (half_t)0.f};     // BGR -> RGB
+                patch[(oy + 1) * PW + ox + 1] = __builtin_bit_cast(uint2, hv);
+            }
+        } else {
+            const Taps tx = xt[ox];
+            const bool two = tx.i1 != tx.i0;
+            const unsigned c0 = (unsigned)(x1 + tx.i0) * 3u + fd;
+#pragma unroll 2
+            for (int oy = wv; oy < H; oy += 8) {
+                const Taps ty = yt[oy];
+                int b0[2][3], b1[2][3];
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr) {
                     // both taps of a row are 6 consecutive bytes: one aligned 12-byte load per row (the frame ring has >= 16 bytes of slack)
-                    const Taps tx = xt[ox], ty = yt[oy];
-                    const bool two = tx.i1 != tx.i0;
-                    int b0[2][3], b1[2][3];
+                    const unsigned o = __umul24((unsigned)(y1 + (rr ? ty.i1 : ty.i0)), (unsigned)pitch) + c0;      // row < 2^24, pitch < 2^24 (launch_reid_stem_pool)
+                    const uint3 w3 = *reinterpret_cast<const uint3*>(fa + (o & ~3u));
+                    const unsigned shb = o & 3u;
+                    const unsigned q0 = __builtin_amdgcn_alignbyte(w3.y, w3.x, shb), q1 = __builtin_amdgcn_alignbyte(w3.z, w3.y, shb);
+                    b0[rr][0] = q0 & 255u, b0[rr][1] = (q0 >> 8) & 255u, b0[rr][2] = (q0 >> 16) & 255u;
+                    b1[rr][0] = two ? (q0 >> 24) : b0[rr][0], b1[rr][1] = two ? (q1 & 255u) : b0[rr][1], b1[rr][2] = two ? ((q1 >> 8) & 255u) : b0[rr][2];
+                }
+                int px[3];
 #pragma unroll
-                    for (int rr = 0; rr < 2; ++rr) {
-                        const uintptr_t A = reinterpret_cast<uintptr_t>(f + (size_t)(y1 + (rr ? ty.i1 : ty.i0)) * pitch + (size_t)(x1 + tx.i0) * 3);
-                        const uint3 w3 = *reinterpret_cast<const uint3*>(A & ~(uintptr_t)3);
-                        const unsigned shb = (unsigned)(A & 3);
-                        const unsigned q0 = __builtin_amdgcn_alignbyte(w3.y, w3.x, shb), q1 = __builtin_amdgcn_alignbyte(w3.z, w3.y, shb);
-                        b0[rr][0] = q0 & 255u, b0[rr][1] = (q0 >> 8) & 255u, b0[rr][2] = (q0 >> 16) & 255u;
-                        b1[rr][0] = two ? (q0 >> 24) : b0[rr][0], b1[rr][1] = two ? (q1 & 255u) : b0[rr][1], b1[rr][2] = two ? ((q1 >> 8) & 255u) : b0[rr][2];
-                    }
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        const int h0 = b0[0][c] * tx.w0 + b1[0][c] * tx.w1;
-                        const int h1 = b0[1][c] * tx.w0 + b1[1][c] * tx.w1;
-                        px[c] = (((ty.w0 * (h0 >> 4)) >> 16) + ((ty.w1 * (h1 >> 4)) >> 16) + 2) >> 2;
-                    }
+                for (int c = 0; c < 3; ++c) {
+                    // bytes <= 255, weights <= 2048, h >> 4 < 2^15: every factor fits 24 bits, so these are full-rate v_mul / v_mad_i32_i24
+                    // (a 32-bit v_mul_lo_u32 is a quarter-rate instruction and there are twelve of them per pixel) -- same integers
+                    const int h0 = __mul24(b0[0][c], tx.w0) + __mul24(b1[0][c], tx.w1);
+                    const int h1 = __mul24(b0[1][c], tx.w0) + __mul24(b1[1][c], tx.w1);
+                    px[c] = ((__mul24(ty.w0, h0 >> 4) >> 16) + (__mul24(ty.w1, h1 >> 4) >> 16) + 2) >> 2;
                 }
                 const half4 hv = {(half_t)lut[0][px[2]], (half_t)lut[1][px[1]], (half_t)lut[2][px[0]], (half_t)0.f};     // BGR -> RGB
-                v = __builtin_bit_cast(uint2, hv);
+                patch[(oy + 1) * PW + ox + 1] = __builtin_bit_cast(uint2, hv);
             }
-            patch[idx] = v;
         }
     }
 
@@ -857,6 +881,7 @@ __global__ __launch_bounds__(512) void reid_stem_pool2_kernel(const StemArgs a) 
     const int t0 = 2 * q, t1 = 2 * q + 1;
     const int off0 = (t0 / 3) * PW + t0 % 3 + r, off1 = (t1 / 3) * PW + t1 % 3 + r, off2 = 2 * PW + 2 + r;
     __syncthreads();
+    if (a.dbg == 1) return;
 
     auto conv_tile = [&](int y, int tx) -> Row8 {   // conv + bias + ReLU of 16 pixels (row y, columns 16tx..) x 64 channels
         Row8 o;
@@ -874,9 +899,11 @@ __global__ __launch_bounds__(512) void reid_stem_pool2_kernel(const StemArgs a) 
             floatx4 acc = bi[ct];
             acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[ct], xa, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[ct], xb, acc, 0, 0, 0);
+            // (written as a vector conversion every pair becomes a v_cvt_pk_f16_f32 and the kernel needs 132 registers: one block per CU,
+            //  28 % slower; held to 128 it spills.  This form compiles to a mix of packed and scalar conversions inside 128)
             const half2_t h01 = {(half_t)acc[0], (half_t)acc[1]}, h23 = {(half_t)acc[2], (half_t)acc[3]};
-            o.u[2 * ct] = pk_max(__builtin_bit_cast(unsigned, h01), 0u);
-            o.u[2 * ct + 1] = pk_max(__builtin_bit_cast(unsigned, h23), 0u);
+            o.u[2 * ct] = __builtin_bit_cast(unsigned, h01);        // (ReLU: once, on the pooled vector -- see the store)
+            o.u[2 * ct + 1] = __builtin_bit_cast(unsigned, h23);
         }
         return o;
     };
@@ -910,7 +937,11 @@ __global__ __launch_bounds__(512) void reid_stem_pool2_kernel(const StemArgs a) 
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const unsigned nb = dpp<ROW_SHR1, true>(0u, hm.u[4 + i]);
-                op[i] = (r & 1) ? nb : hm.u[i];
+                // ReLU after the pool: max(relu(a), relu(b), ...) = relu(max(a, b, ...)), and the signed-integer max above is still exact for
+                // it -- a positive half beats every negative one (sign bit = negative integer) and the larger of two positives wins; if all
+                // nine are negative the winner is SOME negative half, which the max against 0 here turns into the same 0.  Out-of-image
+                // taps stay 0.  Four v_pk_max per 16 x 64 outputs instead of the sixteen that clamped both conv rows first.
+                op[i] = pk_max((r & 1) ? nb : hm.u[i], 0u);
             }
             const size_t pix = ((size_t)img * Hp + py) * Wp + 8 * tx + (r >> 1);
             *reinterpret_cast<uint4*>(yg + pix * a.y_cs + a.y_coff + (r & 1) * 32 + 8 * q) = out;
@@ -926,9 +957,11 @@ bool reid_stem2_usable(int H, int W) {
 void launch_reid_stem_pool(const void* x, const void* w, const float* bias, void* y, int n, int H, int W, int Kp, int y_cs,
                            int y_coff, int in_stride, hipStream_t s, const CropSrc* crop, const int* n_dev) {
     if (n <= 0) return;
-    StemArgs a{x, w, bias, y, n, H, W, Kp, y_cs, y_coff, in_stride, nullptr, 0, 0, nullptr, nullptr, nullptr, n_dev};
+    static const int dbg = [] { const char* e = getenv("AICAM_STEM_DBG"); return e ? atoi(e) : 0; }();
+    StemArgs a{x, w, bias, y, n, H, W, Kp, y_cs, y_coff, in_stride, nullptr, 0, 0, nullptr, nullptr, nullptr, n_dev, dbg};
     if (crop && crop->frames) {
         AIC_REQUIRE(reid_stem2_usable(H, W) && H <= 256 - 64, AIC_ERR_INVALID, "fused crop needs the second stem form");
+        AIC_REQUIRE(crop->fh < (1 << 23) && crop->fw * 3 < (1 << 23) && (size_t)crop->fh * crop->fw * 3 < ((size_t)1 << 31), AIC_ERR_INVALID, "fused crop: frame too large for its 24-bit row arithmetic");
         a.frames = crop->frames, a.fh = crop->fh, a.fw = crop->fw, a.boxes = crop->boxes, a.frame_of = crop->frame_of, a.valid = crop->valid;
     }
     AIC_REQUIRE(in_stride == 8 || (in_stride == 4 && reid_stem2_usable(H, W)), AIC_ERR_INVALID, "NHWC4 input needs the second stem form");

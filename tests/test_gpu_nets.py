@@ -210,6 +210,26 @@ def test_reid_embeddings(gpu, engines, frames, dtype, tol):
     assert reid.extract_features_batched([np.zeros((3, 3, 1), np.uint8)]).shape == (0, 512)
 
 
+def test_embed_boxes_fused_crop_equals_crop_kernel_plus_stem(gpu, engines, frames):
+    """aic_reid_embed resamples every crop INSIDE the stem kernel (fp16 engines, frame handed over in host memory); the crop kernel
+    followed by the stem on its tensor must give the same bits -- boxes that are clipped, one pixel wide, empty, exactly 2x the crop
+    (cv2's INTER_AREA branch) and the whole frame included."""
+    ip = pkg("image_processing")
+    sc = syn.Scene(seed=4, n_targets=30)
+    frame = sc.render(3)
+    extra = np.array([[-20.5, -3.2, 40.9, 90.1], [1270.2, 700.7, 1300, 760], [100, 100, 100.9, 180], [50, 60, 178, 316],
+                      [0, 0, 1280, 720], [640.99, 10.01, 641.99, 11.5], [300, 200, 290, 260], [5, 5, 69, 133]], np.float32)
+    boxes = np.concatenate([sc.detections(3)[0], extra])
+    eng = HipEngine(engines[1], dtype="fp16", max_items=64, warm_up=False)
+    emb, valid = eng.embed_boxes_np(frame, boxes)
+    crops, cvalid = ip.crops_from_boxes(frame, boxes)
+    ref = eng.reid_infer_np(crops)
+    eng.close()
+    assert valid.tolist() == cvalid.tolist() and 0 < valid.sum() < len(boxes)
+    ok = valid.astype(bool)
+    assert np.array_equal(emb[ok], ref[ok])
+
+
 @pytest.mark.parametrize("n_crops", [960, 950])
 @pytest.mark.parametrize("dtype,tol_split,tol", [("fp32", 2e-5, 1e-5), ("fp16", 1e-3, 5e-4)])
 def test_reid_large_batch_kernels(gpu, engines, dtype, tol_split, tol, n_crops):
