@@ -108,7 +108,7 @@ __device__ __forceinline__ float iou_xyxy(const float4 p, const float4 q) {
 // Dynamic LDS: keys[P] (u64) | kept boxes[max_det] (float4) | kept labels[max_det] | flags[NT]
 constexpr int NMS_THREADS = 1024;
 
-__global__ __launch_bounds__(NMS_THREADS) void select_sort_nms_kernel(const DetArgs a, int P) {
+__global__ __launch_bounds__(NMS_THREADS) void select_sort_nms_kernel(const DetArgs a, int P, int dbg) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);
     float4* kbox = reinterpret_cast<float4*>(smem + (size_t)P * 8);
@@ -135,6 +135,7 @@ __global__ __launch_bounds__(NMS_THREADS) void select_sort_nms_kernel(const DetA
             ((unsigned long long)ordered_bits(v) << 32) | (unsigned int)(0xFFFFFFFFu - (unsigned int)i);
     }
     __syncthreads();
+    if (dbg == 1) return;                      // (AICAM_NMS_DBG, timing only: 1 = leave after the selection, 2 = after the sort)
     const int n = s_count;
     int p2 = 1;
     while (p2 < n) p2 <<= 1;
@@ -155,6 +156,7 @@ __global__ __launch_bounds__(NMS_THREADS) void select_sort_nms_kernel(const DetA
         }
     }
     if (t == 0) a.n_cand[img] = n;
+    if (dbg == 2) return;
     // 3. greedy NMS in chunks of NMS_THREADS candidates (thread = candidate, sorted order = chunk, wave, lane).  A chunk
     //    first drops what the boxes kept so far suppress; then its 16 wave tiles take turns: everyone still waiting tests
     //    against the boxes the previous tile kept, and the tile's own 64 candidates are walked greedily with ballot /
@@ -303,7 +305,8 @@ void launch_select_sort_nms(const DetArgs& a, hipStream_t s) {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
         attr_set = true;
     }
-    hipLaunchKernelGGL(select_sort_nms_kernel, dim3(a.batch), dim3(NMS_THREADS), lds, s, a, P);
+    static const int dbg = [] { const char* e = getenv("AICAM_NMS_DBG"); return e ? atoi(e) : 0; }();
+    hipLaunchKernelGGL(select_sort_nms_kernel, dim3(a.batch), dim3(NMS_THREADS), lds, s, a, P, dbg);
     KCHECK();
 }
 

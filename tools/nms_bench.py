@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Decode + NMS microbench through the C ABI: the seeded YOLOv8n engine of bench.py on synthetic frames, time of the
-decode_nms profiling class per frame (HIP events inside the library) and candidate / detection counts.
-  python tools/nms_bench.py [frames]"""
+"""Decode + select / sort / NMS of a launch group alone: B frames of the bench's scene through aic_detect, the decode_nms class's own HIP-event
+bracket read back (AICAM_NMS_DBG=1 / 2: the NMS kernel leaves after the selection / after the sort -- timing only).
+  python tools/nms_bench.py [frames = 256]"""
 import importlib
 import os
 import sys
@@ -11,27 +11,24 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 ef = importlib.import_module("ai-camera_amd.engine_file")
+syn = importlib.import_module("ai-camera_amd.synthetic")
 L = importlib.import_module("ai-camera_amd._lib")
 he = importlib.import_module("ai-camera_amd.hip_engine")
-syn = importlib.import_module("ai-camera_amd.synthetic")
 
-
-def main():
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 128
-    path, _ = ef.ensure_seeded_engines(ROOT, scale="n")          # the engines bench.py runs
-    eng = he.HipEngine(path, dtype="fp16", max_items=n, warm_up=False)
-    frames = syn.Scene(seed=0, n_targets=30, width=1280, height=720).render_batch(0, n)
-    eng.detect_np(frames)
-    L.call("aic_prof_enable", 0, 0xFF)
-    L.call("aic_prof_reset", 0)
-    reps = 5
-    for _ in range(reps):
-        nd, *_ = eng.detect_np(frames)
-    pr = L.prof_read(0)
-    L.call("aic_prof_enable", 0, 0)
-    d = pr["decode_nms"]
-    print(f"frames {n}: decode+nms {d['ms'] * 1e3 / (reps * n):.2f} us/frame ({d['launches']} launches), dets/frame mean {np.mean(nd):.1f} max {np.max(nd)}")
-
-
-if __name__ == "__main__":
-    main()
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+ypath, _ = ef.ensure_seeded_engines(ROOT)
+sc = syn.Scene(seed=0, n_targets=30)
+frames = sc.render_batch(0, n)
+eng = he.HipEngine(ypath, dtype="fp16", max_items=n, warm_up=False)
+nd, boxes, scores, labels = eng.detect_np(frames)
+L.call("aic_prof_enable", 0, 0x7f)
+L.call("aic_prof_reset", 0)
+R = 3
+for _ in range(R):
+    nd, boxes, scores, labels = eng.detect_np(frames)
+p = L.prof_read(0)
+L.call("aic_prof_enable", 0, 0)
+d = p["decode_nms"]
+print(f"{n} frames: decode + NMS {1e3 * d['ms'] / R:.1f} us per launch group ({d['launches'] // R} launches), detections per frame {nd.mean():.1f}, "
+      f"checksum {float(boxes.sum()):.3f} {int(labels.sum())}")
+eng.close()
