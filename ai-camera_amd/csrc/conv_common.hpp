@@ -495,7 +495,94 @@ __device__ __forceinline__ void tail_1x1(const ConvArgs& a, floatx4 (&acc)[MT][N
 #pragma unroll
             for (int j = 0; j < NT; ++j) acc2[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j][s], bf[s], acc2[0][j], 0, 0, 0);
         const int m1[1] = {mrow[i]};
-        epilogue_dispatch<half_t, 1, NT, true>(a2, acc2, m1, 0, q);
+        if (a.t_max) {
+            // class reduction (ConvArgs::t_max): lane (r, q) holds 4 NT channels of pixel r, in ascending order when walked (j, e); the
+            // four q-lanes of the pixel meet by two xor-shuffles.  Larger value wins, equal values: the lower channel (first maximum)
+            // (the tail's bias is fetched HERE, per pixel tile, behind the MFMAs just issued: their ~400 cycles cover the L1 round trip,
+            //  and twenty registers carried through the tile loop would cost the lead kernels a wave per SIMD)
+            floatx4 bt[NT];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                bt[2 * p] = *reinterpret_cast<const floatx4*>(a.b_tail + 32 * p + 8 * q);
+                bt[2 * p + 1] = *reinterpret_cast<const floatx4*>(a.b_tail + 32 * p + 8 * q + 4);
+            }
+            if constexpr (NT & 1) bt[NT - 1] = *reinterpret_cast<const floatx4*>(a.b_tail + 16 * (NT - 1) + 4 * q);
+            float best = -__builtin_inff();
+            int arg = 0x7fffffff;
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int ch = perm_ch<NT>(j, q, e);
+                    const float v = acc2[0][j][e] + bt[j][e];              // (linear, fp32: the value the store would have written)
+                    if (ch < a.t_cout && v > best) { best = v; arg = ch; }
+                }
+#pragma unroll
+            for (int off = 16; off <= 32; off <<= 1) {
+                const float ov = __shfl_xor(best, off);
+                const int oa = __shfl_xor(arg, off);
+                if (ov > best || (ov == best && oa < arg)) { best = ov; arg = oa; }
+            }
+            const int m = mrow[i];
+            if (q == 0 && m >= 0) {
+                const int im = m / a.t_hw;
+                const size_t o = (size_t)im * a.t_na + a.t_a0 + (m - im * a.t_hw);
+                a.t_max[o] = best;
+                a.t_arg[o] = arg;
+            }
+        } else if (NT == 4 && a.t_box) {
+            // box decode (ConvArgs::t_box).  Lane (r, q) holds bins 8 (q & 1) .. + 7 of side q >> 1 (tiles 0, 1) and of side 2 + (q >> 1)
+            // (tiles 2, 3); its partner q ^ 1 holds the other eight.  decode_kernel's order is kept exactly: the maximum of the sixteen
+            // (exact in any order), then e_k = expf(v_k - max), sum += e_k, ex += e_k * k for k = 0 .. 15 IN THAT ORDER -- the even lane
+            // runs bins 0 .. 7 from zero, hands its two running sums to the odd lane, which continues with 8 .. 15 and divides.
+            if constexpr (NT == 4) {
+                floatx4 bt[4];
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    bt[2 * p] = *reinterpret_cast<const floatx4*>(a.b_tail + 32 * p + 8 * q);
+                    bt[2 * p + 1] = *reinterpret_cast<const floatx4*>(a.b_tail + 32 * p + 8 * q + 4);
+                }
+                const bool odd = q & 1;
+                float dist[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {                            // h = 0: side q >> 1, h = 1: side 2 + (q >> 1)
+                    float v[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = acc2[0][2 * h + (k >> 2)][k & 3] + bt[2 * h + (k >> 2)][k & 3];
+                    float mx = v[0];
+#pragma unroll
+                    for (int k = 1; k < 8; ++k) mx = fmaxf(mx, v[k]);
+                    mx = fmaxf(mx, __shfl_xor(mx, 16));
+                    float e[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) e[k] = expf(v[k] - mx);
+                    float sum = 0.f, ex = 0.f;
+                    if (!odd) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) { sum += e[k]; ex += e[k] * (float)k; }
+                    }
+                    const float s_in = __shfl_xor(sum, 16), x_in = __shfl_xor(ex, 16);
+                    if (odd) {
+                        sum = s_in, ex = x_in;
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) { sum += e[k]; ex += e[k] * (float)(8 + k); }
+                    }
+                    dist[h] = ex / sum;                                  // (meaningful in odd lanes)
+                }
+                // lane q = 1 holds sides 0 and 2, lane q = 3 sides 1 and 3: q = 1 fetches the other two and stores the box
+                const float d1 = __shfl_xor(dist[0], 32), d3 = __shfl_xor(dist[1], 32);
+                const int m = mrow[i];
+                if (q == 1 && m >= 0) {
+                    const int im = m / a.t_hw, cell = m - im * a.t_hw;
+                    const int gy = cell / a.t_w, gx = cell - gy * a.t_w;
+                    const float cx = (float)gx + 0.5f, cy = (float)gy + 0.5f, st = (float)a.t_stride;
+                    const size_t o = (size_t)im * a.t_na + a.t_a0 + cell;
+                    *reinterpret_cast<floatx4*>(a.t_box + o * 4) = floatx4{(cx - dist[0]) * st, (cy - d1) * st, (cx + dist[1]) * st, (cy + d3) * st};
+                }
+            }
+        } else {
+            epilogue_dispatch<half_t, 1, NT, true>(a2, acc2, m1, 0, q);
+        }
     }
 }
 

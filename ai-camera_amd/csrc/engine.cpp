@@ -449,6 +449,7 @@ bool Model::input_pix4_ok() const {
 void Model::run(int n, hipStream_t s) {
     AIC_REQUIRE(n >= 0 && n <= max_items, AIC_ERR_CAPACITY, "batch exceeds the engine's max_items");
     if (n == 0) return;
+    cls_reduced = box_decoded = 0;
     AIC_REQUIRE(!n_items_dev || !(lead_ops > 0 && sub_items > 0), AIC_ERR_INVALID, "a device-side item count cannot be combined with sub-batching");
     if (lead_ops > 0 && sub_items > 0 && n > sub_items + sub_items / 2) {
         // producer -> consumer tensors of the first layers exceed the 256 MiB Infinity Cache at full batch:
@@ -478,6 +479,7 @@ void Model::run_frames(const uint8_t* frames, int n, const LetterboxGeom& g, hip
             ok = launch_yolo_stem_fused(frames, n, g, w.w.p, w.bias.p, w.Kp, db.p, db.c, v[5], db.h, db.w, s);
         }
         if (ok) {
+            cls_reduced = box_decoded = 0;
             run_range(1, ops.size(), 0, n, s);
             return;
         }
@@ -601,6 +603,28 @@ void Model::run_range(size_t op0, size_t op1, int i0, int n, hipStream_t s) {
                     ConvArgs at = a;
                     at.w_tail = t.w, at.b_tail = t.bias, at.y_tail = t.y, at.t_cout = t.Cout, at.t_kp = t.Kp;
                     at.t_y_cs = t.y_cs, at.t_y_coff = t.y_coff, at.t_out_f32 = t.out_f32, at.t_act = t.act;
+                    static const bool cls_reduce_on = getenv("AICAM_NO_CLS_REDUCE") == nullptr;
+                    static const bool box_decode_on = getenv("AICAM_NO_BOX_DECODE") == nullptr;
+                    if (reduce_cls && kind == KIND_YOLO && t.out_f32 && t.act == 0 && t.y_coff == 0 && t.y_cs == t.Cout) {
+                        // a detect level's class / box branch: its logits only feed decode's arg-max / DFL expectation
+                        const bool is_cls = cls_reduce_on && t.Cout == meta[0], is_box = box_decode_on && meta[1] == 16 && t.Cout == 64 && !is_cls;
+                        int a0 = 0;
+                        for (size_t l = 0; l < outs.size() && (is_cls || is_box); ++l) {
+                            const int* ov = outs[l].v;
+                            const BufDesc& ob = bufs[ov[is_cls ? 1 : 0]];
+                            if (static_cast<char*>(ob.p) + (size_t)i0 * ob.per_item == static_cast<char*>(t.y) && ov[3] * ov[4] == t.Ho * t.Wo) {
+                                at.t_hw = ov[3] * ov[4], at.t_a0 = a0, at.t_na = n_anchors;
+                                if (is_cls) {
+                                    at.t_max = d_maxlogit.p + (size_t)i0 * n_anchors, at.t_arg = d_labels.p + (size_t)i0 * n_anchors;
+                                    cls_reduced |= 1u << l;
+                                } else {
+                                    at.t_box = d_boxes.p + (size_t)i0 * n_anchors * 4, at.t_w = ov[4], at.t_stride = ov[2];
+                                    box_decoded |= 1u << l;
+                                }
+                            }
+                            a0 += ov[3] * ov[4];
+                        }
+                    }
                     if (prof_conv) dev->prof_account(PROF_CONV, fl, by);
                     launch_conv_igemm(dtype, at, s);
                     ++oi;
@@ -640,6 +664,7 @@ DetArgs Model::det_args(int batch, float conf, float iou, int max_det, const Let
         a.lvl[l].box = reinterpret_cast<const float*>(bufs[v[0]].p);
         a.lvl[l].cls = reinterpret_cast<const float*>(bufs[v[1]].p);
         a.lvl[l].stride = v[2], a.lvl[l].h = v[3], a.lvl[l].w = v[4], a.lvl[l].a0 = a0;
+        a.lvl[l].cls_reduced = (cls_reduced >> l) & 1u, a.lvl[l].box_decoded = (box_decoded >> l) & 1u;
         a0 += v[3] * v[4];
     }
     a.n_levels = (int)outs.size(), a.n_anchors = n_anchors, a.nc = meta[0], a.reg_max = meta[1], a.batch = batch;
@@ -760,6 +785,7 @@ int aic_yolo_infer(aic_model* mm, const float* images, int batch, int mem, float
         m.dev->use();
         hipStream_t s = m.dev->s_main;
         load_input_nchw(m, images, batch, mem, s);
+        m.reduce_cls = true;                    // (only the decoded outputs leave this call)
         m.run(batch, s);
         m.decode_nms(batch, conf, iou, max_det, nullptr, s);
         copy_out(num_dets, m.d_numdets.p, (size_t)batch * 4, mem, s);
@@ -778,6 +804,7 @@ int aic_yolo_head(aic_model* mm, const float* images, int batch, int mem, float*
         m.dev->use();
         hipStream_t s = m.dev->s_main;
         load_input_nchw(m, images, batch, mem, s);
+        m.reduce_cls = false;                   // the raw class logits are what this call returns
         m.run(batch, s);
         const int nc = m.meta[0], nb = 4 * m.meta[1];
         int a0 = 0;
@@ -805,6 +832,7 @@ int aic_yolo_decode(aic_model* mm, const float* images, int batch, int mem, floa
         m.dev->use();
         hipStream_t s = m.dev->s_main;
         load_input_nchw(m, images, batch, mem, s);
+        m.reduce_cls = true;
         m.run(batch, s);
         const DetArgs a = m.det_args(batch, 0.5f, 0.5f, 1, nullptr);
         launch_decode(a, s);
@@ -914,6 +942,7 @@ int aic_detect(aic_model* mm, const uint8_t* frames, int batch, int h, int w, in
         hipStream_t s = m.dev->s_main;
         const uint8_t* df = stage_frames(m, frames, (size_t)batch * h * w * 3, mem, s);
         const LetterboxGeom g = letterbox_geometry(h, w, m.in_h, m.in_w);
+        m.reduce_cls = true;
         m.run_frames(df, batch, g, s);
         m.decode_nms(batch, conf, iou, max_det, &g, s);
         copy_out(num_dets, m.d_numdets.p, (size_t)batch * 4, AIC_HOST, s);

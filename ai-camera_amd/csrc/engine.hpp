@@ -55,6 +55,12 @@ struct Model {
     // set around run(): the number of items is only known on the device (ReID behind the on-device detection filter): run(n) then
     // sizes every launch for the bound n and the kernels leave past n_items_dev[0] (ConvArgs::n_dev)
     const int* n_items_dev = nullptr;
+    // set before run() by callers that go on to decode (aic_detect, aic_yolo_infer, aic_yolo_decode, the pipeline) and never look at the
+    // raw head logits: the detect branches' tails then store max logit + label (class branch, ConvArgs::t_max) and the decoded box (box
+    // branch, ConvArgs::t_box) per anchor themselves, and decode_kernel skips what the levels named in cls_reduced / box_decoded
+    // already have (bit l = level l of the LAST run).  aic_yolo_head leaves it off.
+    bool reduce_cls = false;
+    unsigned cls_reduced = 0, box_decoded = 0;
     bool input_pix4_ok() const;
     void run(int n_items, hipStream_t s);
     // u8 BGR frames -> letterbox -> the whole graph; fp16 YOLO engines fuse the letterbox into the stem conv

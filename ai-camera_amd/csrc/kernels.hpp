@@ -55,6 +55,19 @@ struct ConvArgs {
     const float* b_tail;  // [t_cout_pad]
     void* y_tail;         // NHWC output of the tail (fp16, or float when t_out_f32)
     int t_cout, t_kp, t_y_cs, t_y_coff, t_out_f32, t_act;
+    // ---- optional CLASS REDUCTION of the tail (the detect head's class branch, whose logits only ever feed an arg-max): instead of
+    // storing t_cout fp32 logits per pixel (320 bytes per anchor written here, read back by decode_kernel) the tail stores their
+    // maximum and the FIRST channel that reaches it (np.argmax's rule, as decode_kernel) -- the very fp32 values it would have stored,
+    // compared in registers.  Pixel m of the tail's map goes to t_max / t_arg[(m / t_hw) * t_na + t_a0 + m % t_hw]
+    // (image-major anchor order of DetArgs).  t_max == NULL: none (y_tail is then written as usual).
+    float* t_max; int* t_arg;
+    int t_hw, t_a0, t_na;
+    // ---- optional BOX DECODE of the tail (the detect head's box branch: 4 sides x 16 DFL bins per pixel): instead of 64 fp32 logits
+    // per pixel (256 bytes per anchor written, read back by decode_kernel) the tail stores the decoded xyxy box -- decode_kernel's own
+    // arithmetic on the same fp32 values in the same order (max, then exp / running sums bin 0 .. 15, one division per side), so the
+    // boxes are the bits decode_kernel would have produced.  Same anchor indexing as t_max; t_w / t_stride: the level's map width and
+    // stride.  t_box == NULL: none.
+    float* t_box; int t_w, t_stride;
 };
 // true when launch_conv_igemm can run `lead` with `tail` (a 1x1 / stride 1 / pad 0 conv reading exactly lead's output) in its epilogue:
 // fp16, lead = SiLU without residual with Cout 64 or 80 (a wave then owns every channel of its pixels), tail.Cout <= lead.Cout
@@ -123,7 +136,7 @@ void launch_crop_resize(const uint8_t* frames, int h, int w, const float* boxes,
                         hipStream_t s, bool slack = false);
 
 // ------------------------------------------------------------------ detection head (kernels_det.hip)
-struct HeadLevel { const float* box; const float* cls; int h, w, stride, a0; };
+struct HeadLevel { const float* box; const float* cls; int h, w, stride, a0; int cls_reduced, box_decoded; };   // cls_reduced / box_decoded: max_logit + labels / boxes of this level were written by the branch's own tail (ConvArgs::t_max / t_box)
 struct DetArgs {
     HeadLevel lvl[4];
     int n_levels, n_anchors, nc, reg_max, batch;

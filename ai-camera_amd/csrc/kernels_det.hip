@@ -29,7 +29,9 @@ __global__ void decode_kernel(const DetArgs a) {
     const size_t pix = (size_t)img * L.h * L.w + cell;
     const float* d = L.box + pix * (4 * a.reg_max);
     float dist[4];
-    if (a.reg_max == 16) {   // the common case: 16-byte loads, bins in registers
+    if (L.box_decoded) {
+        if (L.cls_reduced) return;              // both halves of this level came from the detect branches' own tails (ConvArgs::t_box / t_max)
+    } else if (a.reg_max == 16) {   // the common case: 16-byte loads, bins in registers
         for (int sd = 0; sd < 4; ++sd) {
             const float4* v4 = reinterpret_cast<const float4*>(d + sd * 16);
             float v[16];
@@ -61,12 +63,15 @@ __global__ void decode_kernel(const DetArgs a) {
             dist[sd] = ex / sum;
         }
     }
-    const float cx = (float)gx + 0.5f, cy = (float)gy + 0.5f, st = (float)L.stride;
-    float* b = a.boxes + idx * 4;
-    b[0] = (cx - dist[0]) * st;
-    b[1] = (cy - dist[1]) * st;
-    b[2] = (cx + dist[2]) * st;
-    b[3] = (cy + dist[3]) * st;
+    if (!L.box_decoded) {
+        const float cx = (float)gx + 0.5f, cy = (float)gy + 0.5f, st = (float)L.stride;
+        float* b = a.boxes + idx * 4;
+        b[0] = (cx - dist[0]) * st;
+        b[1] = (cy - dist[1]) * st;
+        b[2] = (cx + dist[2]) * st;
+        b[3] = (cy + dist[3]) * st;
+    }
+    if (L.cls_reduced) return;                  // max logit + label of this level came from the class branch's own tail (ConvArgs::t_max)
     const float* c = L.cls + pix * a.nc;
     float best = c[0];
     int arg = 0;
@@ -289,6 +294,9 @@ void launch_det_filter(const DetFilterArgs& a, hipStream_t s) {
 void launch_decode(const DetArgs& a, hipStream_t s) {
     const long tot = (long)a.batch * a.n_anchors;
     if (tot <= 0) return;
+    bool left = a.n_levels <= 0;                // every level already decoded by the detect branches' own tails (ConvArgs::t_max / t_box)?
+    for (int l = 0; l < a.n_levels; ++l) left = left || !(a.lvl[l].cls_reduced && a.lvl[l].box_decoded);
+    if (!left) return;
     hipLaunchKernelGGL(decode_kernel, dim3(ceil_div(tot, 128)), dim3(128), 0, s, a);
     KCHECK();
 }

@@ -295,6 +295,7 @@ struct Pipeline {
         }
         const uint8_t* f0 = ring.p + (size_t)slot * frame_bytes;
         if (pipe_times) HIP_CHECK(hipEventRecord(c.t_begin, s));
+        c.ln->yolo->reduce_cls = true;           // the pipeline only ever decodes: the class tails store max logit + label themselves
         c.ln->yolo->run_frames(f0, frames, geom, s);
         // decode + NMS + read-back on the side stream: a few latency-bound blocks that overlap the
         // (CU-filling) ReID launch group instead of serialising the main stream

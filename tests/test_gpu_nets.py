@@ -302,6 +302,42 @@ sys.exit(0 if d < 3e-3 and np.allclose(np.linalg.norm(e_big, axis=1), 1, atol=1e
     assert r.returncode == 0
 
 
+def test_detect_branch_tails_decode_in_place_bit_exact(gpu, engines, tmp_path):
+    """fp16 engines, calls that go on to decode: the class branch's 1x1 tail stores max logit + first arg-max per anchor and the box
+    branch's tail the decoded box (ConvArgs::t_max / t_box) instead of 80 + 64 fp32 logits that decode_kernel would read back.  Same
+    fp32 values, same order of operations: boxes, max logits and labels must be IDENTICAL to the two-step form (a child process with the
+    switches off: they are read once per process), at 2 frames (128-pixel tail tiles) and at 40 (512-pixel tiles, the patch kernel's tail)."""
+    import subprocess
+    import sys
+    code = r"""
+import importlib, sys, numpy as np
+sys.path.insert(0, %r)
+he = importlib.import_module("ai-camera_amd.hip_engine")
+rng = np.random.default_rng(5)
+out = {}
+for n in (2, 40):
+    x = rng.random((n, 3, 640, 640), dtype=np.float32)
+    eng = he.HipEngine(%r, dtype="fp16", max_items=n, warm_up=False)
+    b, ml, lab = eng.yolo_decode_np(x)
+    nd, ob, sc, ol = eng.yolo_infer_np(x, conf=0.25, iou=0.45, max_det=300)
+    eng.close()
+    out.update({f"b{n}": b, f"ml{n}": ml, f"lab{n}": lab, f"nd{n}": nd, f"ob{n}": ob, f"sc{n}": sc, f"ol{n}": ol})
+np.savez(sys.argv[1], **out)
+""" % (ROOT, engines[0])
+    files = []
+    for name, env in (("tails", {}), ("two_step", {"AICAM_NO_CLS_REDUCE": "1", "AICAM_NO_BOX_DECODE": "1"})):
+        f = str(tmp_path / (name + ".npz"))
+        r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        print(r.stdout[-300:], r.stderr[-300:])
+        assert r.returncode == 0
+        files.append(np.load(f))
+    a, b = files
+    assert sorted(a.files) == sorted(b.files)
+    for k in a.files:
+        assert np.array_equal(a[k], b[k]), k
+    assert a["nd40"].min() > 0 and len(np.unique(a["lab40"])) > 10          # the check is not vacuous
+
+
 @pytest.mark.parametrize("dtype,tol", [("fp32", 5e-4), ("fp16", 6e-2)])
 def test_yolo_large_batch_kernels(gpu, engines, dtype, tol):
     """The detector's big-tile kernels (512 x 80 class-branch tiles, 16-channel direct kernel, patch forms) engage only
