@@ -182,8 +182,15 @@ def test_fp16_frames_path_fused_stem(gpu, engines, frames):
         best = np.where(same, iou, 0).max(1)
         strong = s0[i, :nd0[i]] > 0.35                               # away from the 0.3 threshold
         frac = (best[strong] > 0.9).mean()
-        print(f"frame {i}: {nd0[i]} vs {nd1[i]} detections, {frac:.4f} of the confident ones matched")
+        # the matched pairs' scores: both paths feed the same network the same letterboxed pixels (the fused stem resamples with the
+        # letterbox kernel's arithmetic), so a pair differs by fp16 rounding in the stem's K order only -- a wrong halo or a shifted
+        # tap in a fused kernel moves scores by 1e-2 and more while still passing the IoU criterion above
+        partner = np.where(same, iou, 0).argmax(1)
+        ok = strong & (best > 0.9)
+        ds = np.abs(s0[i, :nd0[i]][ok] - s1[i, :nd1[i]][partner[ok]])
+        print(f"frame {i}: {nd0[i]} vs {nd1[i]} detections, {frac:.4f} of the confident ones matched, max |score difference| of matched pairs {ds.max():.2e}")
         assert frac > 0.95       # max_det saturates on seeded heads: near-ties at the rank-300 cut swap a few boxes
+        assert ds.max() < 6e-3   # measured 2.5e-3 (fp16 engines); a fused stem + 1.conv kernel with a bug somewhere in its halo: 1.7e-2
     eng.close()
 
 

@@ -29,6 +29,8 @@ for _ in range(R):
 p = L.prof_read(0)
 L.call("aic_prof_enable", 0, 0)
 d = p["decode_nms"]
-print(f"{n} frames: decode + NMS {1e3 * d['ms'] / R:.1f} us per launch group ({d['launches'] // R} launches), detections per frame {nd.mean():.1f}, "
+lb, cv = p["letterbox"], p["conv_igemm"]
+print(f"{n} frames: letterbox + stem (+ 1.conv) {1e3 * lb['ms'] / R:.1f} us, conv class {1e3 * cv['ms'] / R:.1f} us ({cv['launches'] // R} launches); "
+      f"decode + NMS {1e3 * d['ms'] / R:.1f} us per launch group ({d['launches'] // R} launches), detections per frame {nd.mean():.1f}, "
       f"checksum {float(boxes.sum()):.3f} {int(labels.sum())}")
 eng.close()
