@@ -248,7 +248,39 @@ void launch_maxpool3s2(int dtype, const EltArgs& a, hipStream_t s) {
     const int oh = (a.h - 1) / 2 + 1, ow = (a.w - 1) / 2 + 1;
     ELT_LAUNCH(maxpool3s2_kernel, (long)a.n * oh * ow * (a.c / vecn(dtype)));
 }
-void launch_avgpool(int dtype, const EltArgs& a, hipStream_t s) { ELT_LAUNCH(avgpool_kernel, (long)a.n * a.c); }
+// fp16, channels in groups of eight: one 16-byte load per pixel instead of eight 2-byte ones (the scalar form moved the ReID trunk's
+// 252 MB at 1.7 TB/s: 150 us per 15 360 crops); every channel is still summed over p = 0 .. hw-1 in that order: same bits
+__global__ void avgpool8_kernel(const EltArgs a) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c8 = a.c / 8;
+    if (idx >= (long)(a.n_dev ? min(a.n, a.n_dev[0]) : a.n) * c8) return;
+    const int cg = (int)(idx % c8);
+    const int img = (int)(idx / c8);
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    const half_t* src = reinterpret_cast<const half_t*>(a.src) + (size_t)img * a.h * a.w * a.s_cs + a.s_coff + 8 * cg;
+    float sum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int hw = a.h * a.w;
+#pragma unroll 4
+    for (int p = 0; p < hw; ++p) {
+        const h8 v = *reinterpret_cast<const h8*>(src + (size_t)p * a.s_cs);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sum[e] += (float)v[e];
+    }
+    h8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (half_t)(sum[e] / (float)hw);
+    *reinterpret_cast<h8*>(reinterpret_cast<half_t*>(a.dst) + (size_t)img * a.d_cs + a.d_coff + 8 * cg) = o;
+}
+
+void launch_avgpool(int dtype, const EltArgs& a, hipStream_t s) {
+    if (dtype == AIC_F16 && a.n > 0 && a.c % 8 == 0 && ((a.s_cs | a.s_coff | a.d_cs | a.d_coff) % 8) == 0) {
+        const long tot = (long)a.n * (a.c / 8);
+        hipLaunchKernelGGL(avgpool8_kernel, dim3(ceil_div(tot, 256)), dim3(256), 0, s, a);
+        KCHECK();
+        return;
+    }
+    ELT_LAUNCH(avgpool_kernel, (long)a.n * a.c);
+}
 void launch_l2norm(int dtype, const EltArgs& a, hipStream_t s) {
     if (a.n <= 0) return;
     if (dtype == AIC_F16) hipLaunchKernelGGL(l2norm_kernel<half_t>, dim3(ceil_div(a.n, 4)), dim3(256), 0, s, a);
