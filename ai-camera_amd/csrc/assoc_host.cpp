@@ -28,14 +28,22 @@ void cascade_match(int T, int N, const int* state, const int* tsu, const float* 
     }
     for (int j = 0; j < N; ++j) unmatched_d.push_back(j);
     std::vector<char> got(T, 0);
-    std::vector<float> sub;
-    std::vector<int> mr, mc, rows;
+    static thread_local std::vector<float> sub;
+    static thread_local std::vector<int> mr, mc, rows, keep, first, next;
+    static thread_local std::vector<char> dead;
+    // the confirmed tracks of every level, in track order (one pass instead of one scan of the table per level: max_age = 70 levels
+    // x 160 tracks was a fifth of this function on a crowded scene)
+    first.assign(max_age + 2, -1);
+    next.assign(T, -1);
+    for (int k = (int)confirmed.size() - 1; k >= 0; --k) {
+        const int i = confirmed[k], lv = tsu[i];
+        if (lv >= 1 && lv <= max_age) { next[i] = first[lv]; first[lv] = i; }
+    }
     // stage 1: cascade over time_since_update = 1 .. max_age, gated appearance cost
     for (int level = 0; level < max_age; ++level) {
         if (unmatched_d.empty()) break;
         rows.clear();
-        for (int i : confirmed)
-            if (tsu[i] == level + 1) rows.push_back(i);
+        for (int i = first[level + 1]; i >= 0; i = next[i]) rows.push_back(i);
         if (rows.empty()) continue;
         const int nr = (int)rows.size(), nc = (int)unmatched_d.size();
         sub.resize((size_t)nr * nc);
@@ -45,13 +53,14 @@ void cascade_match(int T, int N, const int* state, const int* tsu, const float* 
                 sub[(size_t)r * nc + c] = (maha[k] > kChi2_4) ? kInfty : app[k];   // linear_assignment.py:187-210
             }
         min_cost_matching(sub.data(), nr, nc, max_cosine_distance, mr, mc);
-        std::vector<char> dead(nc, 0);
+        if (mr.empty()) continue;                        // (nothing accepted: the unmatched list stays as it is)
+        dead.assign(nc, 0);
         for (size_t k = 0; k < mr.size(); ++k) {
             matches.emplace_back(rows[mr[k]], unmatched_d[mc[k]]);
             got[rows[mr[k]]] = 1;
             dead[mc[k]] = 1;
         }
-        std::vector<int> keep;
+        keep.clear();
         for (int c = 0; c < nc; ++c)
             if (!dead[c]) keep.push_back(unmatched_d[c]);
         unmatched_d.swap(keep);

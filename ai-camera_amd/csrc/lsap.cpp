@@ -26,16 +26,26 @@ namespace aic {
 
 namespace {
 
-struct Solver {
-    int nr, nc;            // nr <= nc
-    const double* c;       // row-major nr x nc
+struct SolverBufs {       // one set per thread: a solve allocates nothing once the vectors have grown
     std::vector<double> u, v, dist;
     std::vector<int> pred, col_of_row, row_of_col, todo;
     std::vector<char> row_seen, col_seen;
+};
 
+struct Solver {
+    int nr, nc;            // nr <= nc
+    const double* c;       // row-major nr x nc
+    std::vector<double> &u, &v, &dist;
+    std::vector<int> &pred, &col_of_row, &row_of_col, &todo;
+    std::vector<char> &row_seen, &col_seen;
+
+    static SolverBufs& bufs() { static thread_local SolverBufs b; return b; }
     Solver(int r, int cc, const double* cost)
-        : nr(r), nc(cc), c(cost), u(r, 0.0), v(cc, 0.0), dist(cc), pred(cc, -1), col_of_row(r, -1),
-          row_of_col(cc, -1), todo(cc), row_seen(r), col_seen(cc) {}
+        : nr(r), nc(cc), c(cost), u(bufs().u), v(bufs().v), dist(bufs().dist), pred(bufs().pred), col_of_row(bufs().col_of_row),
+          row_of_col(bufs().row_of_col), todo(bufs().todo), row_seen(bufs().row_seen), col_seen(bufs().col_seen) {
+        u.assign(r, 0.0), v.assign(cc, 0.0), dist.assign(cc, 0.0), pred.assign(cc, -1), col_of_row.assign(r, -1);
+        row_of_col.assign(cc, -1), todo.assign(cc, 0), row_seen.assign(r, 0), col_seen.assign(cc, 0);
+    }
 
     // Grow the alternating tree from free row `root` until it reaches an unassigned column.
     int augment_from(int root, double& reached) {
@@ -133,16 +143,54 @@ void min_cost_matching(const float* cost, int nr, int nc, double max_distance_f6
     if (nr == 0 || nc == 0) return;
     const float max_distance = (float)max_distance_f64;        // weak Python float vs float32 array
     const float clamp = (float)(max_distance_f64 + 1e-5);      // fp64 sum stored into a float32 array
-    std::vector<double> c((size_t)nr * nc);
-    std::vector<float> cf((size_t)nr * nc);
-    for (size_t k = 0; k < c.size(); ++k) {
+    // (scratch kept per thread: the cascade calls this once per level, 10-25 times per frame, on blocks of a few hundred entries)
+    static thread_local std::vector<double> c;
+    static thread_local std::vector<float> cf;
+    static thread_local std::vector<int64_t> ri, ci;
+    c.resize((size_t)nr * nc);
+    cf.resize((size_t)nr * nc);
+    bool admissible = false, odd = false;
+    for (size_t k = 0, tot = (size_t)nr * nc; k < tot; ++k) {
         float x = cost[k];
         if (x > max_distance) x = clamp;
+        else if (x <= max_distance) admissible = true;
+        else odd = true;                                       // NaN: the solver below reports it
+        if (x == -std::numeric_limits<float>::infinity()) odd = true;
         cf[k] = x;
         c[k] = (double)x;
     }
+    // Every entry above the threshold: whatever assignment the solver returned, linear_assignment.py:76 would keep none of its
+    // pairs (each costs `clamp` > max_distance).  The answer is the empty matching; the solve is skipped.
+    if (!admissible && !odd) return;
+    // Unique optimum read off the rows (nr <= nc, the cascade's usual shape): if every row that has an entry <= max_distance has a
+    // STRICT row minimum and those minima sit in pairwise different columns, the sum of the row minima is attained (rows without an
+    // admissible entry cost `clamp` in any column, and there are columns enough), so EVERY optimal assignment -- SciPy's included --
+    // gives each such row exactly that column, and :76 keeps exactly those pairs, in row order.  A tie anywhere: the solver decides.
+    if (!odd && nr <= nc) {
+        static thread_local std::vector<int> arg, owner;
+        arg.assign(nr, -1);
+        owner.assign(nc, -1);
+        bool unique = true;
+        for (int r = 0; r < nr && unique; ++r) {
+            const float* row = cf.data() + (size_t)r * nc;
+            float best = row[0];
+            int at = 0, ties = 0;
+            for (int k = 1; k < nc; ++k) {
+                if (row[k] < best) { best = row[k]; at = k; ties = 0; }
+                else if (row[k] == best) ++ties;
+            }
+            if (best > max_distance) continue;               // no admissible entry: this row ends up unmatched either way
+            if (ties || owner[at] >= 0) unique = false;
+            else { owner[at] = r; arg[r] = at; }
+        }
+        if (unique) {
+            for (int r = 0; r < nr; ++r)
+                if (arg[r] >= 0) { mrow.push_back(r); mcol.push_back(arg[r]); }
+            return;
+        }
+    }
     const int n = std::min(nr, nc);
-    std::vector<int64_t> ri(n), ci(n);
+    ri.resize(n), ci.resize(n);
     const int rc = lsap_solve(c.data(), nr, nc, ri.data(), ci.data());
     AIC_REQUIRE(rc == 0, AIC_ERR_INVALID, "cost matrix contains NaN/-inf or is infeasible");
     for (int k = 0; k < n; ++k) {

@@ -123,11 +123,11 @@ void Tracker::resolve_pending(bool need_sync) {
 
 namespace {
 struct TrkTimes {
-    double prep = 0, gpu = 0, host = 0, commit = 0; long n = 0;
+    double prep = 0, gpu = 0, host = 0, commit = 0, copy = 0, cascade = 0; long n = 0;
     bool on = getenv("AICAM_TRK_TIMES") != nullptr;
     ~TrkTimes() {
-        if (on && n) fprintf(stderr, "[trk_times] frames %ld: prep+launch %.1f us, wait for the association rows %.1f, host match+lifecycle %.1f, commit issue %.1f\n",
-                             n, 1e6 * prep / n, 1e6 * gpu / n, 1e6 * host / n, 1e6 * commit / n);
+        if (on && n) fprintf(stderr, "[trk_times] frames %ld: prep+launch %.1f us, wait for the association rows %.1f, host match+lifecycle %.1f (of which: previous outputs + copy of the rows %.1f, cascade %.1f), commit issue %.1f\n",
+                             n, 1e6 * prep / n, 1e6 * gpu / n, 1e6 * host / n, 1e6 * copy / n, 1e6 * cascade / n, 1e6 * commit / n);
     }
     static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 } g_trk_times;
@@ -268,11 +268,13 @@ void Tracker::update(const float* det_tlwh, const float* conf, const int32_t* cl
     }
 
     resolve_pending(true);                     // (no-op when the sync above already resolved it)
+    const double tt2a = g_trk_times.on ? TrkTimes::now() : 0.0;
 
     // ---- host: association
     std::vector<std::pair<int, int>> matches;
     std::vector<int> un_t, un_d;
     match(T, n, last_app.data(), last_maha.data(), last_iou.data(), matches, un_t, un_d);
+    if (g_trk_times.on) { const double tt2b = TrkTimes::now(); g_trk_times.copy += tt2a - tt2, g_trk_times.cascade += tt2b - tt2a; }
     last_matches.clear();
     for (auto& m : matches) last_matches.emplace_back(tracks[m.first].id, m.second);
 

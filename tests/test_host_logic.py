@@ -98,6 +98,50 @@ def test_min_cost_matching_matches_reference_fixtures(lib, golden):
     assert la.min_cost_matching(lambda *a: cost, 0.2, None, None, [], [0, 1]) == ([], [], [0, 1])
 
 
+def test_min_cost_matching_shortcuts_vs_scipy(lib):
+    """min_cost_matching (csrc/lsap.cpp) answers without the solver when every entry is above the threshold (empty matching) and when
+    the optimum can be read off the rows (strict row minima in pairwise different columns).  Both must give what SciPy's assignment
+    followed by linear_assignment.py:70-88 gives -- on matrices built to sit on both sides of each shortcut: unique minima, tied
+    minima, two rows wanting one column, rows without an admissible entry, wide / square / tall shapes, quantised costs."""
+    rng = np.random.default_rng(23)
+    hits = {"empty": 0, "some": 0}
+    for it in range(6000):
+        nr, nc = (int(v) for v in rng.integers(1, 28, 2))
+        kind = it % 6
+        thr = 0.2 if it % 2 else 0.7
+        if kind == 0:                                    # mostly above the threshold, a few admissible entries
+            m = rng.uniform(thr + 0.01, 1.0, (nr, nc))
+            for _ in range(int(rng.integers(0, min(nr, nc) + 1))):
+                m[rng.integers(nr), rng.integers(nc)] = rng.uniform(0, thr)
+        elif kind == 1:                                  # a planted permutation of clear minima (the crowded cascade's usual case)
+            m = rng.uniform(thr + 0.05, 1.0, (nr, nc))
+            k = min(nr, nc)
+            for r, c in zip(rng.permutation(nr)[:k], rng.permutation(nc)[:k]):
+                if rng.uniform() < 0.8: m[r, c] = rng.uniform(0, thr)
+        elif kind == 2:                                  # quantised: ties everywhere
+            m = np.round(rng.uniform(0, 2 * thr, (nr, nc)), 1)
+        elif kind == 3:                                  # two rows compete for one column
+            m = rng.uniform(thr + 0.05, 1.0, (nr, nc))
+            c = int(rng.integers(nc))
+            m[rng.integers(nr), c] = 0.05
+            m[rng.integers(nr), c] = 0.06
+            if nc > 1: m[rng.integers(nr), (c + 1) % nc] = 0.07
+        elif kind == 4:                                  # nothing admissible at all
+            m = rng.uniform(thr + 1e-3, 5.0, (nr, nc))
+        else:
+            m = rng.uniform(0, 1, (nr, nc))
+        m = m.astype(np.float32)
+        mr, mc, nm = np.zeros(32, np.int32), np.zeros(32, np.int32), np.zeros(1, np.int32)
+        lib.call("aic_min_cost_matching", lib.ptr(m), nr, nc, float(thr), lib.ptr(mr), lib.ptr(mc), lib.ptr(nm))
+        c = m.copy()
+        c[c > thr] = thr + 1e-5                          # linear_assignment.py:59 (float32 array, Python-float threshold)
+        ri, ci = scipy_lsa(c)
+        keep = c[ri, ci] <= thr                          # :76
+        assert mr[:nm[0]].tolist() == ri[keep].tolist() and mc[:nm[0]].tolist() == ci[keep].tolist(), (it, kind, m.shape)
+        hits["some" if nm[0] else "empty"] += 1
+    assert hits["empty"] > 500 and hits["some"] > 2000
+
+
 def test_match_cascade_matches_oracle(lib):
     """aic_match_cascade (csrc/assoc_host.cpp) vs the oracle cascade on random frames with ties, gated entries, tentative /
     confirmed / stale tracks and empty sides (linear_assignment.py:91-157, tracker_core.py:83-177)."""
