@@ -348,6 +348,18 @@ __global__ __launch_bounds__(512) void conv3x3_pp_patch_kernel(const ConvArgs a,
     constexpr int EOFF = RING + NSTAGE * WSTAGE, NE = BM / 128;        // second source: buffer offset, LDS-DMA passes per chunk
     static_assert(WM * WN == 8 && BM % TPIX == 0 && NPASS <= 11 - NSTAGE && TW % 4 == 0 && NSTAGE >= 4, "geometry");
     static_assert(!X2 || (NSTAGE == 4 && NPASS <= 5 && (NE == 2 || NE == 4) && MT % 2 == 0), "second source: slots at taps 6..8, counted waits of the 4-stage ring");
+    // LEAN (4-stage ring, no second source): a LOAD segment whose tap has no patch pass due issues its weight loads only.  The form before
+    // kept every segment at B_PER + 1 loads with a zero-page load into a dummy slot, so that ONE counted wait fitted all taps; an LDS-DMA
+    // costs 60-185 cycles to issue, 9 - NPASS of a chunk's nine were stand-ins, and a wave's LOAD and COMPUTE segments are serial.  The
+    // wait of a segment still lets exactly its OWN loads stay in flight -- B_PER or B_PER + 1, a compile-time property of the tap.
+    // Measured: nothing (layer2 / 3 / 4 shapes against the build before both changes, same box each: +2.4 / +1.8 / +1.8 % with the cheaper
+    // integer work of issue_patch AND this, +2.5 / +1.6 / +1.7 % with the integer work alone): a zero-page LDS-DMA is cheap to issue after
+    // all.  Kept as a build switch (-DAICAM_PPP_LEAN), off.
+#if defined(AICAM_PPP_LEAN) && !defined(AICAM_PPP_PF_BUILD)
+    constexpr bool LEAN = !X2 && NSTAGE == 4;
+#else
+    constexpr bool LEAN = false;
+#endif
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -385,13 +397,20 @@ __global__ __launch_bounds__(512) void conv3x3_pp_patch_kernel(const ConvArgs a,
     // room for them) instead of living in NPASS registers: with the tile loop around it the kernel has no register to spare, and every
     // spilled value reloaded after an epilogue is an s_waitcnt vmcnt(0) -- 8 us per tile on the 512 x 128 tile.
     char* const pdst = smem + plane * PLANE + (wv >> 2) * 1024;     // + buffer*PBUF + pass*2048 (+ lane*16 by the DMA)
+    // (integer work of a pass, per thread: the two divisions by compile-time constants as ONE 24-bit multiply + shift each -- exact for
+    //  p < 1024 and divisors >= 4, checked below -- and the three multiplications of the address as 24-bit ones: a 32-bit v_mul_lo /
+    //  v_mul_hi / v_mad_u64 is a quarter-rate instruction, there were eleven of them per pass, and a LOAD segment shares its SIMD's VALU
+    //  port with the other half's MFMAs.  launch_pp_patch admits only tensors whose pixel count and strides fit 24 bits.)
+    static_assert(NPIXP <= 1024 && PW >= 4 && IPIXP >= 4, "udiv24 range");
+    auto udiv24 = [](int x, auto dc) { constexpr int D = decltype(dc)::value; constexpr unsigned M = (1u << 24) / D + 1u; return (int)(__umul24((unsigned)x, M) >> 24); };
     auto issue_patch = [&](int i, int buf, int chunk_off, int im0, int oy, int ox) {        // i: compile-time pass index; tile (im0, oy, ox)
         const int p = i * 128 + (wv >> 2) * 64 + lane_here();
-        const int il = p / IPIXP, rem = p - il * IPIXP;
-        const int py = rem / PW, px = rem - py * PW;
+        int il = 0, rem = p;
+        if constexpr (NI > 1) { il = udiv24(p, std::integral_constant<int, IPIXP>{}); rem = p - __mul24(il, IPIXP); }
+        const int py = udiv24(rem, std::integral_constant<int, PW>{}), px = rem - __mul24(py, PW);
         const int img = im0 + il, iy = oy + py - 1, ix = ox + px - 1;
         const bool ok = p < NPIX && rem < IPIX && img < n_img && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-        const T* src = ok ? xg + (((img * a.H + iy) * a.W + ix) * a.x_cs + a.x_coff + plane * CH + chunk_off) : zero;
+        const T* src = ok ? xg + (__mul24(__mul24(__mul24(img, a.H) + iy, a.W) + ix, a.x_cs) + a.x_coff + plane * CH + chunk_off) : zero;
         asm volatile("" : "+v"(src));
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(pdst + buf * PBUF + i * 2048), 16, 0, 0);
     };
@@ -506,9 +525,10 @@ __global__ __launch_bounds__(512) void conv3x3_pp_patch_kernel(const ConvArgs a,
 #pragma unroll
     for (int st = 0; st < NSTAGE - 2; ++st) {
         issue_w();
-        if (st) issue_dummy();                 // every set in flight has LPS loads: the counted waits below rely on it
+        if (st && !LEAN) issue_dummy();        // (not LEAN) every set in flight has LPS loads: the counted waits below rely on it
     }
-    wait_vmcnt<(NSTAGE - 3) * LPS>();          // patch chunk 0 and the weights of step 0 have landed (this wave's part)
+    if constexpr (LEAN) wait_vmcnt<B_PER>();   // patch chunk 0 and the weights of step 0 have landed (this wave's part): only step 1's weights may be in flight
+    else wait_vmcnt<(NSTAGE - 3) * LPS>();
     __builtin_amdgcn_s_barrier();
     PP_STAMP(1);
 
@@ -528,8 +548,11 @@ __global__ __launch_bounds__(512) void conv3x3_pp_patch_kernel(const ConvArgs a,
             il = (tl / TH) * G + rr / TW, ly = tl % TH, lx = rr % TW;
         }
         const int img = img0 + il;
-        const T* src = (on && img < n_img) ? reinterpret_cast<const T*>(a.x2) + (((long)img * a.H2 + (oy0 + ly) * a.s2) * a.W2 + (ox0 + lx) * a.s2) * a.x2_cs +
-                                                 a.x2_coff + e * BKE + kcl * CH
+        // (24-bit multiplies, as in issue_patch: row of the second source < 2^23, element offset < 2^31 -- launch_pp_patch checks both;
+        //  the 64-bit form was three quarter-rate multiplies per thread and pass)
+        const int row2 = __mul24(img, a.H2) + __mul24(oy0 + ly, a.s2);
+        const T* src = (on && img < n_img) ? reinterpret_cast<const T*>(a.x2) + (__mul24(row2, a.W2 * a.x2_cs) + __mul24(__mul24(ox0 + lx, a.s2), a.x2_cs) +
+                                                                                 a.x2_coff + e * BKE + kcl * CH)
                                            : zero;
         asm volatile("" : "+v"(src));
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + EOFF + p * 8192 + (16 * wv) * 64), 16, 0, 0);
@@ -579,17 +602,22 @@ __global__ __launch_bounds__(512) void conv3x3_pp_patch_kernel(const ConvArgs a,
             for (int i = 0; i < MT; ++i) xf[i] = *reinterpret_cast<const frag_t*>(smem + xa0 + tapoff + patch_pix(16 * i) * 16);
             __builtin_amdgcn_sched_barrier(0);
             issue_w();
-            if (tap >= 1 && tap <= NPASS && more) issue_patch(tap >= 1 && tap <= NPASS ? tap - 1 : 0, BUF ^ 1, noff, p_im, p_oy, p_ox);
-            else if constexpr (!EP) {
+            constexpr bool SLOT = tap >= 1 && tap <= NPASS;          // this tap's segment carries a patch pass
+            if (SLOT && more) issue_patch(SLOT ? tap - 1 : 0, BUF ^ 1, noff, p_im, p_oy, p_ox);
+            else if constexpr (!EP && (SLOT || !LEAN)) {              // LEAN: a tap without a pass issues NO stand-in (its wait is one lower)
+#ifdef AICAM_PPP_PF_BUILD                               // (the residual prefetch experiment: measured, no net gain; not in the default build's K loop)
                 if (!X2 && !inner && ((pf >> tap) & 1)) issue_res(__builtin_popcount(pf & ((1 << tap) - 1)));
-                else issue_dummy();
+                else
+#endif
+                issue_dummy();
             }
             if constexpr (EP) {
                 if constexpr (NE == 4) {
                     if (tap == 6) { issue_e(0, c, c < ns2); issue_e(1, c, c < ns2); } else issue_e(tap - 5, c, c < ns2);
                 } else issue_e(tap - 7, c, c < ns2);
             }
-            if constexpr (X2 && NE == 4 && tap == 6) wait_vmcnt<(NSTAGE - 3) * LPS + 1>();
+            if constexpr (LEAN) wait_vmcnt<B_PER + (SLOT ? 1 : 0)>();         // everything older than THIS segment's own loads has landed
+            else if constexpr (X2 && NE == 4 && tap == 6) wait_vmcnt<(NSTAGE - 3) * LPS + 1>();
             else wait_vmcnt<(NSTAGE - 3) * LPS>();
             __builtin_amdgcn_s_barrier();
             // ---- COMPUTE segment
@@ -654,6 +682,9 @@ static bool launch_pp_patch(const ConvArgs& a, hipStream_t s) {
     constexpr size_t lds = (size_t)2 * 4 * NPASS * 128 * 16 + 8192 + (size_t)NSTAGE * BNP * 64 + (X2 ? BM * 64 : 0);
     static_assert(lds <= 160 * 1024, "does not fit the LDS");
     if (a.H % TH || a.W % TW || a.Ho != a.H || a.Wo != a.W) return false;
+    if (a.M >= (1 << 23) || a.x_cs >= (1 << 23) || (long)a.M * a.x_cs >= (1l << 31)) return false;      // issue_patch's 24-bit address arithmetic
+    if (X2 && ((long)(a.M / (a.Ho * a.Wo)) * a.H2 >= (1 << 23) || (long)a.W2 * a.x2_cs >= (1 << 23) ||
+               (long)(a.M / (a.Ho * a.Wo)) * a.H2 * a.W2 * a.x2_cs >= (1l << 31))) return false;                // issue_e's
     const int tiles_x = a.W / TW, tiles_y = a.H / TH;
     const int n_img = a.M / (a.Ho * a.Wo);
     auto kfn = conv3x3_pp_patch_kernel<T, MT, NT, WM, WN, TH, TW, NSTAGE, X2>;
