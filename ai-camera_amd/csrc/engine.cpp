@@ -376,37 +376,6 @@ Model::Model(Device& d, const void* blob, size_t nbytes, int dtype_, int max_ite
             if (!other_reader) ops[i].fuse = 3;          // the follower keeps fuse = 0: it runs on its own whenever the lead cannot take it
         }
     }
-    // ---- fusion: a 32-channel C2f bottleneck (3x3 32 -> 32 SiLU, then 3x3 32 -> 32 SiLU + the first conv's input; YOLOv8n's 80 x 80 C2f
-    // blocks) as ONE kernel that never writes the intermediate (kernels_conv_bneck.hip).  Marked here when the value the first conv
-    // writes has no reader but the second: the bottlenecks of a C2f share one intermediate buffer, each pair rewriting it, so "no other
-    // reader of the BUFFER" would refuse them all -- what must hold is that nobody reads it between this pair and its next full rewrite.
-    if (dtype == AIC_F16 && !getenv("AICAM_NO_FUSE")) {                 // (conv_try_bneck32 itself is opt-in: AICAM_BNECK=1)
-        auto overlap = [](int a0, int an, int b0, int bn) { return a0 < b0 + bn && b0 < a0 + an; };
-        for (size_t i = 0; i + 1 < ops.size(); ++i) {
-            const int* c = ops[i].v;
-            const int* p = ops[i + 1].v;
-            if (c[0] != OP_CONV || p[0] != OP_CONV || ops[i].fuse || ops[i + 1].fuse || ops[i].xs_buf >= 0 || ops[i + 1].xs_buf >= 0 || c[16] || p[16]) continue;
-            auto k3 = [](const int* u) { return u[3] == 32 && u[6] == 32 && u[7] == 3 && u[8] == 3 && u[9] == 1 && u[10] == 1 && u[11] == 1; };
-            if (!k3(c) || !k3(p) || c[14] != 0 || (p[14] != 2 && p[14] != 0)) continue;
-            if (p[1] != c[4] || p[2] != c[5] || (p[14] == 2 && (p[12] != c[1] || p[13] != c[2]))) continue;   // second reads the first's output (and adds the first's input)
-            if (bufs[c[4]].f32 || bufs[p[4]].f32 || c[4] == p[4]) continue;
-            const int B = c[4], b0 = c[5];
-            bool ok = true;
-            for (auto& o : outs)
-                if (o.v[0] == B || (kind == KIND_YOLO && o.v[1] == B)) ok = false;
-            for (size_t k = i + 2; k < ops.size() && ok; ++k) {
-                if (ops[k].fuse == 2) continue;
-                const int* u = ops[k].v;
-                const int rc = (u[0] == OP_CONV && u[3] == 3) ? 8 : u[3];
-                if (u[1] == B && overlap(u[2], rc, b0, 32)) ok = false;                              // a later reader of the value
-                if (u[0] == OP_CONV && u[14] && u[12] == B && overlap(u[13], u[6], b0, 32)) ok = false;
-                if (ops[k].xs_buf == B) ok = false;
-                if (u[0] == OP_CONV && u[16] && u[16] - 1 == B) ok = false;
-                if (ok && u[0] == OP_CONV && u[4] == B && u[5] == b0 && u[6] >= 32) break;          // rewritten in full: whoever reads after this reads that
-            }
-            if (ok) ops[i].fuse = 4;                       // the second conv keeps fuse = 0: it runs on its own whenever the pair cannot fuse
-        }
-    }
     {   // sub-batching plan: the maximal prefix of ops whose outputs are >= min_kb per item
         const char* e_items = getenv("AICAM_SB_ITEMS");
         const char* e_kb = getenv("AICAM_SB_MINKB");
@@ -578,16 +547,6 @@ void Model::run_range(size_t op0, size_t op1, int i0, int n, hipStream_t s) {
                 }
                 fl = fl0, by = by0;
             }
-            if (o.fuse == 4 && oi + 1 < op1 && ops[oi + 1].fuse == 0) {       // a 32-channel bottleneck (marked at load time) as one kernel
-                const double fl0 = fl, by0 = by;
-                const ConvArgs b2 = conv_args(oi + 1);
-                if (conv_try_bneck32(a, b2, s)) {
-                    if (prof_conv) dev->prof_account(PROF_CONV, fl, by);
-                    ++oi;
-                    continue;
-                }
-                fl = fl0, by = by0;
-            }
             if (pair && conv_try_c64_block(a, a2, s)) {
                 if (prof_conv) dev->prof_account(PROF_CONV, fl, by);
                 ++oi;
@@ -607,7 +566,7 @@ void Model::run_range(size_t op0, size_t op1, int i0, int n, hipStream_t s) {
                     static const bool box_decode_on = getenv("AICAM_NO_BOX_DECODE") == nullptr;
                     if (reduce_cls && kind == KIND_YOLO && t.out_f32 && t.act == 0 && t.y_coff == 0 && t.y_cs == t.Cout) {
                         // a detect level's class / box branch: its logits only feed decode's arg-max / DFL expectation
-                        const bool is_cls = cls_reduce_on && t.Cout == meta[0], is_box = box_decode_on && meta[1] == 16 && t.Cout == 64 && !is_cls;
+                        const bool is_cls = cls_reduce_on && t.Cout == meta[0], is_box = box_decode_on && meta[1] == 16 && t.Cout == 64 && a.Cout == 64 && !is_cls;   // tail_1x1 decodes in place only in its NT == 4 form (lead Cout 64; YOLOv8x leads with 80)
                         int a0 = 0;
                         for (size_t l = 0; l < outs.size() && (is_cls || is_box); ++l) {
                             const int* ov = outs[l].v;

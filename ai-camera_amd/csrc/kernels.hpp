@@ -84,9 +84,6 @@ bool conv_try_c64_block(const ConvArgs& c1, const ConvArgs& c2, hipStream_t s);
 // a whole C2f block with 16-channel halves (cv1 1x1 32->32, m.cv1 / m.cv2 3x3 16->16 with shortcut, cv2 1x1 48->32) in one fp16 kernel,
 // concat buffer and intermediate in LDS (kernels_conv_c2f.hip); false = pattern / geometry not supported, nothing launched
 bool conv_try_c2f16(const ConvArgs& cv1, const ConvArgs& m_cv1, const ConvArgs& m_cv2, const ConvArgs& cv2, hipStream_t s);
-// a 32-channel C2f bottleneck (3x3 32 -> 32 SiLU, 3x3 32 -> 32 SiLU + the first conv's input) in one fp16 kernel, the intermediate in LDS
-// (kernels_conv_bneck.hip); false = pattern / geometry not supported, nothing launched
-bool conv_try_bneck32(const ConvArgs& m_cv1, const ConvArgs& m_cv2, hipStream_t s);
 
 // letterbox + conv 3x3/2 (3->16) + SiLU fused (fp16 YOLOv8 stem); false = geometry not supported, nothing launched
 struct LetterboxGeom;

@@ -83,7 +83,7 @@ struct Pipeline {
     Lane lane[2];
     std::unique_ptr<Model> yolo2, reid2;
     int dual_max = [] { const char* e = getenv("AICAM_DUAL_MAX"); return e ? atoi(e) : 128; }();   // aic_pipeline_option("dual_lane_frames")
-    long n_lane1_groups = 0;
+    long n_lane1_groups = 0, n_lane1_failed = 0;
     static constexpr int NCK = 2;   // launch groups in flight. 4 was measured: the GPU never idles, but the tracker chain then queues behind more conv work (84 -> 106 us/frame) and becomes the bound
     Chunk ck[NCK];
     int dim;
@@ -385,6 +385,10 @@ struct Pipeline {
         if (nc) {
             HIP_CHECK(hipMemcpyAsync(c.d_boxes.p, c.h_boxes.p, (size_t)nc * 16, hipMemcpyHostToDevice, sr));
             HIP_CHECK(hipMemcpyAsync(c.d_frame_of.p, c.h_frame_of.p, (size_t)nc * 4, hipMemcpyHostToDevice, sr));
+            // the engine's host-side launch state (in_pix4, crop_src, n_items_dev) is shared with the consumer thread, which may be running
+            // the overflow rounds of a device-filtered group of the OTHER chunk context on the same Model (the filter is chosen per group
+            // since round 4: a device-filtered group k and a host-filtered group k + 1 can be in flight together)
+            std::lock_guard<std::mutex> lk(reid_mu);
             c.ln->reid->in_pix4 = c.ln->reid->input_pix4_ok();
             static const bool fuse_crop = getenv("AICAM_NO_FUSE_CROP") == nullptr;
             for (int c0 = 0; c0 < nc; c0 += c.ln->reid->max_items) {   // more crops than the ReID arena holds: several launch groups, nothing dropped
@@ -717,9 +721,19 @@ struct Pipeline {
             bool any = false;
             for (int k = 0; k < nchunks; ++k)
                 if ((k & 1) && glen[k] <= std::min(dual_max, yolo->max_items) && glen[k] * prm.max_persons <= reid->max_items) { glane[k] = 1; any = true; }
-            if (any) ensure_lane1();
+            if (any) {
+                try {
+                    ensure_lane1();
+                } catch (const std::exception&) {        // e.g. no memory for second arenas: one lane does everything, as before round 4
+                    yolo2.reset(), reid2.reset();
+                    lane[1] = Lane{};
+                    dual_max = 0;
+                    n_lane1_failed += 1;
+                    (void)hipGetLastError();
+                }
+            }
             for (int k = 0; k < nchunks; ++k)
-                if (glane[k] && (glen[k] > yolo2->max_items)) glane[k] = 0;
+                if (glane[k] && (!lane[1].yolo || glen[k] > yolo2->max_items)) glane[k] = 0;
         }
         group_times.clear();
         submit_t.assign(nchunks, 0.0);
@@ -1014,7 +1028,10 @@ int aic_pipeline_option(aic_pipeline* p, const char* key, int value) {
     return guarded([&] {
         AIC_REQUIRE(p && key, AIC_ERR_INVALID, "NULL argument");
         const std::string k(key);
-        if (k == "taper") p->p.taper = value != 0;
+        if (k == "taper") {                          // like AICAM_NO_TAPER: 0 switches the tail taper AND the head ramp off ("head_ramp" sets the ramp alone)
+            p->p.taper = value != 0;
+            if (!value) p->p.head_ramp = false;
+        }
         else if (k == "split_streams") p->p.split_streams = value != 0;
         else if (k == "device_assoc") {
             AIC_REQUIRE(value >= 0 && value <= 2, AIC_ERR_INVALID, "device_assoc: 0 host, 1 auto, 2 always on the device");

@@ -100,13 +100,30 @@ def gpu_numa_node(dev: int):
     return (nodes[dev] if dev < len(nodes) else -1), None
 
 
-def bind_rank_to_gpu_numa(local_rank: int, world: int):
-    """os.sched_setaffinity for this process (and every thread it starts later): the allowed cores of the GPU's NUMA node,
-    split among the ranks that share the node; without NUMA information an even slice of the allowed cores.  Call first thing in a
-    rank.  The PCI bus ids come from the HIP runtime's own enumeration (gpu_numa_node -> torch.cuda.get_device_properties), so with
-    world > 1 this call DOES initialise the runtime: its helper threads exist before the affinity is set (they are not on any hot
-    path; every thread started afterwards -- producer, consumer, exchange -- inherits the binding), and NO exec / relaunch may
-    follow it in this process.  Returns a description for the bench line; never raises (a rehearsal on a laptop must still run)."""
+def _bind_all_threads(cores):
+    """sched_setaffinity for EVERY thread this process already has (the HIP runtime's and RCCL's helpers exist by the time the ranks can
+    talk to each other) and, by inheritance, every thread started later (producer, consumer, exchange)."""
+    os.sched_setaffinity(0, cores)
+    try:
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                os.sched_setaffinity(int(tid), cores)
+            except (OSError, ValueError):
+                pass          # a thread that ended meanwhile
+    except OSError:
+        pass
+
+
+def bind_rank_to_gpu_numa(local_rank: int, world: int, device=None, gather=None):
+    """CPU affinity of this rank: the allowed cores of ITS GPU's NUMA node, split among the ranks that share the node; without NUMA
+    information an even slice of the allowed cores.  A rank asks the HIP runtime about ONE device only -- its own (`device`, default
+    local_rank) -- so that no rank ever touches the other seven GPUs of the node (the first version queried every
+    device from every rank).  Which ranks share a NUMA node comes from `gather`, a callable that all-gathers one small Python object
+    over the ranks (bench.py passes torch.distributed.all_gather_object once the process group exists); without it (a library user
+    who binds before any rendezvous) the other ranks' nodes are the sysfs bus-order guess of gpu_numa_nodes().  Every existing thread
+    of the process is bound, not just the caller, so the call may come after the runtime and the communicator started their helpers.
+    NO exec / relaunch may follow it in this process.  Returns a description for the bench line; never raises (a rehearsal on a
+    laptop must still run)."""
     try:
         allowed = sorted(os.sched_getaffinity(0))
     except AttributeError:
@@ -114,9 +131,14 @@ def bind_rank_to_gpu_numa(local_rank: int, world: int):
     if world <= 1 and os.environ.get("AICAM_BIND_SINGLE") is None:
         return {"bound": False, "cores": len(allowed), "reason": "single rank: the cores the box grants are all ours"}
     try:
-        per_rank = [gpu_numa_node(r) for r in range(world)]        # rank r runs on HIP device r of this node (one process per GPU)
-        nodes = [n for n, _ in per_rank]
-        node, bus = per_rank[local_rank] if local_rank < len(per_rank) else (-1, None)
+        node, bus = gpu_numa_node(local_rank if device is None else int(device))      # this rank's own GPU: the only runtime query
+        if gather is not None:
+            nodes = [int(n) for n in gather(int(node))]                                # one entry per rank, in rank order
+        else:
+            guess = gpu_numa_nodes()
+            nodes = [guess[r] if r < len(guess) else -1 for r in range(world)]
+            if local_rank < len(nodes):
+                nodes[local_rank] = node
         mine, sharers, my_pos = allowed, world, local_rank
         if node >= 0:
             cl = set(_cpulist(open(f"/sys/devices/system/node/node{node}/cpulist").read()))
@@ -126,8 +148,9 @@ def bind_rank_to_gpu_numa(local_rank: int, world: int):
                 mine, sharers, my_pos = local, max(len(same), 1), same.index(local_rank) if local_rank in same else 0
         per = max(1, len(mine) // sharers)
         cores = mine[my_pos * per:(my_pos + 1) * per] or mine
-        os.sched_setaffinity(0, cores)
-        return {"bound": True, "numa_node": node, "pci_bus_id": bus, "cores": len(cores), "first_core": cores[0], "last_core": cores[-1]}
+        _bind_all_threads(cores)
+        return {"bound": True, "numa_node": node, "pci_bus_id": bus, "cores": len(cores), "first_core": cores[0], "last_core": cores[-1],
+                "ranks_on_this_node": sharers, "nodes_from": "all-gather over the ranks" if gather is not None else "sysfs bus order (no rendezvous yet)"}
     except Exception as e:            # noqa: BLE001 -- placement is an optimisation, never a failure
         return {"bound": False, "reason": str(e)}
 

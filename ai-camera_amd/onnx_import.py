@@ -37,7 +37,7 @@ from . import engine_file as ef
 from . import import_weights as iw
 
 # ------------------------------------------------------------------------------------------------ protobuf wire format
-_FLOAT, _INT64 = 1, 7          # TensorProto.DataType
+_FLOAT, _INT64, _FLOAT16 = 1, 7, 10          # TensorProto.DataType
 _ATTR_FLOAT, _ATTR_INT, _ATTR_STRING, _ATTR_TENSOR, _ATTR_FLOATS, _ATTR_INTS = 1, 2, 3, 4, 6, 7
 
 
@@ -89,7 +89,7 @@ def _packed_varints(v):
 
 
 def _tensor(buf):
-    dims, dtype, name, raw, floats, int64s = [], 0, "", None, [], []
+    dims, dtype, name, raw, floats, int64s, int32s = [], 0, "", None, [], [], []
     for f, wt, v in _fields(buf):
         if f == 1:
             dims.extend(_packed_varints(v) if wt == 2 else [_signed(v)])
@@ -97,6 +97,8 @@ def _tensor(buf):
             dtype = v
         elif f == 4:
             floats.extend(np.frombuffer(bytes(v), "<f4").tolist() if wt == 2 else [struct.unpack("<f", v)[0]])
+        elif f == 5:                           # int32_data: where a FLOAT16 tensor without raw_data keeps its bit patterns
+            int32s.extend(_packed_varints(v) if wt == 2 else [v])
         elif f == 7:
             int64s.extend(_packed_varints(v) if wt == 2 else [_signed(v)])
         elif f == 8:
@@ -107,6 +109,8 @@ def _tensor(buf):
         arr = np.frombuffer(raw, "<f4") if raw is not None else np.asarray(floats, np.float32)
     elif dtype == _INT64:
         arr = np.frombuffer(raw, "<i8") if raw is not None else np.asarray(int64s, np.int64)
+    elif dtype == _FLOAT16:                    # half exports (`yolo export format=onnx half=True`): widened once, exactly
+        arr = (np.frombuffer(raw, "<f2") if raw is not None else np.asarray(int32s, np.uint16).view(np.float16)).astype(np.float32)
     else:
         arr = np.zeros(0, np.float32)          # other dtypes are never weights of these graphs
     if dims and arr.size == int(np.prod(dims)):
@@ -359,8 +363,8 @@ def _s(fno, text):
 
 def _enc_tensor(name, arr):
     arr = np.ascontiguousarray(arr)
-    dt = _FLOAT if arr.dtype == np.float32 else _INT64
-    out = b"".join(_vi(1, int(d)) for d in arr.shape) + _vi(2, dt) + _s(8, name) + _ld(9, arr.astype("<f4" if dt == _FLOAT else "<i8").tobytes())
+    dt = {np.dtype(np.float32): _FLOAT, np.dtype(np.float16): _FLOAT16}.get(arr.dtype, _INT64)
+    out = b"".join(_vi(1, int(d)) for d in arr.shape) + _vi(2, dt) + _s(8, name) + _ld(9, arr.astype({_FLOAT: "<f4", _FLOAT16: "<f2"}.get(dt, "<i8")).tobytes())
     return out
 
 
@@ -389,12 +393,18 @@ def _enc_value_info(name, dims):
     return _s(1, name) + _ld(2, _ld(1, ttype))
 
 
-def export_onnx(g: ef.Graph, nms=None, module_names=True, fold_bn=True) -> bytes:
+def export_onnx(g: ef.Graph, nms=None, module_names=True, fold_bn=True, half=False) -> bytes:
     """Engine graph -> ONNX ModelProto bytes.  module_names: initializers carry the source module paths (else anonymous
     `onnx::Conv_<n>` like a BN-folding exporter); fold_bn=False: every activated conv is followed by an identity-statistics
     BatchNormalization node (the reader must fold it); nms: dict(score_threshold, iou_threshold, max_output_boxes) appends an
-    EfficientNMS_TRT node with the four outputs the reference detector reads."""
+    EfficientNMS_TRT node with the four outputs the reference detector reads; half: conv weights and biases as FLOAT16 initializers
+    (a half-precision export)."""
     yolo = g.kind == ef.KIND_YOLO
+    if half:
+        assert fold_bn, "half export is written with folded BatchNorm"
+        g_weights = [(w.astype(np.float16), b.astype(np.float16)) for w, b in g.weights]
+    else:
+        g_weights = g.weights
     nodes, inits = [], []
     produced = {}                                   # buffer -> sorted list of (coff, channels, tensor name)
 
@@ -427,7 +437,7 @@ def export_onnx(g: ef.Graph, nms=None, module_names=True, fold_bn=True) -> bytes
     for oi, o in enumerate(g.ops):
         typ, sb, sc, cin, db, dc, cout, kh, kw, st, pad, act, rb, rc, rmode, wi = o[:16]
         if typ == ef.OP_CONV:
-            w, b = g.weights[wi]
+            w, b = g_weights[wi]
             nm = g.names[wi]
             if yolo:
                 prefix, has_bn = iw.yolo_key(nm)

@@ -203,13 +203,11 @@ def launch_ranks(n):
     """`python bench.py --gpus N` with N > 1 and no torchrun around it: start `python -m torch.distributed.run --nproc-per-node N bench.py
     <same arguments>` as a CHILD process, forward its output (rank 0's one JSON line) and return its exit code.  This process has made
     no GPU call (no HIP library loaded, torch not even imported), and it does not exec: it waits for the child."""
-    import socket
     import subprocess
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # --standalone: torchrun's own c10d rendezvous on a port IT picks and keeps (a port found here by bind(0) + close could be taken by
+    # another bench starting on the same box before torchrun binds it; ADVICE r4)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", "--nproc-per-node", str(n),
+           os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: what RCCL needs on this pool
     env.setdefault("OMP_NUM_THREADS", "1")
@@ -231,15 +229,12 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus} "
                          f"(or without it: bench.py starts the ranks itself)")
     D = importlib.import_module("ai-camera_amd.distributed")
-    # First thing in a rank: pin its host threads (producer, tracker/consumer, copy engine submissions) to the cores of the NUMA node
-    # its GPU hangs off, so 8 ranks do not share cores and page-locked buffers are allocated node-locally.  With N > 1 the PCI query
-    # goes through the HIP runtime (it is initialised from here on): nothing below may exec or relaunch this process.
-    affinity = D.bind_rank_to_gpu_numa(local_rank, world)
     import torch
     import torch.distributed as dist
 
     ndev = max(torch.cuda.device_count(), 1)
     dev = local_rank % ndev            # one GPU per rank on a real node; rehearsals may share a GPU
+    gather = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         kw = {}
@@ -247,6 +242,16 @@ def main():
             torch.cuda.set_device(dev)
             kw["device_id"] = torch.device("cuda", dev)     # eager communicator on this rank's GPU (no lazy-init warning, no guess)
         dist.init_process_group(backend=args.backend, rank=rank, world_size=world, **kw)
+
+        def gather(obj):
+            out = [None] * world
+            dist.all_gather_object(out, obj)
+            return out
+    # Before any page-locked allocation or worker thread: pin this rank's threads (producer, tracker / consumer, copy submissions, and the
+    # runtime's and RCCL's helpers that already exist) to the cores of the NUMA node ITS GPU hangs off, so 8 ranks do not share cores and
+    # page-locked buffers are allocated node-locally.  The rank asks the runtime about its own device only; which ranks share a node is
+    # all-gathered over the process group.  The runtime is initialised from here on: nothing below may exec or relaunch this process.
+    affinity = D.bind_rank_to_gpu_numa(local_rank, world, device=dev, gather=gather)
     if args.dry_run:                   # CPU rehearsal: everything around the GPU work (tests/test_distributed_cpu.py)
         dt = 0.25 + 0.01 * rank
         dt_max = D.reduce_max_time(dt) if world > 1 else dt
@@ -499,7 +504,7 @@ def main():
                                 f"{now_digest} (re-run tools/refresh_profiles.sh)")
             except Exception:
                 pass
-            roof = {"kernel": "conv class = conv_igemm_dma / conv_igemm_pp / conv3x3_pp_patch / conv3x3_patch / conv3x3_c16 / conv3x3_c64_resident / conv3x3_c64_block / c2f16_fused / bneck32_fused kernels (MFMA implicit GEMM: every conv of YOLOv8 + ReID except the two fused 3-channel stems)",
+            roof = {"kernel": "conv class = conv_igemm_dma / conv_igemm_pp / conv3x3_pp_patch / conv3x3_patch / conv3x3_c16 / conv3x3_c64_resident / conv3x3_c64_block / c2f16_fused kernels (MFMA implicit GEMM: every conv of YOLOv8 + ReID except the two fused 3-channel stems)",
                     "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                     "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": tsrc, "traffic_algorithmic_same_basis": talg,
                     "denominator": ("union of the conv class's bracketed intervals over both streams (paired HIP events per stream, device clock)" if have_union

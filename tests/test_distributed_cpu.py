@@ -157,6 +157,30 @@ def test_bench_launches_its_own_ranks_gloo_world2():
     assert bad.returncode != 0
 
 
+def test_bench_world8_gloo_dry_run():
+    """configs[3] / configs[4] rehearsed at their real rank count without eight GPUs: `python bench.py --gpus 8 --backend gloo --dry-run
+    --gallery-exchange 8` -- eight ranks rendezvous on 127.0.0.1, every rank asks about ITS OWN device only and the NUMA nodes are
+    all-gathered (no rank enumerates the node's other GPUs), the cores they bind are pairwise disjoint while the host has
+    at least eight, all eight gallery shards arrive everywhere, and rank 0 prints ONE line with eight per-rank rows."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--backend", "gloo", "--dry-run",
+           "--gallery-exchange", "8"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(env, OMP_NUM_THREADS="1"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["dry_run"] is True
+    assert abs(out["value"] - 2048 * 2 * 8 / 0.32) < 1.0            # MAX over ranks: rank 7 takes 0.25 + 0.07 s
+    assert out["config"]["gallery_shards_seen"] == 8
+    pr = out["config"]["per_rank"]
+    assert [p["rank"] for p in pr] == list(range(8))
+    assert out["config"]["affinity"]["nodes_from"].startswith("all-gather")
+    if len(os.sched_getaffinity(0)) >= 8:
+        assert len({p["first_core"] for p in pr}) == 8               # eight ranks, eight different first cores
+
+
 def test_rank_core_binding_is_disjoint():
     import importlib
     D = importlib.import_module("ai-camera_amd.distributed")

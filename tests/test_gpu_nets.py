@@ -309,28 +309,38 @@ sys.exit(0 if d < 3e-3 and np.allclose(np.linalg.norm(e_big, axis=1), 1, atol=1e
     assert r.returncode == 0
 
 
-def test_detect_branch_tails_decode_in_place_bit_exact(gpu, engines, tmp_path):
+@pytest.mark.parametrize("scale", ["n", "x"])
+def test_detect_branch_tails_decode_in_place_bit_exact(gpu, engines, tmp_path, scale):
     """fp16 engines, calls that go on to decode: the class branch's 1x1 tail stores max logit + first arg-max per anchor and the box
     branch's tail the decoded box (ConvArgs::t_max / t_box) instead of 80 + 64 fp32 logits that decode_kernel would read back.  Same
     fp32 values, same order of operations: boxes, max logits and labels must be IDENTICAL to the two-step form (a child process with the
-    switches off: they are read once per process), at 2 frames (128-pixel tail tiles) and at 40 (512-pixel tiles, the patch kernel's tail)."""
+    switches off: they are read once per process), at 2 frames (128-pixel tail tiles) and at 40 (512-pixel tiles, the patch kernel's tail).
+    Scale 'x' (ADVICE r4): its box branch LEADS with 80 channels (cb = max(16, 320 / 4, 64)) into the 64-output 1x1 -- the five-tile tail,
+    which has no in-place box decode; the engine must leave that level to decode_kernel instead of marking it decoded (a 320 x 320
+    engine keeps the 68 M-parameter net cheap)."""
     import subprocess
     import sys
+    epath, hw = engines[0], 640
+    if scale == "x":
+        epath, hw = str(tmp_path / "yolov8x_320.aicw"), 320
+        ef = pkg("engine_file")
+        ef.write_engine(epath, ef.build_yolov8("x", in_hw=(320, 320), seed=3))
     code = r"""
 import importlib, sys, numpy as np
 sys.path.insert(0, %r)
 he = importlib.import_module("ai-camera_amd.hip_engine")
 rng = np.random.default_rng(5)
 out = {}
+HW = %d
 for n in (2, 40):
-    x = rng.random((n, 3, 640, 640), dtype=np.float32)
+    x = rng.random((n, 3, HW, HW), dtype=np.float32)
     eng = he.HipEngine(%r, dtype="fp16", max_items=n, warm_up=False)
     b, ml, lab = eng.yolo_decode_np(x)
     nd, ob, sc, ol = eng.yolo_infer_np(x, conf=0.25, iou=0.45, max_det=300)
     eng.close()
     out.update({f"b{n}": b, f"ml{n}": ml, f"lab{n}": lab, f"nd{n}": nd, f"ob{n}": ob, f"sc{n}": sc, f"ol{n}": ol})
 np.savez(sys.argv[1], **out)
-""" % (ROOT, engines[0])
+""" % (ROOT, hw, epath)
     files = []
     for name, env in (("tails", {}), ("two_step", {"AICAM_NO_CLS_REDUCE": "1", "AICAM_NO_BOX_DECODE": "1"})):
         f = str(tmp_path / (name + ".npz"))
@@ -489,62 +499,6 @@ def test_fused_head_tail(gpu, engines, tmp_path):
     assert n_u - n_f == 7, (n_u, n_f)
     assert np.isfinite(dfl).all() and np.abs(dfl).max() > 0.1 and np.abs(cls).max() > 0.1
     assert np.array_equal(dfl, dfl_u) and np.array_equal(cls, cls_u)
-
-
-@pytest.mark.parametrize("n_img", [2, 40])
-def test_fused_bottleneck32(gpu, engines, n_img):
-    """YOLOv8n's 80 x 80 C2f blocks (layers 4 and 15) hold three 32-channel bottlenecks -- m.cv1 3x3, m.cv2 3x3 (+ the block's input in the
-    backbone's) -- that run as ONE kernel each (bneck32_fused_kernel, csrc/kernels_conv_bneck.hip): the 32-channel intermediate stays in LDS.
-    Checked where it happens: the bottlenecks' OUTPUT SLICES of the C2f concat buffers (aic_model_read_buffer), fused against the same
-    engine's default (the two convs of every pair as two launches; the fused form is opt-in, AICAM_BNECK=1, read per call -- it measured
-    slower at full launch groups and neutral at small ones).  Same taps in the same order, bias after
-    the accumulation, same SiLU, same roundings -- and yet not the same bits: on identical inputs ~0.1 % of the fp16 outputs land one ulp
-    apart (measured: 13 of 204 800 elements of the intermediate, 197-307 of a pair's output; the cause is below fp32 resolution and was
-    not found).  Asserted: the first pair's input is bit-identical, the layer-4 pairs' outputs differ in < 1 % / < 2 % of their elements and no pair's anywhere by more
-    than 0.1 (a one-ulp flip of an intermediate value near 4 is 0.004, times a weight, before the second conv's own rounding; later pairs
-    also see their predecessor's flips), three conv launches fewer, and the raw head stays within the fp16 engine's tolerance of the fp32 oracle.  2 images: the unfused pair runs on the LDS-DMA implicit GEMM; 40: on
-    the 3x3 patch kernel."""
-    L = pkg("_lib")
-    x = np.random.default_rng(13).standard_normal((n_img, 3, 640, 640)).astype(np.float32) * 0.5
-    eng = HipEngine(engines[0], dtype="fp16", max_items=n_img, warm_up=False)
-
-    def run():
-        L.call("aic_prof_reset", 0)
-        L.call("aic_prof_enable", 0, 1)
-        head = eng.yolo_head_np(x)
-        n = L.prof_read(0)["conv_igemm"]["launches"]
-        L.call("aic_prof_enable", 0, 0)
-        bufs = {}
-        for b, ch in ((11, 128), (24, 96)):               # concat buffers of 4.c2f and 15.c2f (engine_file.build_yolov8 buffer indices)
-            a = np.zeros((n_img, 80, 80, ch), np.float16)
-            L.call("aic_model_read_buffer", eng._h, b, L.ptr(a), a.nbytes)
-            bufs[b] = a
-        return head, n, bufs
-
-    assert "AICAM_BNECK" not in os.environ
-    (dfl_u, cls_u), n_u, bu = run()
-    os.environ["AICAM_BNECK"] = "1"
-    try:
-        (dfl, cls), n_f, bf = run()
-    finally:
-        del os.environ["AICAM_BNECK"]
-    eng.close()
-    assert n_u - n_f == 3, (n_u, n_f)
-    assert np.array_equal(bf[11][..., :64], bu[11][..., :64])                    # 4.c2f.cv1's output: the first pair's input
-    for name, b, sl in (("4.c2f.m0", 11, slice(64, 96)), ("4.c2f.m1", 11, slice(96, 128)), ("15.c2f.m0", 24, slice(64, 96))):
-        f, u = bf[b][..., sl].astype(np.float32), bu[b][..., sl].astype(np.float32)
-        d = np.abs(f - u)
-        frac = float((d > 0).mean())
-        print(f"{name}: {int((d > 0).sum())} of {d.size} outputs differ from the two-launch form ({100 * frac:.3f} %), max {float(d.max()):.3e}")
-        # (15.c2f.m0's INPUT already carries the flips of layer 4, ten layers upstream: most of its outputs move by a rounding)
-        assert (frac < {"4.c2f.m0": 0.01, "4.c2f.m1": 0.02}.get(name, 1.1)) and float(d.max()) < 0.1, name
-    eo = N.EngineOracle(engines[0])
-    k = min(n_img, 2)
-    dfl_ref, cls_ref = (t.numpy() for t in eo.yolo_head(torch.from_numpy(x[:k])))
-    e_f = max(np.abs(dfl[:k] - dfl_ref).max(), np.abs(cls[:k] - cls_ref).max())
-    e_u = max(np.abs(dfl_u[:k] - dfl_ref).max(), np.abs(cls_u[:k] - cls_ref).max())
-    print(f"raw head vs fp32 oracle: fused {e_f:.3e}, two-launch form {e_u:.3e}")
-    assert e_f < 0.15 and e_f < 1.5 * e_u + 1e-2
 
 
 def test_merged_detect_branch_heads(gpu, engines, tmp_path):

@@ -392,6 +392,49 @@ def test_device_filter_crowded_groups_take_extra_reid_rounds(gpu, engines):
         config.CLASSES_TO_TRACK.update(old)
 
 
+def test_per_group_filter_choice_beside_overflow_rounds(gpu, engines):
+    """with the filter chosen per launch group (device_filter = 1) a device-filtered group k -- crowded, so the CONSUMER thread
+    runs its overflow ReID rounds -- and a host-filtered group k + 1 -- whose ReID the PRODUCER launches -- can be in flight on the same
+    ReID engine; both set the engine's launch state (crop source, device-side count) and both now hold Pipeline::reid_mu around it.
+    Crowded texture frames, a 48-crop ReID arena, the auto association with a limit the scene crosses back and forth: the counters must
+    show both filters AND overflow rounds, and every row, count and the final table must be those of the host filter."""
+    old = set(config.CLASSES_TO_TRACK)
+    config.CLASSES_TO_TRACK.clear()
+    config.CLASSES_TO_TRACK.update(config.CLASSES)
+    try:
+        n_frames = 40
+        sc = syn.Scene(seed=33, n_targets=8)
+        frames = sc.render_batch(0, n_frames)
+        TP = pkg("pipeline").TrackingPipeline
+        out = {}
+        for filt in (1, 0):
+            reid = HipEngine(engines[1], dtype="fp16", max_items=48, warm_up=False)
+            pipe = TP(engines[0], reid, (720, 1280), batch=4, ring_frames=n_frames, max_persons=16, dtype="fp16", inject=False, n_init=2, max_tracks=2048)
+            pipe.option("device_filter", filt)
+            pipe.option("device_assoc", 1)
+            pipe.option("device_assoc_limit", 150)
+            pipe.option("taper", 0)
+            pipe.upload(0, frames)
+            nt, rows, nd = (x.copy() for x in pipe.run_raw(0, n_frames))
+            c = pipe.counters()
+            out[filt] = (nt, rows, nd, pipe.tracker_core.export_arrays())
+            print(filt, c)
+            if filt:
+                assert c["filter_device_groups"] >= 2 and c["filter_host_groups"] >= 2 and c["reid_overflow_rounds"] >= 2, c
+                assert c["assoc_device_frames"] > 0 and c["assoc_host_frames"] > 0, c
+            pipe.close()
+            reid.close()
+        (na, ra, da, xa), (nb, rb, db, xb) = out[1], out[0]
+        assert np.array_equal(da, db) and np.array_equal(na, nb)
+        for f in range(n_frames):
+            assert np.array_equal(ra[f][:min(na[f], 16)], rb[f][:min(nb[f], 16)]), f
+        for key in ("track_id", "state", "hits", "age", "time_since_update", "gallery_len", "mean"):
+            assert np.array_equal(xa[key], xb[key]), key
+    finally:
+        config.CLASSES_TO_TRACK.clear()
+        config.CLASSES_TO_TRACK.update(old)
+
+
 def test_more_than_512_detections_in_a_frame_fall_back_to_the_host_chain(gpu, engines):
     """The epoch kernel takes at most 512 detections per frame (one thread per detection); the host chain takes 1 536.  With
     device_assoc = 2 ("always on the device") a launch group holding such a frame must take the host chain for that group -- not fail

@@ -1,5 +1,5 @@
 #!/bin/bash
-# interleaved A/B of the headline bench under an environment switch: tools/ab_env.sh "AICAM_NO_BNECK=1" [rounds]
+# interleaved A/B of the headline bench under an environment switch: tools/ab_env.sh "AICAM_NO_TAIL=1" [rounds]
 B="--no-curve --no-own --no-plugin --cpu-frames 0"
 for i in $(seq 1 ${2:-3}); do
 for cfg in "X=1" "$1"; do

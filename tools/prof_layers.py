@@ -34,7 +34,7 @@ def main(d, frames=16, crops=480, top=30, fused_stem=1, fused_yolo_stem=1, fused
     print(f"{'kernel':42s} {'calls':>7s} {'total ms':>9s} {'%':>6s} {'avg us':>8s}")
     for n, (c, us) in sorted(tot.items(), key=lambda kv: -kv[1][1])[:24]:
         print(f"{n[:42]:42s} {c:7d} {us / 1e3:9.2f} {100 * us / all_us:6.1f} {us / c:8.1f}")
-    conv = [r for r in rows if any(k in r["Kernel_Name"] for k in ("conv_igemm", "conv3x3_patch", "conv3x3_pp_patch", "conv3x3_c16", "conv3x3_c64_resident", "conv3x3_c64_block", "c2f16_fused", "bneck32_fused"))]
+    conv = [r for r in rows if any(k in r["Kernel_Name"] for k in ("conv_igemm", "conv3x3_patch", "conv3x3_pp_patch", "conv3x3_c16", "conv3x3_c64_resident", "conv3x3_c64_block", "c2f16_fused"))]
     # the conv class over the steady-state middle of the trace: summed kernel durations against the UNION of their intervals (with the class
     # on two streams -- bench.py's default since round 4 -- the sum counts every overlapped microsecond twice; bench.py's roofline uses
     # the union, from paired HIP events per stream), and the class's rate over each, from the full launch groups that START in the window
@@ -89,15 +89,6 @@ def main(d, frames=16, crops=480, top=30, fused_stem=1, fused_yolo_stem=1, fused
                 merged.append(L)
                 i += 1
         layers = merged
-    if fused_block and os.environ.get("AICAM_BNECK"):     # a 32-channel C2f bottleneck (m.cv1 + m.cv2, 3x3 32 -> 32 each) is ONE launch of bneck32_fused_kernel
-        merged = []
-        for L in layers:
-            if merged and L[0] == "yolo" and L[1].endswith(".cv2") and ".m" in L[1] and merged[-1][1] == L[1][:-1] + "1" and L[3] == 32 and L[4] == 288 and merged[-1][3] == 32:
-                p = merged.pop()
-                merged.append((p[0], L[1][:-4] + " (bneck x2)", p[2], p[3], p[4] + L[4]))
-            else:
-                merged.append(L)
-        layers = merged
     if fused_block:     # the detect branches' last 1x1 (22.box*.2 / 22.cls*.2, n-scale: 64 / 80 channels) runs in the epilogue of the 3x3 before it
         merged = []
         for L in layers:
@@ -134,7 +125,7 @@ def main(d, frames=16, crops=480, top=30, fused_stem=1, fused_yolo_stem=1, fused
     per = len(layers)
     # a launch group starts at its (fused) YOLO stem; groups of other sizes (tapered tail of a call: fewer frames, and below
     # the fused-block threshold two more launches) are dropped: keep the groups with `per` conv launches and the modal grid
-    is_conv = lambda r: any(k in r["Kernel_Name"] for k in ("conv_igemm", "conv3x3_patch", "conv3x3_pp_patch", "conv3x3_c16", "conv3x3_c64_resident", "conv3x3_c64_block", "c2f16_fused", "bneck32_fused"))
+    is_conv = lambda r: any(k in r["Kernel_Name"] for k in ("conv_igemm", "conv3x3_patch", "conv3x3_pp_patch", "conv3x3_c16", "conv3x3_c64_resident", "conv3x3_c64_block", "c2f16_fused"))
     glist, cur = [], None
     for r in rows:
         if "yolo_stem_fused" in r["Kernel_Name"] or "letterbox" in r["Kernel_Name"]:

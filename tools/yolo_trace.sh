@@ -1,5 +1,5 @@
 #!/bin/bash
-# per-kernel stats of the detector alone (512 frames, one stream) with and without a kernel switch: tools/yolo_trace.sh "AICAM_NO_BNECK=1"
+# per-kernel stats of the detector alone (512 frames, one stream) with and without a kernel switch: tools/yolo_trace.sh "AICAM_NO_TAIL=1"
 R=$PWD; cd /tmp; export TMPDIR=/tmp
 for e in "X=1" "$1"; do
   O=$R/gpurun_out/ytrace_$(echo $e | tr -c 'A-Za-z0-9' '_')
@@ -11,7 +11,7 @@ f=glob.glob(sys.argv[1]+'/*/*kernel_stats.csv')[0]
 rows=list(csv.DictReader(open(f)))
 for r in rows:
     n=r['Name']
-    if any(k in n for k in ('bneck','conv3x3_patch_kernel','c2f16')):
+    if any(k in n for k in ('conv3x3_patch_kernel','c2f16')):
         print(n[:110], r['Calls'], r['TotalDurationNs'], 'avg us', float(r['AverageNs'])/1e3)
 PY
 done
