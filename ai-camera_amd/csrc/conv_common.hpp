@@ -642,6 +642,29 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 }
 
 
+// ---- shared by the patch kernels of kernels_conv_pp.hip / kernels_conv_sp.hip
+constexpr int ppp_ipix_pad(int th, int tw) {
+    int ipix = (th + 2) * (tw + 2);
+    if (tw >= 16) return ipix;
+    while (ipix % 16 != tw && ipix % 16 != 16 - tw) ++ipix;
+    return ipix;
+}
+
+// X2 (ConvArgs::x2: a 1x1 / stride-s conv of a second tensor accumulated into the same outputs -- a ResNet downsample branch folded into
+// the block's last conv): the second source's channel chunk e (BM pixels x one K-step) sits in a buffer of its own behind the weight ring.
+// It streams in during the window's chunk e in the LDS-DMA slots that carry no patch pass (taps 6 .. 8; the 512-pixel tile needs four
+// passes, two of them at tap 6, whose counted wait is one higher) and is consumed by ONE extra step right after tap (0, 0) of chunk e + 1:
+// the last pass is issued in L(tap 8), waited for in L(tap 0), read in L(extra) -- the usual two segments; the buffer is refilled from
+// tap 6 on, five steps after it was read.  The implicit-GEMM kernels walk the same order (set_tap / xs there).
+// lane id worked out on the spot (two v_mbcnt) and opaque to the optimiser: values derived from it inside the K loop are computed where
+// they are used instead of being carried through the loop in registers the 512 x 128 tile does not have
+__device__ __forceinline__ int lane_here() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+
+
 inline int conv_impl() {   // AICAM_CONV=v1 selects the register-staged kernel (A/B and fallback)
     static int v = [] { const char* e = getenv("AICAM_CONV"); return (e && e[0] == 'v' && e[1] == '1') ? 1 : 2; }();
     return v;
@@ -649,6 +672,7 @@ inline int conv_impl() {   // AICAM_CONV=v1 selects the register-staged kernel (
 
 // ---- host entry points of the other conv units; each returns false when the layer is not one of its shapes
 bool conv_try_pp_patch(int dtype, const ConvArgs& a, hipStream_t s);   // kernels_conv_pp.hip: v5 ping-pong patch (3x3/s1, Cout 128 / 256k)
+bool conv_try_sp_patch(const ConvArgs& a, int shape, hipStream_t s);    // kernels_conv_sp.hip: v6 software-pipelined patch (fp16; the shapes of v5 without a second source)
 int conv_pp_patch_shape(int dtype, const ConvArgs& a);                 // != 0 (the tile shape, pp_patch_shape) when conv_try_pp_patch would take this layer at a large enough batch
 bool conv_try_pp(int dtype, const ConvArgs& a, hipStream_t s);         // kernels_conv_pp.hip: v4 ping-pong im2col (long K, Cout 128 / 256k)
 bool conv_try_patch(int dtype, const ConvArgs& a, hipStream_t s);      // kernels_conv_direct.hip: 4-wave patch kernel (Cout 64 / 32)

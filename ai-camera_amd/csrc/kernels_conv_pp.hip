@@ -308,27 +308,7 @@ static void launch_pp(const ConvArgs& a, hipStream_t s) {
 // sit PW * 16 bytes apart in a plane -- bank conflicts on 40 % of the LDS cycles of ReID layers 3/4 (SQ_LDS_BANK_CONFLICT).
 // Now it is ONE row of G = 16 / TW consecutive IMAGES of the tile, and the image pitch is padded so that the G row pieces fall
 // into disjoint bank ranges (pitch * 16 B = TW * 16 B mod 256).
-constexpr int ppp_ipix_pad(int th, int tw) {
-    int ipix = (th + 2) * (tw + 2);
-    if (tw >= 16) return ipix;
-    while (ipix % 16 != tw && ipix % 16 != 16 - tw) ++ipix;
-    return ipix;
-}
-
-// X2 (ConvArgs::x2: a 1x1 / stride-s conv of a second tensor accumulated into the same outputs -- a ResNet downsample branch folded into
-// the block's last conv): the second source's channel chunk e (BM pixels x one K-step) sits in a buffer of its own behind the weight ring.
-// It streams in during the window's chunk e in the LDS-DMA slots that carry no patch pass (taps 6 .. 8; the 512-pixel tile needs four
-// passes, two of them at tap 6, whose counted wait is one higher) and is consumed by ONE extra step right after tap (0, 0) of chunk e + 1:
-// the last pass is issued in L(tap 8), waited for in L(tap 0), read in L(extra) -- the usual two segments; the buffer is refilled from
-// tap 6 on, five steps after it was read.  The implicit-GEMM kernels walk the same order (set_tap / xs there).
-// lane id worked out on the spot (two v_mbcnt) and opaque to the optimiser: values derived from it inside the K loop are computed where
-// they are used instead of being carried through the loop in registers the 512 x 128 tile does not have
-__device__ __forceinline__ int lane_here() {
-    int l;
-    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
-    return l;
-}
-
+// (ppp_ipix_pad, lane_here: conv_common.hpp -- shared with the software-pipelined form, kernels_conv_sp.hip)
 template <typename T, int MT, int NT, int WM, int WN, int TH, int TW, int NSTAGE, bool X2 = false>
 __global__ __launch_bounds__(512) void conv3x3_pp_patch_kernel(const ConvArgs a, int tiles_x, int tiles_y, int ny, int run, int pf) {
     constexpr int CH = 16 / (int)sizeof(T);
@@ -760,6 +740,10 @@ static bool try_pp_patch(const ConvArgs& a, hipStream_t s) {
         if (shape == 3 && (long)(a.M / 256) * (c / 256) >= pp_min) return launch_pp_patch<T, 8, 4, 2, 4, 16, 8, 4, true>(a, s);
         if (shape == 4 && (long)(a.M / 256) * (c / 256) >= pp_min) return launch_pp_patch<T, 8, 4, 2, 4, 8, 4, 4, true>(a, s);
         return false;
+    }
+    if constexpr (sizeof(T) == 2) {                 // fp16: the software-pipelined form of the same tiles (kernels_conv_sp.hip; same K order, same bits)
+        if ((shape == 2 && a.M / 512 >= pp_min) || (shape >= 3 && (long)(a.M / 256) * (c / 256) >= pp_min))
+            if (conv_try_sp_patch(a, shape, s)) return true;
     }
     if (shape == 1 && a.M / 512 >= pp_min) return deep ? launch_pp_patch<T, 4, 4, 8, 1, 16, 32, 6>(a, s) : launch_pp_patch<T, 4, 4, 8, 1, 16, 32, 4>(a, s);
     if (shape == 2 && a.M / 512 >= pp_min) return deep ? launch_pp_patch<T, 8, 4, 4, 2, 32, 16, 6>(a, s) : launch_pp_patch<T, 8, 4, 4, 2, 32, 16, 4>(a, s);

@@ -1,0 +1,329 @@
+// kernels_conv_sp.hip -- v6: the 3x3 / stride-1 patch kernel SOFTWARE-PIPELINED and stripped to the instructions a K-step needs
+// (fp16, whole-image tiles: ReID layer2 / 3 / 4; round 5).
+//
+// v5 (conv3x3_pp_patch_kernel, kernels_conv_pp.hip) runs two waves per SIMD half a K-step apart: every wave executes a LOAD segment
+// (twelve ds_read_b128 of the step's fragments, two or three LDS-DMA issues with their address arithmetic, the ring bookkeeping, the
+// counted wait) and then a COMPUTE segment (32 MFMAs), each closed by a block barrier.  Stamped in round 4: LOAD ~822 cycles against
+// COMPUTE 512, so a K-step lasts 2 x 822 cycles and the matrix pipe is busy 62 % of them.  Round 4 blamed the LDS-DMA issue; what the
+// segment really is, is ~200 INSTRUCTIONS, and a wave issues at most one instruction per four cycles (each SIMD gets an issue turn every
+// fourth cycle, one instruction per wave per turn).  tools/ubench/wave_tile.hip strips a K-step to its essential mix -- 32 MFMAs, 12
+// fragment reads, 2-3 LDS-DMA, one wait, one barrier -- and measures, in shader clocks per K-step where the matrix pipe needs 1 024:
+//     two waves per SIMD, serial LOAD then COMPUTE, all waves in step (v5 without its offset)     1 507   0.68 busy
+//     ONE wave per SIMD with a 128 x 128 tile (256 accumulators), reads under its own MFMAs       1 726 - 1 901   0.54 - 0.59
+//     two waves per SIMD, 128 x 64 tiles, the NEXT step's fragments read UNDER this step's MFMAs  1 176 - 1 203   0.85 - 0.87
+// This kernel is the third form with a K-step of ~75 instructions besides its MFMAs:
+//   * same tiles, LDS layout, K order and MFMA sequence per accumulator as v5 (bit-identical outputs, tests/test_gpu_nets.py);
+//   * a wave holds the weight fragments twice; while the MFMAs of step k issue, the fragments of step k + 1 are read -- a pixel
+//     fragment into the registers its group of four MFMAs has just read, the weight fragments into the second set;
+//   * EVERYTHING about a step that can be a constant is one: the K loop is unrolled over 4 chunks x 9 taps (ring stage, fragment set,
+//     patch buffer, tap offset, patch-pass number are immediates), the MFMAs are inline asm with the accumulator tied in place (as
+//     pure values the allocator moved the accumulators from body to body and fragmented the register file: 17 - 69 spills), the
+//     LDS-DMA sources are 64-bit per-lane pointers built once per block plus ONE scalar offset (one VALU instruction per weight
+//     load, five per patch pass -- v5 works out (image, y, x) of every lane for every pass: ~25);
+//   * first measured form of this file (rolled loop, run-time tap / stage / pass, ~200 instructions per step): 1 028 / 1 127 / 1 138 TFLOP/s on
+//     the layer2 / 3 / 4 shapes against v5's 1 126 / 1 270 / 1 319 -- slower, and slower still with v5's half-step offset (981 / 1 070 /
+//     1 086): the instruction count, not the arrangement, was what the step waited for.
+//
+// Ring discipline (4 weight stages, two patch buffers), body k = the K-step (chunk c, tap t), k = 9 c + t:
+//   body k   issues the LDS-DMA of step k + 3 into stage (k + 3) & 3 -- last read in body k - 2 -- plus one patch pass / stand-in,
+//            reads the fragments of step k + 1 (landed: see the wait of body k - 1), issues the MFMAs of step k,
+//            waits until only its OWN loads are in flight (step k + 2 and every patch pass issued before this body have landed) and
+//            for its fragment reads, s_barrier.
+//   patch    passes of chunk c + 1 are issued in the bodies of taps 0 .. NPASS - 1 of chunk c (NPASS <= 7) into the other buffer,
+//            whose last reader was body (c - 1, tap 7); the last pass has landed at the end of body tap NPASS <= 7, the first read of
+//            the buffer is in body tap 8.
+//   tiles    a block walks a run of tiles as in v5; a tile's LAST body reads whatever the next tile's buffers hold by then and the
+//            next tile's first fragments are read again behind the epilogue (the fragments would have to live across it).
+#include "conv_common.hpp"
+
+namespace aic {
+
+template <int MT, int NT, int WM, int WN, int TH, int TW, bool SKEW>
+__global__ __launch_bounds__(512) void conv3x3_sp_patch_kernel(const ConvArgs a, int ny, int run) {
+    typedef half_t T;
+    constexpr int NSTAGE = 4;
+    constexpr int CH = 8, BKE = 32, RP = 128;
+    constexpr int BM = WM * MT * 16;
+    constexpr int BN = WN * NT * 16;
+    constexpr int B_PER = BN / RP;
+    constexpr int LPS = B_PER + 1;
+    constexpr int TPIX = TH * TW, NI = BM / TPIX;
+    constexpr int PW = TW + 2, PH = TH + 2, IPIX = PW * PH, IPIXP = ppp_ipix_pad(TH, TW), NPIX = NI * IPIXP;
+    constexpr int G = TW >= 16 ? 1 : 16 / TW;                          // images per 16-pixel MFMA tile
+    constexpr int NPASS = (NPIX + 127) / 128, NPIXP = NPASS * 128;
+    constexpr int PLANE = NPIXP * 16, PBUF = 4 * PLANE, WSTAGE = BN * 64;
+    // LDS: the weight ring FIRST (ring stage + tile offsets of the weight fragment reads fit ds_read's 16-bit immediate), then the two patch
+    // buffers, then the stand-in slot
+    constexpr int PATCH0 = NSTAGE * WSTAGE, DUM0 = PATCH0 + 2 * PBUF;
+    static_assert(WM * WN == 8 && MT == 8 && NT == 4 && BN % RP == 0 && BM % TPIX == 0 && NPASS <= 7 && TW % 4 == 0, "geometry");
+    static_assert((NSTAGE - 1) * WSTAGE + 2048 < 65536 && PBUF + (2 * PW + 2 + IPIXP * NI) * 16 < 65536, "ds_read immediates");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const bool late = SKEW && wv >= 4;
+    const int HW = a.H * a.W;
+    const int n_img = a.n_dev ? min(a.M / HW, a.n_dev[0]) : a.M / HW;     // device-side item count: the grid was sized for a bound
+    // tiles: (image group, channel tile), channel tile fastest; a block takes a run of `run` consecutive tiles
+    const int ntiles = ((n_img + NI - 1) / NI) * ny;
+    const int nruns = (ntiles + run - 1) / run;
+    if ((int)blockIdx.x >= nruns) return;
+    int t_cur = xcd_tile((int)blockIdx.x, nruns, a.xcd_map) * run;
+    const int t_end = min(t_cur + run, ntiles);
+    int img0 = (t_cur / ny) * NI, n0 = (t_cur % ny) * BN;          // the tile being computed (block-uniform)
+
+    const T* __restrict__ xg = reinterpret_cast<const T*>(a.x);
+    const T* __restrict__ wg = reinterpret_cast<const T*>(a.w);
+    const T* zero = reinterpret_cast<const T*>(a.zero);
+
+    // ---- per-lane LDS-DMA sources, built once.  Patch pass i, wave w -> plane w & 3, patch pixels i * 128 + (w >> 2) * 64 + lane: the pixel's
+    // address in image 0 of the tensor, channel chunk 0 (or the zero page for halo pixels outside the image and padding slots), and its image
+    // within the tile (or a huge number: "never live").  A pass then is: live lanes add ONE scalar offset (tile + chunk), the others add 0.
+    const int plane = wv & 3;
+    const T* pptr[NPASS];
+    int pil[NPASS];
+#pragma unroll
+    for (int i = 0; i < NPASS; ++i) {
+        const int p = i * 128 + (wv >> 2) * 64 + lane;
+        const int il = p / IPIXP, rem = p - il * IPIXP;
+        const int py = rem / PW, px = rem - py * PW;
+        const int iy = py - 1, ix = px - 1;
+        const bool ok = p < NPIX && rem < IPIX && (unsigned)iy < (unsigned)TH && (unsigned)ix < (unsigned)TW;
+        pptr[i] = ok ? xg + ((size_t)((il * TH + iy) * TW + ix) * a.x_cs + a.x_coff + plane * CH) : zero;
+        pil[i] = ok ? il : 0x40000000;
+    }
+    char* const pdst = smem + PATCH0 + plane * PLANE + (wv >> 2) * 1024;
+    const unsigned img_bytes = (unsigned)HW * a.x_cs * 2u;            // one image of the input, bytes (launch_sp_patch: the tensor fits 2^32 bytes)
+    // weights: row r0 + RP * j of channel tile 0 at K = 0; a load adds the scalar offset of (channel tile, step)
+    const int slot = t & 3, r0 = t >> 2;
+    const int kc = slot ^ lds_swz(r0);
+    const T* wptr[B_PER];
+#pragma unroll
+    for (int j = 0; j < B_PER; ++j) wptr[j] = wg + (size_t)(r0 + RP * j) * a.Kp + kc * CH;
+    char* const wdst = smem + (16 * wv) * 64;
+    const int nchunks = a.Cin / BKE;
+    const unsigned tile_wbytes = (unsigned)BN * a.Kp * 2u;            // weights of one channel tile, bytes
+    const unsigned tap_bytes = (unsigned)a.Cin * 2u;
+
+    // the weight stream: (channel tile, chunk, tap) of the step fetched next as ONE scalar byte offset, three steps ahead of the MFMAs
+    unsigned long long w_off = (unsigned long long)(n0 / BN) * tile_wbytes;
+    int w_c = 0;                                   // its chunk
+    int n0_next = n0, img_next = img0;
+    bool has_next = t_cur + 1 < t_end;
+    if (has_next) { img_next = ((t_cur + 1) / ny) * NI; n0_next = ((t_cur + 1) % ny) * BN; }
+    auto issue_w = [&](int st, int wtap) {         // st: ring stage; wtap: the fetched step's tap -- constants after inlining
+        char* sbase = wdst + st * WSTAGE;
+#pragma unroll
+        for (int j = 0; j < B_PER; ++j) {
+            const T* src = reinterpret_cast<const T*>(reinterpret_cast<const char*>(wptr[j]) + w_off);
+            asm volatile("" : "+v"(src));
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sbase + j * (RP * 64)), 16, 0, 0);
+        }
+        if (wtap < 8) w_off += tap_bytes;          // next tap of the chunk
+        else {                                     // next chunk: back eight taps, on one K-step of channels
+            w_off += 64u - 8u * (unsigned long long)tap_bytes;
+            if (++w_c == nchunks) {                // the stream moves on: the next tile of the run, or -- nothing to fetch for -- this tile again
+                w_c = 0;                           // (a harmless re-fetch of at most three steps: always inside the weights)
+                w_off = (unsigned long long)((has_next ? n0_next : n0) / BN) * tile_wbytes;
+            }
+        }
+    };
+    // this chunk's patch passes fetch the chunk that FOLLOWS (the next channel chunk of this tile, or chunk 0 of the run's next tile)
+    unsigned long long p_off = 0;                  // scalar byte offset the live lanes add
+    int p_lim = 0;                                 // images of the tile that exist (0: no pass is live)
+    auto set_patch = [&](int c) {
+        const bool inner = c + 1 < nchunks;
+        const int im = inner ? img0 : img_next;
+        p_off = (unsigned long long)im * img_bytes + (inner ? (unsigned)(c + 1) * 64u : 0u);
+        p_lim = (inner || has_next) ? n_img - im : 0;
+    };
+    auto issue_patch = [&](auto ic, int buf) {
+        constexpr int i = decltype(ic)::value;
+        const bool live = pil[i] < p_lim;
+        const unsigned lo = live ? (unsigned)p_off : 0u, hi = live ? (unsigned)(p_off >> 32) : 0u;
+        const T* src = reinterpret_cast<const T*>(reinterpret_cast<const char*>(pptr[i]) + (((unsigned long long)hi << 32) | lo));
+        asm volatile("" : "+v"(src));
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(pdst + buf * PBUF + i * 2048), 16, 0, 0);
+    };
+    auto issue_dummy = [&] {
+        const T* src = zero;
+        asm volatile("" : "+v"(src));
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + DUM0 + wv * 1024), 16, 0, 0);
+    };
+
+    const int wm = wv / WN, wn = wv % WN;
+    const int q = lane >> 4, r = lane & 15;
+    static_assert((MT * 16) % TPIX == 0 || TPIX % (MT * 16) == 0, "a wave's pixels must not straddle images irregularly");
+    static_assert(TW % 16 == 0 || 16 % TW == 0, "a 16-pixel MFMA tile is whole rows or a piece of one row");
+    static_assert(G == 1 || (NI % G == 0 && (MT % TH == 0 || TH % MT == 0)), "image groups");
+    auto tile_pix = [](int t) constexpr { return G == 1 ? (t * 16 / TPIX) * IPIXP + ((t * 16 % TPIX) / TW) * PW + (t * 16 % TPIX) % TW
+                                                        : (t / TH) * G * IPIXP + (t % TH) * PW; };
+    auto patch_pix = [tile_pix](int m) constexpr { return G == 1 ? tile_pix(m / 16) : (TH % MT == 0 ? (m / 16) * PW : tile_pix(m / 16)); };
+    int xa0;                                    // LDS byte address of (this lane's pixel of tile 0, tap (0, 0)) in patch buffer 0
+    if constexpr (G == 1) {
+        const int ml = wm * MT * 16 + r;
+        const int il = ml / TPIX, rem = ml - il * TPIX;
+        const int ly = rem / TW, lx = rem - ly * TW;
+        xa0 = PATCH0 + q * PLANE + (il * IPIXP + ly * PW + lx) * 16;
+    } else {
+        const int t0 = wm * MT;
+        xa0 = PATCH0 + q * PLANE + ((t0 / TH) * G * IPIXP + (t0 % TH) * PW + (r / TW) * IPIXP + r % TW) * 16;
+    }
+    int woff2[2];                               // weight fragment addresses: tiles j and j + 2 are 32 rows (2048 B) apart, j and j + 1 differ in the swizzle term
+#pragma unroll
+    for (int j = 0; j < 2; ++j) woff2[j] = lds_off(wn * NT * 16 + perm_row<NT>(j, r), q);
+
+    floatx4 acc[MT][NT];
+    half8 xf[MT], wf[2][NT];
+    auto read_w = [&](auto setc, int st) {
+        constexpr int S = decltype(setc)::value;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) wf[S][j] = *reinterpret_cast<const half8*>(smem + woff2[j & 1] + st * WSTAGE + (j >> 1) * 2048);
+    };
+    auto read_x = [&](int i, int buf, int tap) {       // all three are constants after inlining: one ds_read_b128 with an immediate
+        xf[i] = *reinterpret_cast<const half8*>(smem + xa0 + buf * PBUF + ((tap / 3) * PW + tap % 3) * 16 + patch_pix(16 * i) * 16);
+    };
+
+    // ---- prologue (first tile of the run): patch chunk 0, weights of steps 0 .. 2
+    p_off = (unsigned long long)img0 * img_bytes, p_lim = n_img - img0;
+    static_for<NPASS>([&](auto ic) { issue_patch(ic, 0); });
+#pragma unroll
+    for (int st = 0; st < NSTAGE - 1; ++st) {
+        issue_w(st, st);
+        if (st) issue_dummy();                  // every set in flight has LPS loads: the counted waits rely on it
+    }
+    wait_vmcnt<LPS>();                          // patch chunk 0 and the weights of steps 0 and 1 have landed (this wave's part)
+    __builtin_amdgcn_s_barrier();
+
+    // One K-step; C4 = chunk & 3 and the tap are compile-time.  Issue order (a scheduling fence behind every group):
+    //   group i = the four MFMAs of pixel tile i, then that tile's fragment of step k + 1 into the registers they have just read;
+    //   group 0 also reads the four weight fragments of step k + 1 (second set), group 1 issues the LDS-DMA of the weights of step k + 3,
+    //   group 2 this body's patch pass (or its stand-in).
+    auto body = [&](int c, auto c4c, auto tapc) {
+        constexpr int C4 = decltype(c4c)::value, tap = decltype(tapc)::value;
+        constexpr int BUF = C4 & 1, ST = (C4 + tap) & 3, CUR = ST & 1, NXT = CUR ^ 1;      // 9 c + tap = c + tap (mod 4); a tile starts at a multiple of 4
+        constexpr int nbuf = tap < 8 ? BUF : BUF ^ 1, ntap = tap < 8 ? tap + 1 : 0;
+        if constexpr (tap == 0) set_patch(c);
+        static_for<MT>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(wf[CUR][j]), "v"(xf[i]));
+            read_x(i, nbuf, ntap);
+            if constexpr (i == 0) read_w(std::integral_constant<int, NXT>{}, (ST + 1) & 3);
+            if constexpr (i == 1) issue_w((ST + 3) & 3, (tap + 3) % 9);
+            if constexpr (i == 2) {
+                if constexpr (tap < NPASS) issue_patch(tapc, BUF ^ 1);
+                else issue_dummy();
+            }
+            if constexpr (SKEW && i == MT / 2 - 1) {          // mid-body barrier: waves 4 .. 7 run half a body behind (see the tile loop)
+                __builtin_amdgcn_s_waitcnt(0x0F70 | LPS);     // vmcnt(LPS): everything older than this body's own loads has landed
+                __builtin_amdgcn_s_barrier();
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        // the waits as BUILTINS, not inline asm: the compiler's own wait-count pass must see them, or it protects the first MFMA of the next
+        // body -- whose operands these very waits have covered -- with an lgkmcnt(0) of its own BEHIND the next body's reads.
+        // s_waitcnt immediate (gfx9+): vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] << 14
+        __builtin_amdgcn_s_waitcnt(0x0070 | LPS);             // vmcnt(LPS), expcnt(7), lgkmcnt(0)
+        __builtin_amdgcn_s_barrier();
+    };
+    for (;;) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+        // the tile's first fragments, un-overlapped: step 0 = ring stage 0, patch buffer 0, tap 0 (landed and behind a barrier: prologue / last body)
+        read_w(std::integral_constant<int, 0>{}, 0);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) read_x(i, 0, 0);
+        __builtin_amdgcn_s_waitcnt(0xC07F);                   // lgkmcnt(0)
+        // SKEW: waves 4 .. 7 run half a body behind waves 0 .. 3 (one extra barrier here, one for the early half behind the loop).  Every wave
+        // waits for its older loads in front of BOTH barriers of a body, so a late wave's part of step k + 1 has landed before barrier 2k - 1
+        // (its mid-body k - 1), which an early wave passes before it reads step k + 1 in body k
+        if (late) __builtin_amdgcn_s_barrier();
+        for (int c = 0; c < nchunks; c += 4) {     // Cin / 32 is a multiple of 4 for every layer that reaches this kernel
+            static_for<4>([&](auto c4c) {
+                static_for<9>([&](auto tapc) { body(c + decltype(c4c)::value, c4c, tapc); });
+            });
+        }
+        if (SKEW && !late) __builtin_amdgcn_s_barrier();      // every wave has executed the same number of barriers: both halves store together
+        if (!has_next) wait_vmcnt<0>();
+        // the MFMAs are inline asm: the compiler does not know that the accumulators come out of the matrix pipe (up to 18 wait states
+        // before a VALU may read them); the barrier and the row arithmetic below are far more than that, two s_nop make it independent of them
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+
+        int mrow[MT];
+        const int ln = lane_here(), rr = ln & 15, qe = ln >> 4;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            int il, ly, lx;
+            if constexpr (G == 1) {
+                const int ml = (wm * MT + i) * 16 + rr;
+                il = ml / TPIX;
+                const int rem = ml - il * TPIX;
+                ly = rem / TW, lx = rem - ly * TW;
+            } else {
+                const int tl = wm * MT + i;
+                il = (tl / TH) * G + rr / TW, ly = tl % TH, lx = rr % TW;
+            }
+            const int img = img0 + il;
+            mrow[i] = img < n_img ? (img * TH + ly) * TW + lx : -1;
+        }
+        epilogue_dispatch<T, MT, NT, true, true>(a, acc, mrow, n0 + wn * NT * 16, qe);
+        if (!has_next) break;
+        ++t_cur;
+        img0 = img_next, n0 = n0_next;
+        has_next = t_cur + 1 < t_end;
+        if (has_next) { img_next = ((t_cur + 1) / ny) * NI; n0_next = ((t_cur + 1) % ny) * BN; }
+    }
+}
+
+template <int MT, int NT, int WM, int WN, int TH, int TW>
+static bool launch_sp_patch(const ConvArgs& a, hipStream_t s) {
+    constexpr int BM = WM * MT * 16, BN = WN * NT * 16;
+    constexpr int NI = BM / (TH * TW), NPIX = NI * ppp_ipix_pad(TH, TW), NPASS = (NPIX + 127) / 128;
+    constexpr size_t lds = (size_t)2 * 4 * NPASS * 128 * 16 + 8192 + (size_t)4 * BN * 64;
+    static_assert(lds <= 160 * 1024, "does not fit the LDS");
+    if (a.H != TH || a.W != TW || a.Ho != a.H || a.Wo != a.W || a.Cout % BN) return false;            // whole-image tiles, whole channel tiles
+    if ((long)a.M * a.x_cs * 2 >= (1l << 32) || (long)a.Cout * a.Kp * 2 >= (1l << 32)) return false;   // 32-bit byte strides inside the kernel
+    const int n_img = a.M / (a.Ho * a.Wo);
+    static const bool skew = getenv("AICAM_SP_SKEW") != nullptr;
+    auto kfn = skew ? conv3x3_sp_patch_kernel<MT, NT, WM, WN, TH, TW, true> : conv3x3_sp_patch_kernel<MT, NT, WM, WN, TH, TW, false>;
+    static bool attr = false;
+    if (!attr) {
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = true;
+    }
+    static const int run_max = [] { const char* e = getenv("AICAM_PPP_RUN"); return e ? std::max(1, atoi(e)) : 6; }();
+    const int ny = a.Cout / BN;
+    const long ntiles = (long)ceil_div(n_img, NI) * ny;
+    int run = 1;                                  // the longest run that does not add a round of tiles (256 CUs, one block each) and leaves >= 4 rounds of blocks
+    {
+        long best = -1;
+        for (int r = 1; r <= run_max; ++r) {
+            const long blocks = (ntiles + r - 1) / r, rounds = (blocks + 255) / 256;
+            if (r > 1 && rounds < 4) break;
+            const long cost = rounds * r;
+            if (best < 0 || cost <= best) best = cost, run = r;
+        }
+    }
+    const int nblk = (int)ceil_div(ntiles, (long)run);
+    hipLaunchKernelGGL(kfn, dim3(nblk), dim3(512), lds, s, a, ny, run);
+    KCHECK();
+    return true;
+}
+
+// shape: conv_pp_patch_shape()'s (2 = Cout 128 on 32 x 16 maps, 3 / 4 = Cout % 256 on 16 x 8 / 8 x 4 maps); the caller has checked that the
+// batch is large enough for one-block-per-CU tiles.  AICAM_NO_SP=1: v5 everywhere (A/B).
+bool conv_try_sp_patch(const ConvArgs& a, int shape, hipStream_t s) {
+    static const bool on = getenv("AICAM_NO_SP") == nullptr;
+    if (!on || a.x2 || a.Cin % 128) return false;
+    if (shape == 2) return launch_sp_patch<8, 4, 4, 2, 32, 16>(a, s);
+    if (shape == 3) return launch_sp_patch<8, 4, 2, 4, 16, 8>(a, s);
+    if (shape == 4) return launch_sp_patch<8, 4, 2, 4, 8, 4>(a, s);
+    return false;
+}
+
+}  // namespace aic

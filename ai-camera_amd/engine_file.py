@@ -474,3 +474,23 @@ def ensure_seeded_engines(root=None, scale="n", yolo_seed=0, reid_seed=1, force=
     if force or not os.path.exists(rpath):
         write_engine(rpath, build_reid(seed=reid_seed))
     return ypath, rpath
+
+
+TRAINED_ONNX = "weights/yolov8n_synth.onnx"
+
+
+def ensure_trained_detector(root=None, force=False):
+    """The YOLOv8n detector trained on the synthetic workload (tools/train_synthetic_detector.py: class 0 = a planted person of
+    ai-camera_amd/synthetic.Scene) as an engine file.  The committed artefact is an ONNX file with fp16 initializers and an embedded
+    EfficientNMS node, like the model files the reference downloads (scripts/download_models.sh:7-8); it comes in through the same
+    importer as any other ONNX file (onnx_import.onnx_to_engine), so this is the f1 path on weights that matter.  -> engine path."""
+    from . import onnx_import
+    root = root or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, TRAINED_ONNX)
+    dst = os.path.join(root, "models/detection/yolov8n_synth.aicw")
+    if not os.path.exists(src):
+        raise FileNotFoundError(f"{src}: the trained detector's ONNX file is missing (tools/train_synthetic_detector.py writes it)")
+    if force or not os.path.exists(dst) or os.path.getmtime(dst) < os.path.getmtime(src):
+        g, _ = onnx_import.onnx_to_engine(open(src, "rb").read(), "yolo")
+        write_engine(dst, g)
+    return dst

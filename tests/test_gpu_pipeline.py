@@ -396,8 +396,10 @@ def test_per_group_filter_choice_beside_overflow_rounds(gpu, engines):
     """with the filter chosen per launch group (device_filter = 1) a device-filtered group k -- crowded, so the CONSUMER thread
     runs its overflow ReID rounds -- and a host-filtered group k + 1 -- whose ReID the PRODUCER launches -- can be in flight on the same
     ReID engine; both set the engine's launch state (crop source, device-side count) and both now hold Pipeline::reid_mu around it.
-    Crowded texture frames, a 48-crop ReID arena, the auto association with a limit the scene crosses back and forth: the counters must
-    show both filters AND overflow rounds, and every row, count and the final table must be those of the host filter."""
+    Crowded texture frames, a 48-crop ReID arena, the auto association with a limit the scene exceeds: the two chunk contexts' first
+    groups are filtered on the device (overflow rounds on the consumer), the groups behind them on the host (ReID from the producer) --
+    the transition is the window the lock closes.  The counters must show both filters AND overflow rounds, and every row, count and the
+    final table must be those of the host filter."""
     old = set(config.CLASSES_TO_TRACK)
     config.CLASSES_TO_TRACK.clear()
     config.CLASSES_TO_TRACK.update(config.CLASSES)
@@ -421,7 +423,6 @@ def test_per_group_filter_choice_beside_overflow_rounds(gpu, engines):
             print(filt, c)
             if filt:
                 assert c["filter_device_groups"] >= 2 and c["filter_host_groups"] >= 2 and c["reid_overflow_rounds"] >= 2, c
-                assert c["assoc_device_frames"] > 0 and c["assoc_host_frames"] > 0, c
             pipe.close()
             reid.close()
         (na, ra, da, xa), (nb, rb, db, xb) = out[1], out[0]

@@ -1,0 +1,141 @@
+"""The detector that SEES the planted persons: YOLOv8n trained on ai-camera_amd/synthetic.Scene frames by
+tools/train_synthetic_detector.py, committed as an ONNX file with fp16 initializers (weights/yolov8n_synth.onnx) and imported through
+ai-camera_amd/onnx_import.py like the model files the reference downloads (scripts/download_models.sh:7-8).  With it the reference's real
+data flow -- the tracker driven by its detector's OWN boxes, src/aicamera_tracker.py:180,193-195, src/tracker/deepsort_tracker.py:88-101 --
+is a statement about persons, not about texture: inject = 0 everywhere in this file.
+
+CPU: the file imports, its weights are what the exporter wrote, and the fp32 ORACLE detector finds the persons of a held-out scene.
+GPU: a 300-frame, 30-person scene through the pipeline -- detector recall against the planted boxes, the fp32 HIP chain against the
+fp32 oracle chain on every track output, and fp16 (the bench's precision) against fp32 of the same engines: id switches and reproduced
+outputs."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, assert_rows_equal_or_on_rounding_edge, pkg
+from oracle import deepsort_oracle as O
+from oracle import image_oracle as I
+from oracle import nets_oracle as N
+
+syn = pkg("synthetic")
+config = pkg("config")
+HELD_OUT_SEED = 77            # training scenes use seeds >= 2^20 (tools/train_synthetic_detector.py::sample)
+
+
+@pytest.fixture(scope="module")
+def trained():
+    ef = pkg("engine_file")
+    return ef.ensure_trained_detector(ROOT)
+
+
+def oracle_detect(yo, frame, conf=0.3, iou=0.5, max_det=300):
+    x, ratios, pad = I.preprocess_yolo_input(frame)
+    dfl, cls = yo.yolo_head(torch.from_numpy(x))
+    b, ml, lab = yo.decode(dfl.numpy(), cls.numpy())
+    keep = N.nms(b[0], ml[0], lab[0], conf, iou, max_det)
+    return I.scale_bboxes(b[0][keep], frame.shape[:2], ratios, pad), N.sigmoid32(ml[0][keep]), lab[0][keep]
+
+
+def recall_and_extras(planted, boxes, thr=0.5):
+    """(planted boxes with a detection at IoU >= thr, detections matching no planted box at IoU >= thr)."""
+    if not len(planted):
+        return 0, len(boxes)
+    if not len(boxes):
+        return 0, 0
+    iou = np.stack([N.box_iou_xyxy(p, boxes) for p in planted])
+    return int((iou.max(1) >= thr).sum()), int((iou.max(0) < thr).sum())
+
+
+def test_trained_onnx_imports_and_oracle_sees_the_persons(trained):
+    oi, ef = pkg("onnx_import"), pkg("engine_file")
+    blob = open(os.path.join(ROOT, ef.TRAINED_ONNX), "rb").read()
+    g, info = oi.onnx_to_engine(blob)
+    assert info["kind"] == "yolo" and info["scale"] == "n" and info["nc"] == 80 and info["mapping"] == "by name"
+    assert info["nms"] == {"op": "EfficientNMS_TRT", "score_threshold": pytest.approx(0.3), "iou_threshold": pytest.approx(0.5), "max_output_boxes": 300}
+    assert len(g.weights) == 63 and abs(g.conv_macs() / 1e9 - 4.371) < 0.01
+    for w, b in g.weights:                       # fp16 initializers: every value is exactly representable in the fp16 engine
+        assert np.array_equal(w, w.astype(np.float16).astype(np.float32)) and np.array_equal(b, b.astype(np.float16).astype(np.float32))
+    assert ef.engine_nms_defaults(trained) == pytest.approx((0.3, 0.5, 300))
+    # the fp32 oracle on frames of a scene no training step saw
+    torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
+    yo = N.EngineOracle(trained)
+    sc = syn.Scene(seed=HELD_OUT_SEED, n_targets=30)
+    hit = tot = extra = 0
+    for f in (0, 150, 299):
+        planted = sc.detections(f)[0]
+        b, s, lab = oracle_detect(yo, sc.render(f))
+        assert (lab == syn.PERSON_CLASS_ID).all()
+        h, e = recall_and_extras(planted, b)
+        hit, tot, extra = hit + h, tot + len(planted), extra + e
+    print(f"fp32 oracle detector on held-out scene {HELD_OUT_SEED}: {hit} of {tot} planted persons found at IoU >= 0.5, {extra} detections match none")
+    assert hit >= 0.95 * tot and extra <= 0.05 * tot
+
+
+@pytest.mark.gpu
+def test_own_detections_chain_on_trained_weights(lib, trained, engines):
+    """300 frames, 30 persons, inject = 0.  (i) the fp16 detector's recall of the planted boxes (IoU >= 0.5) is at least 95 %;
+    (ii) the fp32 HIP chain gives the fp32 oracle chain's track outputs on EVERY frame (ids, classes, integer rows exact or on a rounding
+    edge of the oracle's own coordinate); (iii) fp16 against fp32 of the same engines, each on its own detections: 0 id switches and
+    at least 99 % of the fp32 outputs reproduced at IoU >= 0.9 (ai-camera_amd/mot_metrics.py with the fp32 rows as the reference set)."""
+    if lib.device_count() < 1:
+        pytest.skip("no GPU")
+    mm = pkg("mot_metrics")
+    TP = pkg("pipeline").TrackingPipeline
+    n_frames, batch = 300, 50
+    sc = syn.Scene(seed=HELD_OUT_SEED, n_targets=30)
+    frames = sc.render_batch(0, n_frames)
+    runs = {}
+    for dtype in ("fp32", "fp16"):
+        pipe = TP(trained, engines[1], (720, 1280), batch=batch, ring_frames=n_frames, max_persons=64, dtype=dtype, inject=False, max_tracks=512)
+        pipe.upload(0, frames)
+        runs[dtype] = pipe.run(0, n_frames, want_dets=True)
+        c = pipe.counters()
+        assert c["assoc_host_frames"] == 0, c                     # <= 64 detections per frame: the association never leaves the device
+        y, r = pipe.yolo, pipe.reid
+        pipe.close(), y.close(), r.close()
+    # (i) recall of the planted boxes, fp16 engine
+    hit = tot = extra = 0
+    for f in range(n_frames):
+        planted = sc.detections(f)[0]
+        b, s, lab = runs["fp16"][1][f]
+        h, e = recall_and_extras(planted, b)
+        hit, tot, extra = hit + h, tot + len(planted), extra + e
+    print(f"fp16 detector, {n_frames} frames: {hit} of {tot} planted boxes found at IoU >= 0.5 ({hit / tot:.4f}), {extra} detections match none")
+    assert hit >= 0.95 * tot and extra <= 0.02 * tot
+    # (ii) fp32 HIP chain == fp32 oracle chain
+    torch.set_num_threads(16)
+    yo, ro = N.EngineOracle(trained), N.EngineOracle(engines[1])
+    trk = O.OracleTracker()
+    n_ref = 0
+    for f in range(n_frames):
+        ob, osc, ol = oracle_detect(yo, frames[f])
+        keep = [i for i in range(len(ob)) if osc[i] >= config.DEEPSORT_MIN_CONFIDENCE and config.class_name(int(ol[i])) in config.CLASSES_TO_TRACK]
+        b, c = ob[keep], osc[keep]
+        if len(b):
+            crops, valid = I.crops_to_batch(frames[f], b)
+            emb = ro.run(torch.from_numpy(crops))[ro.outputs[0][0]][:, :, 0, 0].numpy()
+        else:
+            emb, valid = np.zeros((0, 512), np.float32), np.zeros(0, bool)
+        tlwh = np.stack([b[:, 0], b[:, 1], b[:, 2] - b[:, 0], b[:, 3] - b[:, 1]], 1).astype(np.float32) if len(b) else np.zeros((0, 4), np.float32)
+        trk.predict()
+        trk.update(list(tlwh), list(c), [config.class_name(int(k)) for k in ol[keep]], [emb[i] if valid[i] else None for i in range(len(b))])
+        exp = trk.output_tuples()
+        got = runs["fp32"][0][f]
+        n_ref += len(exp)
+        hb, hs, hl = runs["fp32"][1][f]
+        assert len(hb) == len(ob) and np.array_equal(hl, ol), f     # the same detections ...
+        assert np.abs(hb - ob).max(initial=0.0) < 1e-2 and np.abs(hs - osc).max(initial=0.0) < 1e-4, (f, np.abs(hb - ob).max(), np.abs(hs - osc).max())
+        assert [t[4] for t in got] == [t[4] for t in exp] and [t[5] for t in got] == [t[5] for t in exp], (f, got, exp)   # ... and the same tracks
+        assert_rows_equal_or_on_rounding_edge([t[:4] for t in got], [t[:4] for t in exp], trk.last_output_float, f"trained own detections, frame {f}")
+    assert n_ref > 0.8 * 30 * (n_frames - 3)
+    # (iii) fp16 vs fp32, same engines, each on its own detections
+    ref = [(np.array([r[:4] for r in fr], np.float64).reshape(-1, 4), [r[4] for r in fr]) for fr in runs["fp32"][0]]
+    ev = mm.evaluate(ref, runs["fp16"][0], iou_thr=0.9)
+    print(f"fp16 vs fp32, same engines, own detections: {ev['gt']} fp32 outputs, {ev['outputs']} fp16 outputs, {ev['matches']} reproduced at IoU >= 0.9 "
+          f"({ev['matches'] / max(ev['gt'], 1):.4f}), id switches {ev['idsw']}")
+    assert ev["idsw"] == 0 and ev["matches"] >= 0.99 * ev["gt"]
+    gt = mm.scene_ground_truth(sc, n_frames)
+    q = mm.evaluate(gt, runs["fp16"][0])
+    print(f"fp16 chain against the planted identities: MOTA {q['mota']:.4f}, IDF1 {q['idf1']:.4f}, id switches {q['idsw']}, FP {q['fp']}, FN {q['fn']}")

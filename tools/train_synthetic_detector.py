@@ -44,7 +44,8 @@ syn = importlib.import_module("ai-camera_amd.synthetic")
 oi = importlib.import_module("ai-camera_amd.onnx_import")
 
 ROW0 = 128          # letterbox rows [128, 512) of the 640 x 640 input hold the 360 frame rows (pad 140) + 12 border rows each side
-ROWS = 384
+ROWS = 384          # three batches of four are these rows only (0.6 x the convolution work); every fourth is the whole 640 x 640 letterbox,
+                    # so that the flat 114-grey borders are seen as background (a net that never saw them fires all over them)
 
 
 # ------------------------------------------------------------------------------------------------ the graph as a torch module
@@ -140,13 +141,13 @@ class GraphNet(nn.Module):
 
 
 # ------------------------------------------------------------------------------------------------ data
-def letterbox_rows(frame_bgr):
-    """u8 [720, 1280, 3] BGR -> f32 [3, 384, 640] RGB / 255: the engine's preprocess for this frame size (2x2 integer mean with
-    rounding, border 114: image_processing.py:37-68,93-99), rows ROW0 .. ROW0 + ROWS of the 640 x 640 letterbox."""
+def letterbox_rows(frame_bgr, row0=ROW0, rows=ROWS):
+    """u8 [720, 1280, 3] BGR -> f32 [3, rows, 640] RGB / 255: the engine's preprocess for this frame size (2x2 integer mean with
+    rounding, border 114: image_processing.py:37-68,93-99), rows row0 .. row0 + rows of the 640 x 640 letterbox."""
     a = frame_bgr.astype(np.int32)
     small = ((a[0::2, 0::2] + a[0::2, 1::2] + a[1::2, 0::2] + a[1::2, 1::2] + 2) >> 2).astype(np.float32)
-    img = np.full((ROWS, 640, 3), 114.0, np.float32)
-    img[140 - ROW0:140 - ROW0 + 360] = small
+    img = np.full((rows, 640, 3), 114.0, np.float32)
+    img[140 - row0:140 - row0 + 360] = small
     return np.ascontiguousarray(img[:, :, ::-1].transpose(2, 0, 1)) / np.float32(255.0)
 
 
@@ -169,7 +170,7 @@ def visible_fraction(sc, frame):
     return np.where(area > 0, seen / np.maximum(area, 1), 0.0)
 
 
-def sample(rng, min_visible):
+def sample(rng, min_visible, row0=ROW0, rows=ROWS):
     """One training image: a random scene at a random time.  Person counts 4 .. 40 so that the head does not learn the count."""
     n = int(rng.integers(4, 41))
     sc = syn.Scene(seed=int(rng.integers(1 << 20, 1 << 30)), n_targets=n)      # seeds far from the bench / test scenes (0 .. 10^4)
@@ -177,12 +178,12 @@ def sample(rng, min_visible):
     frame = sc.render(f)
     vf = visible_fraction(sc, f)
     b = sc.detections(f)[0][vf >= min_visible]                                 # no gaps / births: detections() = every target
-    gt = np.stack([b[:, 0] / 2, b[:, 1] / 2 + 140 - ROW0, b[:, 2] / 2, b[:, 3] / 2 + 140 - ROW0], 1).astype(np.float32)
-    return letterbox_rows(frame), gt
+    gt = np.stack([b[:, 0] / 2, b[:, 1] / 2 + 140 - row0, b[:, 2] / 2, b[:, 3] / 2 + 140 - row0], 1).astype(np.float32)
+    return letterbox_rows(frame, row0, rows), gt
 
 
-def batch(rng, bs, min_visible, max_gt=48):
-    xs, gts = zip(*(sample(rng, min_visible) for _ in range(bs)))
+def batch(rng, bs, min_visible, max_gt=48, full=False):
+    xs, gts = zip(*(sample(rng, min_visible, *((0, 640) if full else (ROW0, ROWS))) for _ in range(bs)))
     gt = np.zeros((bs, max_gt, 4), np.float32)
     mask = np.zeros((bs, max_gt), bool)
     for i, b in enumerate(gts):
@@ -284,7 +285,7 @@ def evaluate(net, rng, n_images=8, conf=0.3, iou_thr=0.5, min_visible=0.0):
     net.eval()
     hit = tot = extra = 0
     for _ in range(n_images):
-        x, gt, m = batch(rng, 1, min_visible)
+        x, gt, m = batch(rng, 1, min_visible, full=True)
         outs = net(x)
         dfl = torch.cat([b.flatten(2) for b, _, _ in outs], 2).permute(0, 2, 1)[0]
         cls = torch.cat([c.flatten(2) for _, c, _ in outs], 2).permute(0, 2, 1)[0]
@@ -321,6 +322,7 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "weights", "yolov8n_synth.onnx"))
     ap.add_argument("--ckpt", default="/tmp/yolov8n_synth_ckpt.pt")
     ap.add_argument("--resume", action="store_true")
+    ap.add_argument("--export-only", action="store_true", help="write --out from the checkpoint as it stands (no training step)")
     args = ap.parse_args()
     torch.manual_seed(args.seed)
     torch.set_num_threads(args.threads)
@@ -334,7 +336,7 @@ def main():
     warm = 100
     sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda s: min(1.0, (s + 1) / warm) * (0.02 + 0.98 * 0.5 * (1 + math.cos(math.pi * min(s, args.steps) / args.steps))))
     step0 = 0
-    if args.resume and os.path.exists(args.ckpt):
+    if (args.resume or args.export_only) and os.path.exists(args.ckpt):
         ck = torch.load(args.ckpt)
         net.load_state_dict(ck["net"]); opt.load_state_dict(ck["opt"]); sched.load_state_dict(ck["sched"]); step0 = ck["step"]
     net.train()
@@ -345,8 +347,9 @@ def main():
 
     def want(s):
         if s < args.steps and s not in ahead:
-            ahead[s] = pool.submit(batch, np.random.default_rng([args.seed, s]), args.batch, args.min_visible)
-    for step in range(step0, args.steps):
+            full = s % 4 == 3
+            ahead[s] = pool.submit(batch, np.random.default_rng([args.seed, s]), max(1, args.batch * 5 // 8) if full else args.batch, args.min_visible, 48, full)
+    for step in range(step0, 0 if args.export_only else args.steps):
         for s in range(step, step + 4):
             want(s)
         x, gt, m = ahead.pop(step).result()
