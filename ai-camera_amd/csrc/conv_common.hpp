@@ -97,6 +97,9 @@ __device__ __forceinline__ void fast_divmod(int m, int d, float inv, int& q, int
 
 template <int ACT> __device__ __forceinline__ float act_fast(float v) {
     if constexpr (ACT == 1) {   // SiLU = v * sigmoid(v); v_exp_f32 + v_rcp_f32 (<= 1 ulp each)
+#ifdef AICAM_SILU_AS_RELU          // SIZING build only (VERDICT r4 #2c: what would a free activation be worth?) -- wrong results by design
+        return fmaxf(v, 0.0f);
+#endif
         return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f));
     } else if constexpr (ACT == 2) {
         return fmaxf(v, 0.0f);

@@ -315,6 +315,14 @@ static bool launch_sp_patch(const ConvArgs& a, hipStream_t s) {
     return true;
 }
 
+// (The same schedule with the pixel operand as an im2col tile -- for the STRIDE-2 3x3 convs of ReID layerN.0.conv1 -- was built too
+// (conv3x3_sp_igemm_kernel: per-lane row pointers + one scalar offset per step, a 9-bit tap mask per row, runs of tiles, ~70 instructions
+// per K-step besides the MFMAs; bit-identical to v4, 12 ReID tests green) and measured against v4 on 15 360 crops: 1 906 against ~1 900 us
+// on layer2.0 (64 -> 128), 951 / 1 079 against 963 / 1 159 TFLOP/s on layer3.0 / 4.0.  No gain: an im2col K-step of a stride-2 conv pulls
+// 512 half cache lines (64 bytes, 256 bytes apart) through the L2 -- 9 GB per launch on layer2.0, 4.8 TB/s of LDS-DMA at the time it
+// takes, on top of 3.2 TB/s of HBM -- and that, not the instruction count, is what those three layers wait for.  Removed; what they
+// need is the patch form on the space-to-depth view of their input, which reads every input byte once.)
+
 // shape: conv_pp_patch_shape()'s (2 = Cout 128 on 32 x 16 maps, 3 / 4 = Cout % 256 on 16 x 8 / 8 x 4 maps); the caller has checked that the
 // batch is large enough for one-block-per-CU tiles.  AICAM_NO_SP=1: v5 everywhere (A/B).
 bool conv_try_sp_patch(const ConvArgs& a, int shape, hipStream_t s) {

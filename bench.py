@@ -189,6 +189,73 @@ def plugin_loop(args, ypath, rpath, sc, dev, n_frames=240):
             "detector_boxes_per_frame": round(nd_tot / n_frames, 1), "confirmed_tracks_per_frame": round(nt_tot / n_frames, 1)}
 
 
+def own_detections_trained(args, L, TP, pipe, ypath_trained, rpath, host_frames, sc, R, frames_per_step, max_persons, dev, headline_fps):
+    """inject = 0 on a detector that SEES the persons (weights/yolov8n_synth.onnx: YOLOv8n trained on synthetic.Scene frames by
+    tools/train_synthetic_detector.py, imported through onnx_import): the reference's real data flow -- YOLODetector's own boxes ->
+    DeepSORT's confidence / class filter -> crop + ReID -> association (src/aicamera_tracker.py:180,193-195, deepsort_tracker.py:88-101)
+    -- on the headline clip, from host memory, default thresholds and tracked classes.  Reported: frames/s (2 passes after 1), where the
+    association ran, the detector's recall of the planted boxes, and fp16 (the headline's precision) against fp32 of the SAME engines,
+    each on its own detections (reproduced track outputs, id switches)."""
+    out = {"workload": "the headline clip with inject=0: the trained detector's own boxes -> confidence / class filter (conf >= 0.3, src/config.py classes) "
+                       "-> crop + ReID -> association; one stream (ReID of a launch group depends on its detector)",
+           "detector": "YOLOv8n trained on ai-camera_amd/synthetic.Scene frames (tools/train_synthetic_detector.py), weights/yolov8n_synth.onnx via onnx_import"}
+    try:
+        mm = importlib.import_module("ai-camera_amd.mot_metrics")
+        he = importlib.import_module("ai-camera_amd.hip_engine")
+        yt = he.HipEngine(ypath_trained, device=dev, dtype=args.dtype, max_items=args.batch, warm_up=False)
+        p2 = TP(yt, pipe.reid, (args.height, args.width), batch=args.batch, ring_frames=2 * R, max_persons=max_persons, device=dev,
+                dtype=args.dtype, inject=False, max_tracks=512)
+        p2.run_raw_from_host_passes(host_frames, 1)
+        L.call("aic_device_sync", dev)
+        t3 = time.perf_counter()
+        nt2, _, nd2 = p2.run_raw_from_host_passes(host_frames, 2)
+        L.call("aic_device_sync", dev)
+        dt2 = time.perf_counter() - t3
+        _, cpf = p2.group_embeddings()
+        c2 = p2.counters()
+        fps2 = 2 * frames_per_step / dt2
+        out.update({"fps": round(fps2, 1), "fraction_of_value": round(fps2 / headline_fps, 4),
+                    "nms_detections_per_frame": round(float(nd2.mean()), 2),
+                    "tracked_detections_per_frame(last launch group)": round(float(cpf.mean()), 2) if len(cpf) else None,
+                    "confirmed_tracks_per_frame": round(float(nt2.mean()), 2),
+                    "groups_filtered_on_device": c2["filter_device_groups"], "groups_filtered_on_host": c2["filter_host_groups"],
+                    "association_frames(device, host)": [c2["assoc_device_frames"], c2["assoc_host_frames"]]})
+        p2.close()
+        yt.close()
+        if args.dtype == "fp16":
+            nfr, rows_by, dets16 = 256, {}, None
+            for dt_name in ("fp32", "fp16"):
+                p3 = TP(ypath_trained, rpath, (args.height, args.width), batch=32, ring_frames=nfr, max_persons=64, device=dev, dtype=dt_name,
+                        inject=False, max_tracks=512)
+                p3.upload(0, host_frames[:nfr])
+                rows_by[dt_name], d = p3.run(0, nfr, want_dets=True)
+                if dt_name == "fp16":
+                    dets16 = d
+                y3, r3 = p3.yolo, p3.reid
+                p3.close(), y3.close(), r3.close()
+            hit = tot = extra = 0
+            for f in range(nfr):                      # recall of the planted boxes by the fp16 detector (IoU >= 0.5)
+                planted = sc.detections(f)[0]
+                iou = mm.iou_matrix(planted, dets16[f][0])
+                tot += len(planted)
+                if iou.size:
+                    hit += int((iou.max(1) >= 0.5).sum())
+                    extra += int((iou.max(0) < 0.5).sum())
+            ref = [(np.array([r[:4] for r in fr], np.float64).reshape(-1, 4), [r[4] for r in fr]) for fr in rows_by["fp32"]]
+            ev = mm.evaluate(ref, rows_by["fp16"], iou_thr=0.9)
+            gt = mm.scene_ground_truth(sc, nfr)
+            q = mm.evaluate(gt, rows_by["fp16"])
+            out["detector_vs_planted(fp16, first 256 frames)"] = {"planted_boxes": tot, "found(IoU>=0.5)": hit, "recall": round(hit / max(tot, 1), 4),
+                                                                  "detections_matching_nothing": extra}
+            out["fp16_vs_fp32_same_engine"] = {"frames": nfr, "fp32_track_outputs": ev["gt"], "fp16_track_outputs": ev["outputs"],
+                                               "reproduced(IoU>=0.9)": ev["matches"], "reproduced_fraction": round(ev["matches"] / max(ev["gt"], 1), 4),
+                                               "id_switches": ev["idsw"], "only_in_fp32": ev["fn"], "only_in_fp16": ev["fp"]}
+            out["fp16_vs_planted_identities"] = {"mota": round(q["mota"], 4), "idf1": round(q["idf1"], 4), "id_switches": q["idsw"], "fp": q["fp"], "fn": q["fn"]}
+    except Exception as e:
+        out["error"] = str(e)
+    return out
+
+
 def pct(lat_s, frames, q):
     """Latency percentile over FRAMES (every frame of a launch group shares the group's latency)."""
     if len(lat_s) == 0:
@@ -278,11 +345,18 @@ def main():
     syn = importlib.import_module("ai-camera_amd.synthetic")
     TP = importlib.import_module("ai-camera_amd.pipeline").TrackingPipeline
 
+    def trained_path():
+        try:
+            return ef.ensure_trained_detector(ROOT) if args.model == "n" else None
+        except Exception:
+            return None
     if rank == 0:
         ypath, rpath = ef.ensure_seeded_engines(ROOT, scale=args.model)
+        trained_path()
     if world > 1:
         dist.barrier()
     ypath, rpath = ef.ensure_seeded_engines(ROOT, scale=args.model)
+    ypath_trained = trained_path()             # YOLOv8n trained on the synthetic workload (weights/yolov8n_synth.onnx through onnx_import): the own-detections leg
 
     R = args.ring
     sc = syn.Scene(seed=D.stream_seed(args.seed, rank), n_targets=args.persons, width=args.width, height=args.height)
@@ -403,6 +477,9 @@ def main():
     # background texture in arbitrary classes, so every class is tracked and the tracker floor sits where ~30 detections per frame pass
     # (the headline's load).  Same clip, same engines, from host memory; filter on the device (default) and on the host beside it.
     own = None
+    own_trained = None
+    if rank == 0 and world == 1 and not args.no_own and ypath_trained and args.width == 1280 and args.height == 720:
+        own_trained = own_detections_trained(args, L, TP, pipe, ypath_trained, rpath, host_frames, sc, R, frames_per_step, max_persons, dev, fps)
     if rank == 0 and world == 1 and not args.no_own:
         try:
             cfg = importlib.import_module("ai-camera_amd.config")
@@ -549,7 +626,8 @@ def main():
                                              "wait_for_gpu": round(1e6 * host["wait_s"] / max(host["frames"], 1), 1),
                                              "tracker_chain(host side of the association)": round(1e6 * host["track_s"] / max(host["frames"], 1), 1)},
                        "plugin_loop": plug,
-                       "own_detections(inject=0 side leg, 2 passes, not `value`)": own,
+                       "own_detections_trained_detector(inject=0: the reference's data flow, 2 passes, not `value`)": own_trained,
+                       "own_detections_seeded_texture_scene(inject=0 stress leg, 2 passes, not `value`)": own,
                        "side_error": side.get("error")},
             "roofline": roof, "cpu_baseline": cpu,
         }

@@ -39,12 +39,13 @@ def graph(H, W, cin, cout, k, reps, res, stride=1):
         g.conv(f"t{i}", src, dst, cin, cout, k, stride, ef.ACT_RELU, wb=wg(cout, cin, k, ef.ACT_RELU, 0.5 if res else 1.0),
                **(dict(res=(dst, 0), res_mode=ef.RES_ADD_THEN_ACT) if res and cin == cout else {}))
         src = dst
-    p = g.buf(1, 1, cout)
-    g.simple(ef.OP_AVGPOOL, src, p, cout)
-    e = g.buf(1, 1, cout, ef.DT_F32)
-    g.simple(ef.OP_L2NORM, p, e, cout)
-    g.outputs.append([e, cout, 0, 0, 0, 0, 0, 0])
-    g.meta = [cout, 0, 0, 0, 0, 0, 0, 0]
+    co = cin if src == a else cout               # (no test conv at all -- the CB_NET baseline -- pools the stem's output)
+    p = g.buf(1, 1, co)
+    g.simple(ef.OP_AVGPOOL, src, p, co)
+    e = g.buf(1, 1, co, ef.DT_F32)
+    g.simple(ef.OP_L2NORM, p, e, co)
+    g.outputs.append([e, co, 0, 0, 0, 0, 0, 0])
+    g.meta = [co, 0, 0, 0, 0, 0, 0, 0]
     return g
 
 
