@@ -60,6 +60,7 @@ struct Chunk {
     bool filt_dev = false;           // this group went through the device filter
     int f_cap = 0;                   // rows the arrays below hold (batch * max_det: the filter cannot overflow them)
     int reid_rows = 0;               // rows the producer's (bounded) ReID round covered
+    hipStream_t s_reid_used = nullptr;   // ... and the stream it ran on
     DevBuf<int> d_rank, d_fn, d_fd0, d_total, d_fcls;
     DevBuf<float> d_ftlwh, d_fconf;
     PinBuf<int> h_fn, h_fd0, h_total;
@@ -84,7 +85,13 @@ struct Pipeline {
     std::unique_ptr<Model> yolo2, reid2;
     int dual_max = [] { const char* e = getenv("AICAM_DUAL_MAX"); return e ? atoi(e) : 128; }();   // aic_pipeline_option("dual_lane_frames")
     long n_lane1_groups = 0, n_lane1_failed = 0;
-    static constexpr int NCK = 2;   // launch groups in flight. 4 was measured: the GPU never idles, but the tracker chain then queues behind more conv work (84 -> 106 us/frame) and becomes the bound
+    // Launch groups in flight (chunk contexts in use; aic_pipeline_option("in_flight"), 2 or 3; default 2).  4 was measured in round 1 with
+    // the association on the host: the GPU never idles, but the tracker chain then queues behind more conv work (84 -> 106 us/frame) and
+    // becomes the bound.  3 was measured in round 5 with the association on the device (the consumer releases a context only when the
+    // group's epochs have run, so with two contexts the next detector is issued ~20 ms later): 10 755 against 10 960 frames/s with planted
+    // boxes, 9 561 against 9 950 with the trained detector's own (tools/own_trained.py, same box) -- slower both ways; 2 stays.
+    static constexpr int NCK = 3;
+    int nck = [] { const char* e = getenv("AICAM_IN_FLIGHT"); return e ? std::min(NCK, std::max(2, atoi(e))) : 2; }();
     Chunk ck[NCK];
     int dim;
     std::vector<float> last_emb;
@@ -251,11 +258,13 @@ struct Pipeline {
         while (copies_issued < n && copies_issued <= upto) {
             const int j = copies_issued;
             bool clash = false;
-            for (int i = std::max(0, cur_group - 1); i < j && !clash; ++i)
+            for (int i = std::max(0, cur_group - (nck - 1)); i < j && !clash; ++i)
                 clash = plan_off[i] < plan_off[j] + plan_len[j] && plan_off[j] < plan_off[i] + plan_len[i];
             if (clash && j > cur_group) break;               // copy it when its own group is issued
-            if (clash && cur_group > 0)                       // a short clip looped: group k-1 still reads these slots -> behind its launch group
-                HIP_CHECK(hipStreamWaitEvent(s_copy, ck[(cur_group - 1) % NCK].done, 0));
+            if (clash)                                        // a short clip looped: groups k - nck + 1 .. k - 1 may still read these slots -> behind their launch groups
+                for (int i = std::max(0, cur_group - (nck - 1)); i < cur_group; ++i)
+                    if (plan_off[i] < plan_off[j] + plan_len[j] && plan_off[j] < plan_off[i] + plan_len[i])
+                        HIP_CHECK(hipStreamWaitEvent(s_copy, ck[i % nck].done, 0));
             const int slot = plan_slot + plan_off[j];
             HIP_CHECK(hipMemcpyAsync(ring.p + (size_t)slot * frame_bytes, host_frames + (size_t)(slot - host_slot0) * frame_bytes,
                                      (size_t)plan_len[j] * frame_bytes, hipMemcpyHostToDevice, s_copy));
@@ -314,7 +323,7 @@ struct Pipeline {
         // consumer thread, that mode's critical thread), so the stream-ordered filter only saves a round trip where the association stays
         // on the device too.  The choice reads state the consumer wrote before it released this context: the same frames always take the
         // same path.  dev_filter 2: always on the device.
-        if (!prm.inject && dev_filter && (dev_filter == 2 || c.prev_dev_mode) && !split_streams && c.ln->reid->dtype == AIC_F16 && getenv("AICAM_NO_FUSE_CROP") == nullptr) {
+        if (!prm.inject && dev_filter && (dev_filter == 2 || c.prev_dev_mode) && c.ln->reid->dtype == AIC_F16 && getenv("AICAM_NO_FUSE_CROP") == nullptr) {
             c.ln->reid->in_pix4 = c.ln->reid->input_pix4_ok();
             c.filt_dev = c.ln->reid->in_pix4;
         }
@@ -460,7 +469,13 @@ struct Pipeline {
         HIP_CHECK(hipMemcpyAsync(c.h_fd0.p, c.d_fd0.p, (size_t)frames * 4, hipMemcpyDeviceToHost, sd));
         HIP_CHECK(hipMemcpyAsync(c.h_total.p, c.d_total.p, 8, hipMemcpyDeviceToHost, sd));
         HIP_CHECK(hipEventRecord(c.ev_det, sd));
-        HIP_CHECK(hipStreamWaitEvent(s, c.ev_det, 0));     // the crop list is in HBM: a stream dependency, not a host wait
+        HIP_CHECK(hipStreamWaitEvent(s, c.ev_det, 0));     // the crop list is in HBM: a stream dependency, not a host wait (and this lane's next group reuses the head buffers)
+        // split_streams: crop + ReID of this group on the lane's second stream, beside the DETECTOR OF THE NEXT GROUP on the main stream (inside
+        // a group ReID depends on the detector; across groups the thin YOLOv8n layers and the CU-filling ReID tiles overlap as they do with
+        // planted boxes).  The second stream follows the same event; every later piece of the group (overflow rounds, `done`) stays on it.
+        hipStream_t sr = split_streams ? c.ln->s_reid : s;
+        c.s_reid_used = sr;
+        if (sr != s) HIP_CHECK(hipStreamWaitEvent(sr, c.ev_det, 0));
         const int bound = std::min(c.ln->reid->max_items, frames * prm.max_det);
         c.reid_rows = bound;
         {
@@ -468,20 +483,20 @@ struct Pipeline {
             c.ln->reid->in_pix4 = true;
             c.ln->reid->crop_src = CropSrc{f0, prm.frame_h, prm.frame_w, c.d_boxes.p, c.d_frame_of.p, c.d_valid.p};
             c.ln->reid->n_items_dev = c.d_total.p;
-            c.ln->reid->run(bound, s);
+            c.ln->reid->run(bound, sr);
             c.ln->reid->crop_src.frames = nullptr;
             c.ln->reid->n_items_dev = nullptr;
-            HIP_CHECK(hipMemcpyAsync(c.d_emb.p, c.ln->reid->embeddings(), (size_t)bound * dim * 4, hipMemcpyDeviceToDevice, s));
+            HIP_CHECK(hipMemcpyAsync(c.d_emb.p, c.ln->reid->embeddings(), (size_t)bound * dim * 4, hipMemcpyDeviceToDevice, sr));
         }
         {
-            Prof pr(*dev, PROF_TRK, s, 0, (double)bound * dim * 8);
-            launch_normalize_rows(c.d_emb.p, c.d_emb_n.p, bound, dim, s, c.d_total.p);
+            Prof pr(*dev, PROF_TRK, sr, 0, (double)bound * dim * 8);
+            launch_normalize_rows(c.d_emb.p, c.d_emb_n.p, bound, dim, sr, c.d_total.p);
         }
         // crop validity of the round's rows for a group that ends up on the host chain: queued behind the round (61 KB at 15 360 rows), so
         // that prepare_b has no blocking copy of its own
-        HIP_CHECK(hipMemcpyAsync(c.h_valid.p, c.d_valid.p, (size_t)bound * 4, hipMemcpyDeviceToHost, s));
-        if (pipe_times) HIP_CHECK(hipEventRecord(c.t_end, s));
-        HIP_CHECK(hipEventRecord(c.done, s));
+        HIP_CHECK(hipMemcpyAsync(c.h_valid.p, c.d_valid.p, (size_t)bound * 4, hipMemcpyDeviceToHost, sr));
+        if (pipe_times) HIP_CHECK(hipEventRecord(c.t_end, sr));
+        HIP_CHECK(hipEventRecord(c.done, sr));
         n_filter_dev_groups += 1;
     }
 
@@ -502,7 +517,7 @@ struct Pipeline {
         }
         c.dev_mode = use_device(n_max, c.tracks_after);
         if (total > c.reid_rows) {             // a crowded group: every surviving detection is embedded (deepsort_tracker.py:104-113), in further rounds
-            hipStream_t s = c.ln->s_main;
+            hipStream_t s = c.s_reid_used ? c.s_reid_used : c.ln->s_main;
             const uint8_t* f0 = ring.p + (size_t)c.first_slot * frame_bytes;
             std::lock_guard<std::mutex> lk(reid_mu);
             dev->use();
@@ -751,10 +766,10 @@ struct Pipeline {
                 for (int k = 0; k < nchunks; ++k) {
                     {
                         std::unique_lock<std::mutex> lk(mu);
-                        cv.wait(lk, [&] { return k < consumed + NCK; });
+                        cv.wait(lk, [&] { return k < consumed + nck; });
                     }
                     submit_t[k] = now();
-                    stage_a(ck[k % NCK], slot + goff[k], glen[k], k, glane[k]);
+                    stage_a(ck[k % nck], slot + goff[k], glen[k], k, glane[k]);
                     {
                         std::lock_guard<std::mutex> lk(mu);
                         issued = k + 1;
@@ -777,14 +792,14 @@ struct Pipeline {
                     if (perr) break;
                 }
                 final_group = k == nchunks - 1;
-                if (ck[k % NCK].filt_dev) prepare_b(ck[k % NCK]);
-                ck[k % NCK].prev_dev_mode = ck[k % NCK].dev_mode;
-                if (ck[k % NCK].dev_mode) {
+                if (ck[k % nck].filt_dev) prepare_b(ck[k % nck]);
+                ck[k % nck].prev_dev_mode = ck[k % nck].dev_mode;
+                if (ck[k % nck].dev_mode) {
                     trk.dev_assoc = true;
-                    stage_b_device(ck[k % NCK], goff[k], n_tracks, tracks6, track_conf, n_dets, det_boxes, det_scores, det_labels);
+                    stage_b_device(ck[k % nck], goff[k], n_tracks, tracks6, track_conf, n_dets, det_boxes, det_scores, det_labels);
                 } else {
                     trk.dev_assoc = false;
-                    stage_b(ck[k % NCK], goff[k], n_tracks, tracks6, track_conf, n_dets, det_boxes, det_scores, det_labels);
+                    stage_b(ck[k % nck], goff[k], n_tracks, tracks6, track_conf, n_dets, det_boxes, det_scores, det_labels);
                 }
                 group_times.push_back(GroupTime{glen[k], submit_t[k], now()});
                 {
@@ -798,7 +813,7 @@ struct Pipeline {
         }
         {
             std::lock_guard<std::mutex> lk(mu);
-            consumed = nchunks + NCK;   // never block the producer again
+            consumed = nchunks + nck;   // never block the producer again
         }
         cv.notify_all();
         producer.join();
@@ -1052,6 +1067,10 @@ int aic_pipeline_option(aic_pipeline* p, const char* key, int value) {
             AIC_REQUIRE(value >= 0 && value <= 4096, AIC_ERR_INVALID, "dual_lane_frames must be in 0..4096 (0 = one lane; clamped to the engines' max_items)");
             AIC_REQUIRE(!p->p.lane[1].yolo || value <= p->p.yolo2->max_items, AIC_ERR_INVALID, "dual_lane_frames: the second lane already exists with a smaller arena");
             p->p.dual_max = value;
+        }
+        else if (k == "in_flight") {
+            AIC_REQUIRE(value >= 2 && value <= Pipeline::NCK, AIC_ERR_INVALID, "in_flight: 2 or 3 launch groups");
+            p->p.nck = value;
         }
         else if (k == "group_frames") {
             AIC_REQUIRE(value >= 0 && value <= p->p.prm.batch, AIC_ERR_INVALID, "group_frames must be in 0..batch");

@@ -197,7 +197,7 @@ def own_detections_trained(args, L, TP, pipe, ypath_trained, rpath, host_frames,
     association ran, the detector's recall of the planted boxes, and fp16 (the headline's precision) against fp32 of the SAME engines,
     each on its own detections (reproduced track outputs, id switches)."""
     out = {"workload": "the headline clip with inject=0: the trained detector's own boxes -> confidence / class filter (conf >= 0.3, src/config.py classes) "
-                       "-> crop + ReID -> association; one stream (ReID of a launch group depends on its detector)",
+                       "-> crop + ReID -> association; streams as in the headline (a launch group's crop + ReID on the second stream, beside the NEXT group's detector)",
            "detector": "YOLOv8n trained on ai-camera_amd/synthetic.Scene frames (tools/train_synthetic_detector.py), weights/yolov8n_synth.onnx via onnx_import"}
     try:
         mm = importlib.import_module("ai-camera_amd.mot_metrics")
@@ -205,16 +205,17 @@ def own_detections_trained(args, L, TP, pipe, ypath_trained, rpath, host_frames,
         yt = he.HipEngine(ypath_trained, device=dev, dtype=args.dtype, max_items=args.batch, warm_up=False)
         p2 = TP(yt, pipe.reid, (args.height, args.width), batch=args.batch, ring_frames=2 * R, max_persons=max_persons, device=dev,
                 dtype=args.dtype, inject=False, max_tracks=512)
+        p2.option("split_streams", 0 if args.single_stream else 1)      # the headline's stream arrangement
         p2.run_raw_from_host_passes(host_frames, 1)
         L.call("aic_device_sync", dev)
         t3 = time.perf_counter()
-        nt2, _, nd2 = p2.run_raw_from_host_passes(host_frames, 2)
+        nt2, _, nd2 = p2.run_raw_from_host_passes(host_frames, args.steps)      # as many passes as the timed region: the same share of pipeline fill
         L.call("aic_device_sync", dev)
         dt2 = time.perf_counter() - t3
         _, cpf = p2.group_embeddings()
         c2 = p2.counters()
-        fps2 = 2 * frames_per_step / dt2
-        out.update({"fps": round(fps2, 1), "fraction_of_value": round(fps2 / headline_fps, 4),
+        fps2 = args.steps * frames_per_step / dt2
+        out.update({"fps": round(fps2, 1), "passes": args.steps, "fraction_of_value": round(fps2 / headline_fps, 4),
                     "nms_detections_per_frame": round(float(nd2.mean()), 2),
                     "tracked_detections_per_frame(last launch group)": round(float(cpf.mean()), 2) if len(cpf) else None,
                     "confirmed_tracks_per_frame": round(float(nt2.mean()), 2),
@@ -626,7 +627,7 @@ def main():
                                              "wait_for_gpu": round(1e6 * host["wait_s"] / max(host["frames"], 1), 1),
                                              "tracker_chain(host side of the association)": round(1e6 * host["track_s"] / max(host["frames"], 1), 1)},
                        "plugin_loop": plug,
-                       "own_detections_trained_detector(inject=0: the reference's data flow, 2 passes, not `value`)": own_trained,
+                       "own_detections_trained_detector(inject=0: the reference's data flow, not `value`)": own_trained,
                        "own_detections_seeded_texture_scene(inject=0 stress leg, 2 passes, not `value`)": own,
                        "side_error": side.get("error")},
             "roofline": roof, "cpu_baseline": cpu,

@@ -87,14 +87,21 @@ def test_own_detections_chain_on_trained_weights(lib, trained, engines):
     sc = syn.Scene(seed=HELD_OUT_SEED, n_targets=30)
     frames = sc.render_batch(0, n_frames)
     runs = {}
-    for dtype in ("fp32", "fp16"):
-        pipe = TP(trained, engines[1], (720, 1280), batch=batch, ring_frames=n_frames, max_persons=64, dtype=dtype, inject=False, max_tracks=512)
+    for dtype in ("fp32", "fp16", "fp16 two streams"):
+        pipe = TP(trained, engines[1], (720, 1280), batch=batch, ring_frames=n_frames, max_persons=64, dtype=dtype.split()[0], inject=False, max_tracks=512)
+        if "two streams" in dtype:                                 # a group's crop + ReID on the second stream beside the next group's detector
+            pipe.option("split_streams", 1)
         pipe.upload(0, frames)
         runs[dtype] = pipe.run(0, n_frames, want_dets=True)
         c = pipe.counters()
         assert c["assoc_host_frames"] == 0, c                     # <= 64 detections per frame: the association never leaves the device
+        assert dtype == "fp32" or (c["filter_device_groups"] > 0 and c["filter_host_groups"] == 0), c
         y, r = pipe.yolo, pipe.reid
         pipe.close(), y.close(), r.close()
+    assert runs["fp16 two streams"][0] == runs["fp16"][0]         # the stream arrangement changes no row
+    for u, v in zip(runs["fp16 two streams"][1], runs["fp16"][1]):
+        assert all(np.array_equal(x, y) for x, y in zip(u, v))
+    del runs["fp16 two streams"]
     # (i) recall of the planted boxes, fp16 engine
     hit = tot = extra = 0
     for f in range(n_frames):
