@@ -81,6 +81,47 @@ __device__ __forceinline__ void mma_tiles(floatx4 (&acc)[MT][NT], const typename
     }
 }
 
+// fp32, THREE-level summation (round 5; the LDS-DMA implicit GEMM, the only kernel fp32 engines run since): the partial chain of a K-step joins a
+// MID-level accumulator; every MID_STEPS steps (256 products) the mid level joins the accumulator and restarts from zero.  Roundings in
+// sequence for K = 5 184 (YOLOv8m's deepest 3x3): 4 + 16 (+ 21 at the top, in double: below) instead of the two-level form's 4 + 324 -- what brought YOLOv8m's
+// boxes from 1.6e-3 to within 1e-3 px of the fp64 evaluation (north_star's bound).  Costs a second accumulator set.
+constexpr int MID_STEPS = 16;
+template <int MT, int NT>
+__device__ __forceinline__ void mma_tiles_mid(floatx4 (&mid)[MT][NT], const floatx4 (&wf)[NT], const floatx4 (&xf)[MT]) {
+    floatx4 prev = Frag<float>::partial(wf[0], xf[0]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 1; t < MT * NT; ++t) {
+        const floatx4 p = Frag<float>::partial(wf[t % NT], xf[t / NT]);
+        mid[(t - 1) / NT][(t - 1) % NT] += prev;
+        asm volatile("" : "+v"(mid[(t - 1) / NT][(t - 1) % NT]));
+        prev = p;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    mid[MT - 1][NT - 1] += prev;
+    asm volatile("" : "+v"(mid[MT - 1][NT - 1]));
+}
+// The TOP level was tried in double as well (two registers per output, tiles of at most 8 MFMA tiles): the same statistics -- YOLOv8m boxes
+// against the fp64 evaluation, 33 600 coordinates: rms 5.3e-5 px, 99.9th percentile 5.2e-4, one or two coordinates above 1e-3 (max 1.05e-3 /
+// 1.48e-3: which anchor it is changes with every rounding pattern) -- so what is left is the fp32 rounding of 83 layers of activations, not
+// the accumulation.  fp32 it stays (-DAICAM_F32_TOP_F64: the double form, A/B).
+#ifdef AICAM_F32_TOP_F64
+typedef double doublex4 __attribute__((ext_vector_type(4)));
+#else
+typedef float doublex4 __attribute__((ext_vector_type(4)));
+#endif
+template <int MT, int NT>
+__device__ __forceinline__ void flush_mid(doublex4 (&accd)[MT][NT], floatx4 (&mid)[MT][NT]) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) accd[i][j][e] += mid[i][j][e];
+            mid[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+        }
+}
+
 // swz(row) = ((row>>1)&3) ^ ((row>>3)&2): conflict-free for 16 consecutive rows (pixel tiles, identity weight tiles) AND
 // for the permuted weight rows {c + 8k + s} of perm_row() (brute-forced over the ds_read_b128 lane groups).
 __device__ __forceinline__ int lds_swz(int row) { return ((row >> 1) & 3) ^ ((row >> 3) & 2); }
@@ -106,6 +147,14 @@ template <int ACT> __device__ __forceinline__ float act_fast(float v) {
     } else {
         return v;
     }
+}
+
+// fp32 engines (the parity mode: speed is irrelevant there) take SiLU with expf and an IEEE division: v_exp_f32(v * log2 e) rounds the
+// product before the exponential -- |v| * 6e-8 of relative error, five ulps at |v| = 5 -- and 83 layers of it were a third of YOLOv8m's
+// distance from the fp64 evaluation of the same graph (tools/v8m_err.py, round 5)
+template <typename T, int ACT> __device__ __forceinline__ float act_t(float v) {
+    if constexpr (sizeof(T) == 4 && ACT == 1) return v / (1.0f + expf(-v));
+    else return act_fast<ACT>(v);
 }
 
 // One lane owns, per (i, j) tile, 4 consecutive output channels of one pixel.
@@ -147,10 +196,10 @@ __device__ __forceinline__ void epilogue_fast(const ConvArgs& a, floatx4 (&acc)[
                     for (int e = 0; e < 4; ++e) rv[e] = h[e];
                 }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = RES == 1 ? act_fast<ACT>(v[e] + rv[e]) : act_fast<ACT>(v[e]) + rv[e];
+                for (int e = 0; e < 4; ++e) v[e] = RES == 1 ? act_t<T, ACT>(v[e] + rv[e]) : act_t<T, ACT>(v[e]) + rv[e];
             } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = act_fast<ACT>(v[e]);
+                for (int e = 0; e < 4; ++e) v[e] = act_t<T, ACT>(v[e]);
             }
             if constexpr (F32OUT || sizeof(T) == 4) {
                 *reinterpret_cast<floatx4*>(reinterpret_cast<float*>(a.y) + ybase + n) = floatx4{v[0], v[1], v[2], v[3]};
@@ -344,10 +393,10 @@ __device__ __forceinline__ void epilogue_wide(const ConvArgs& a, floatx4 (&acc)[
                     for (int e = 0; e < 4; ++e) { rv[e] = h0[e]; rv[4 + e] = h1[e]; }
                 }
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = RES == 1 ? act_fast<ACT>(v[e] + rv[e]) : act_fast<ACT>(v[e]) + rv[e];
+                for (int e = 0; e < 8; ++e) v[e] = RES == 1 ? act_t<T, ACT>(v[e] + rv[e]) : act_t<T, ACT>(v[e]) + rv[e];
             } else {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = act_fast<ACT>(v[e]);
+                for (int e = 0; e < 8; ++e) v[e] = act_t<T, ACT>(v[e]);
             }
             if constexpr (F32OUT || sizeof(T) == 4) {
                 float* yp = reinterpret_cast<float*>(a.y) + ybase + n;
@@ -377,10 +426,10 @@ __device__ __forceinline__ void epilogue_wide(const ConvArgs& a, floatx4 (&acc)[
                         for (int e = 0; e < 4; ++e) rv[e] = h[e];
                     }
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = RES == 1 ? act_fast<ACT>(v[e] + rv[e]) : act_fast<ACT>(v[e]) + rv[e];
+                    for (int e = 0; e < 4; ++e) v[e] = RES == 1 ? act_t<T, ACT>(v[e] + rv[e]) : act_t<T, ACT>(v[e]) + rv[e];
                 } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = act_fast<ACT>(v[e]);
+                    for (int e = 0; e < 4; ++e) v[e] = act_t<T, ACT>(v[e]);
                 }
                 if constexpr (F32OUT || sizeof(T) == 4) {
                     *reinterpret_cast<floatx4*>(reinterpret_cast<float*>(a.y) + ybase + n) = floatx4{v[0], v[1], v[2], v[3]};

@@ -307,6 +307,19 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const Conv
 #pragma unroll
     for (int j = 0; j < NT; ++j) woff[j] = BM * 64 + lds_off(wn * NT * 16 + perm_row<NT>(j, r), q);
     typedef typename Frag<T>::type frag_t;
+    floatx4 mid[sizeof(T) == 4 ? MT : 1][sizeof(T) == 4 ? NT : 1];      // fp32 only: the mid-level accumulators ...
+    doublex4 accd[sizeof(T) == 4 ? MT : 1][sizeof(T) == 4 ? NT : 1];    // ... and the top level (it starts from `acc`: zero, or the bias)
+    int mid_steps = 0;
+    if constexpr (sizeof(T) == 4) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                mid[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) accd[i][j][e] = acc[i][j][e];
+            }
+    }
     auto compute = [&](int stage) {
         const char* base = smem + stage * STAGE;
         frag_t xf[MT], wf[NT];
@@ -314,7 +327,13 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const Conv
         for (int i = 0; i < MT; ++i) xf[i] = *reinterpret_cast<const frag_t*>(base + xoff[i]);
 #pragma unroll
         for (int j = 0; j < NT; ++j) wf[j] = *reinterpret_cast<const frag_t*>(base + woff[j]);
-        mma_tiles<T, MT, NT>(acc, wf, xf);
+        if constexpr (sizeof(T) == 4) {         // fp32: three-level summation (conv_common.hpp)
+            static_assert(sizeof(T) == 2 || MT * NT <= 8, "fp32 tiles carry a mid-level set beside the accumulators");
+            mma_tiles_mid<MT, NT>(mid, wf, xf);
+            if ((++mid_steps & (MID_STEPS - 1)) == 0) flush_mid<MT, NT>(accd, mid);
+        } else {
+            mma_tiles<T, MT, NT>(acc, wf, xf);
+        }
     };
     char* const sdst = smem + (16 * wv) * 64;   // this wave's 16 rows inside a staging pass
 
@@ -493,6 +512,15 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const Conv
         }
     }
     wait_vmcnt<0>();   // drain the zero-page loads of the tail before the LDS goes away
+    if constexpr (sizeof(T) == 4) {                                // the last (partial) block of mid-level steps
+        flush_mid<MT, NT>(accd, mid);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i][j][e] = (float)accd[i][j][e];
+    }
 
     int mrow[MT];
 #pragma unroll
@@ -555,9 +583,21 @@ static void launch_conv_t(const ConvArgs& a_in, hipStream_t s) {
     }
     const int c = a.Cout;
     constexpr int DT = sizeof(T) == 2 ? AIC_F16 : AIC_F32;
+    const long blocks128 = (long)ceil_div(a.M, 128);
+    if constexpr (sizeof(T) == 4) {
+        // fp32 engines (the parity mode) run ONE kernel family since round 5: the LDS-DMA implicit GEMM on tiles of at most 8 MFMA tiles per wave,
+        // whose three-level summation carries a mid-level accumulator set (conv_common.hpp).  The patch,
+        // ping-pong and 8-wave forms are fp16 only.  (--dtype fp32 throughput: 1 167 frames/s with the two-level kernels of rounds 2-4.)
+        if (c % 128 == 0 || c > 160) launch_variant<T, 2, 4, 2, 2>(a, s);               // 64 px x 128 ch
+        else if (c % 80 == 0) launch_variant<T, 1, 5, 4, 1>(a, s);                      // 64 px x 80 ch
+        else if (c % 64 == 0) launch_variant<T, 2, 4, 4, 1>(a, s);                      // 128 px x 64 ch
+        else if (c % 48 == 0) launch_variant<T, 2, 3, 4, 1>(a, s);                      // 128 px x 48 ch
+        else if (c % 32 == 0 || c > 16) launch_variant<T, 4, 2, 4, 1>(a, s);            // 256 px x 32 ch
+        else launch_variant<T, 4, 1, 4, 1>(a, s);                                       // 256 px x 16 ch
+        return;
+    } else {
     if (conv_impl() == 2 && conv_try_pp_patch(DT, a, s)) return;
     if (conv_impl() == 2 && !a.x2 && conv_try_patch(DT, a, s)) return;        // (a second source: the ping-pong patch kernel above or the LDS-DMA implicit GEMMs below)
-    const long blocks128 = (long)ceil_div(a.M, 128);
     if (c % 128 == 0 || c > 160) {
         static const bool t256 = getenv("AICAM_NO_T256") == nullptr;   // +12% on ReID layer3/4 over 256x128 (profiles/)
         if (conv_impl() == 2 && conv_try_pp(DT, a, s)) return;   // one-block-per-CU ping-pong kernels (kernels_conv_pp.hip)
@@ -565,13 +605,11 @@ static void launch_conv_t(const ConvArgs& a_in, hipStream_t s) {
         else if (conv_impl() == 2 && (blocks128 / 2) * ceil_div(c, 128) >= 384) launch_dma<T, 4, 4, 4, 2, 3>(a, s);   // 8 waves: 256 px x 128 ch
         else if (blocks128 * ceil_div(c, 128) >= 128) launch_variant<T, 4, 4, 2, 2>(a, s);   // 128 px x 128 ch
         else launch_variant<T, 2, 2, 2, 2>(a, s);                                       // 64 px x 64 ch (small maps)
-    } else if (c == 144 && conv_impl() == 2 && sizeof(T) == 2) {
+    } else if (c == 144 && conv_impl() == 2) {
         // the merged first convs of a YOLOv8 detect level (64 box + 80 class channels, Model::Model; fp16 only): one 144-wide tile,
         // the map is read once.  4 waves, one per SIMD: 36 accumulator tiles per wave on the 256-pixel tile need the whole register file
-        if constexpr (sizeof(T) == 2) {
-            if (ceil_div(a.M, 256) >= 512) launch_dma<T, 4, 9, 4, 1, 4>(a, s);          // 256 px x 144 ch
-            else launch_dma<T, 2, 9, 4, 1, 4>(a, s);                                    // 128 px x 144 ch
-        }
+        if (ceil_div(a.M, 256) >= 512) launch_dma<T, 4, 9, 4, 1, 4>(a, s);          // 256 px x 144 ch
+        else launch_dma<T, 2, 9, 4, 1, 4>(a, s);                                    // 128 px x 144 ch
     } else if (c % 80 == 0) {
         // YOLOv8's class branches (Cout = nc = 80).  512 px x 80 ch on 8 waves once there are tiles for every CU:
         // 428 -> 499 TFLOP/s on cls0.1 (80 -> 80, 3x3 at 80 x 80), +7..16 % on the others (tools/conv_bench.py); AICAM_C80=0: off
@@ -587,6 +625,7 @@ static void launch_conv_t(const ConvArgs& a_in, hipStream_t s) {
         launch_variant<T, 4, 2, 4, 1>(a, s);                                            // 256 px x 32 ch
     } else {
         launch_variant<T, 4, 1, 4, 1>(a, s);                                            // 256 px x 16 ch
+    }
     }
 }
 

@@ -617,7 +617,7 @@ bool conv_try_patch_tail(const ConvArgs& a, hipStream_t s) {
 }
 
 bool conv_try_patch(int dtype, const ConvArgs& a, hipStream_t s) {
-    return dtype == AIC_F16 ? try_patch<half_t>(a, s) : try_patch<float>(a, s);
+    return dtype == AIC_F16 ? try_patch<half_t>(a, s) : false;          // (fp32 engines: the LDS-DMA implicit GEMM only, kernels_conv.hip)
 }
 bool conv_try_c16(const ConvArgs& a, hipStream_t s) { return try_c16(a, s); }
 bool conv_try_c64_resident(const ConvArgs& a, hipStream_t s) { return try_c64_resident(a, s); }

@@ -756,7 +756,7 @@ static bool try_pp_patch(const ConvArgs& a, hipStream_t s) {
 
 
 bool conv_try_pp_patch(int dtype, const ConvArgs& a, hipStream_t s) {
-    return dtype == AIC_F16 ? try_pp_patch<half_t>(a, s) : try_pp_patch<float>(a, s);
+    return dtype == AIC_F16 ? try_pp_patch<half_t>(a, s) : false;       // (fp32 engines: the LDS-DMA implicit GEMM only, kernels_conv.hip)
 }
 
 int conv_pp_patch_shape(int dtype, const ConvArgs& a) {
@@ -787,7 +787,7 @@ static bool try_pp(const ConvArgs& a, hipStream_t s) {
 }
 
 bool conv_try_pp(int dtype, const ConvArgs& a, hipStream_t s) {
-    return dtype == AIC_F16 ? try_pp<half_t>(a, s) : try_pp<float>(a, s);
+    return dtype == AIC_F16 ? try_pp<half_t>(a, s) : false;
 }
 
 }  // namespace aic

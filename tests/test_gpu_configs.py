@@ -131,9 +131,17 @@ def test_yolov8m_head_decode_nms(gpu, engines_m, scene_1080, dtype, tol_logit, t
         eo64 = N.EngineOracle(engines_m[0], dtype=torch.float64)
         d64, c64 = (t.numpy() for t in eo64.yolo_head(torch.from_numpy(x)))
         b64 = eo64.decode(d64, c64, ft=np.float64)[0]
-        e_hip, e_cpu = np.abs(boxes - b64).max(), np.abs(rb - b64).max()
-        print(f"[YOLOv8m fp32] box err vs fp64: HIP {e_hip:.2e} px, torch-CPU fp32 {e_cpu:.2e} px")
-        assert e_hip <= max(1e-3, e_cpu)            # measured 1.6e-3 (HIP) vs 3.0e-3 (torch-CPU fp32) on YOLOv8m
+        eh, ec = np.abs(boxes - b64).ravel(), np.abs(rb - b64).ravel()
+        e_hip, e_cpu = eh.max(), ec.max()
+        print(f"[YOLOv8m fp32] box err vs fp64 over {eh.size} coordinates: HIP max {e_hip:.2e} rms {np.sqrt((eh ** 2).mean()):.2e} p99.9 {np.percentile(eh, 99.9):.2e} px, "
+              f"{int((eh > 1e-3).sum())} above 1e-3; torch-CPU fp32 max {e_cpu:.2e} rms {np.sqrt((ec ** 2).mean()):.2e} px, {int((ec > 1e-3).sum())} above 1e-3")
+        # north_star: "box coords within 1e-3 fp32".  Round 5 (three-level summation, exact SiLU in fp32 engines): rms 5.3e-5 px, 99.9th
+        # percentile 5.2e-4, ONE or TWO of the 33 600 coordinates above 1e-3 (max 1.05e-3 .. 1.5e-3 by summation variant: an anchor with a flat
+        # DFL distribution, where a 2.4e-5 logit difference moves the expectation most) -- what fp32 activations through 83 layers leave,
+        # top level in double or not; the torch-CPU fp32 evaluation of the same graph is at 3.0e-3 with ~100x as many above 1e-3.
+        # Asserted: the distribution, the count above the bound, a ceiling on the one outlier, and HIP no worse than torch-CPU fp32.
+        assert np.percentile(eh, 99.9) <= 1e-3 and np.sqrt((eh ** 2).mean()) <= 1e-4 and int((eh > 1e-3).sum()) <= 4 and e_hip <= 2e-3 and e_hip <= e_cpu
+        assert e_b < 5e-3                           # HIP vs the torch-CPU fp32 oracle's boxes (its own distance from fp64: 3.0e-3)
     else:
         assert e_b < tol_box
     kb, kml, klab = eo.decode(dfl, cls)                      # decode kernel on its own head tensor: kernel-level parity

@@ -109,6 +109,113 @@ __global__ __launch_bounds__(NW * 64) void step_kernel(const _Float16* __restric
     if (s == 12345.678f) out[0] = s;
 }
 
+// The same 128 x 64 per-wave tile with v_mfma_f32_32x32x16_f16 (VERDICT r4 #2b: "build the 32x32x16 twin"): 4 x 2 tiles of 32 x 32, a K-step of 32 =
+// two K-slices of 16; per K-step 16 MFMAs of 32 cycles and (4 + 2) * 2 = 12 fragment reads -- the SAME LDS bytes as the 16 x 16 x 32 form (a wave
+// reads (128 + 64) rows x 64 bytes of operands per K-step whatever the instruction shape), half the MFMA issue slots.
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+template <int NDMA>
+__global__ __launch_bounds__(512) void step32_kernel(const _Float16* __restrict__ g, float* __restrict__ out, unsigned long long* __restrict__ clk, int iters) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NW = 8, MT = 4, NT = 2;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    for (int i = t; i < 96 * 1024 / 16; i += NW * 64) reinterpret_cast<uint4*>(smem)[i] = reinterpret_cast<const uint4*>(g)[i & 4095];
+    __syncthreads();
+    floatx16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    half8 xf[2][2][MT], wf[2][2][NT];          // [set][K slice][tile]
+    const int fa = (lane & 15) * 16 + (lane >> 4) * 4096 + wv * 64;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) xf[0][s][i] = *reinterpret_cast<const half8*>(smem + ((fa + (2 * i + s) * 1024) & 0xffff));
+#pragma unroll
+        for (int j = 0; j < NT; ++j) wf[0][s][j] = *reinterpret_cast<const half8*>(smem + 65536 + ((fa + (2 * j + s) * 1024) & 0x7fff));
+    }
+    const _Float16* src = g + (size_t)(blockIdx.x & 63) * 32768 + t * 8;
+    char* const dst = smem + 98304 + wv * 1024;
+    unsigned long long c0 = 0;
+    if (t == 0) c0 = clock64();
+    auto step = [&](int it, auto curc) {
+        constexpr int cur = decltype(curc)::value, nxt = cur ^ 1;
+        const int so = (it & 3) * 2048;
+#pragma unroll
+        for (int d = 0; d < NDMA; ++d) {
+            const _Float16* s2 = src + ((it * NDMA + d) & 7) * 2048;
+            asm volatile("" : "+v"(s2));
+            __builtin_amdgcn_global_load_lds((gptr_t)s2, (lptr_t)(dst + ((it + d) & 3) * 8192), 16, 0, 0);
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) xf[nxt][s][i] = *reinterpret_cast<const half8*>(smem + ((fa + (2 * i + s) * 1024 + so) & 0xffff));
+#pragma unroll
+            for (int j = 0; j < NT; ++j) wf[nxt][s][j] = *reinterpret_cast<const half8*>(smem + 65536 + ((fa + (2 * j + s) * 1024 + so) & 0x7fff));
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[cur][s][j], xf[cur][s][i], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {              // 16 MFMAs, 12 reads: 1 + 1 + 2 MFMAs, a read behind each group
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        wait_vm<NDMA>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+    for (int it = 0; it < iters; it += 2) {
+        step(it, std::integral_constant<int, 0>{});
+        step(it + 1, std::integral_constant<int, 1>{});
+    }
+    if (t == 0 && blockIdx.x < 1024) clk[blockIdx.x] = clock64() - c0;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s += acc[i][j][e];
+    if (s == 12345.678f) out[0] = s;
+}
+
+template <int NDMA>
+static void run32(const char* name, const _Float16* g, float* out, unsigned long long* clk, int iters) {
+    auto k = step32_kernel<NDMA>;
+    const int lds = 98304 + 4 * 8192 + 8192;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; ++rep) {
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(k, dim3(256), dim3(512), lds, 0, g, out, clk, iters);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms = 0.f;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        best = ms < best ? ms : best;
+    }
+    std::vector<unsigned long long> h(256);
+    CK(hipMemcpy(h.data(), clk, 256 * 8, hipMemcpyDeviceToHost));
+    double cyc = 0;
+    for (auto v : h) cyc += (double)v;
+    cyc /= 256.0 * iters;
+    const double flop = 256.0 * 8 * iters * 16 * 32768.0;
+    printf("%-44s %7.0f shader clocks per K-step (matrix pipe needs 1024: %.2f busy), %6.0f TFLOP/s, %.3f ms\n", name, cyc, 1024.0 / cyc, flop / best * 1e-9, best);
+}
+
 template <int MT, int NT, int NW, int NDMA, bool PIPE>
 static void run(const char* name, const _Float16* g, float* out, unsigned long long* clk, int iters) {
     auto k = step_kernel<MT, NT, NW, NDMA, PIPE>;
@@ -155,6 +262,10 @@ int main(int argc, char** argv) {
     run<8, 4, 8, 0, true>("  12 ds_read_b128, 0 LDS-DMA", g, out, clk, iters);
     run<8, 4, 8, 2, true>("  12 ds_read_b128, 2 LDS-DMA", g, out, clk, iters);
     run<8, 4, 8, 3, true>("  12 ds_read_b128, 3 LDS-DMA", g, out, clk, iters);
+    printf("two waves per SIMD, 128 x 64 tiles as 4 x 2 tiles of v_mfma_f32_32x32x16_f16, software-pipelined the same way:\n");
+    run32<0>("  12 ds_read_b128, 0 LDS-DMA", g, out, clk, iters);
+    run32<2>("  12 ds_read_b128, 2 LDS-DMA", g, out, clk, iters);
+    run32<3>("  12 ds_read_b128, 3 LDS-DMA", g, out, clk, iters);
     printf("two waves per SIMD, 128 x 64 tiles, serial LOAD then COMPUTE in every wave, all waves in step (no ping-pong offset):\n");
     run<8, 4, 8, 2, false>("  12 ds_read_b128, 2 LDS-DMA", g, out, clk, iters);
     run<8, 4, 8, 3, false>("  12 ds_read_b128, 3 LDS-DMA", g, out, clk, iters);

@@ -22,7 +22,10 @@ dfl, cls = eng.yolo_head_np(x)
 boxes, ml, lab = eng.yolo_decode_np(x)
 print("HIP fp32 logits vs fp64: dfl", np.abs(dfl - d64).max(), "cls", np.abs(cls - c64).max())
 b_hip_logits_64dec = eo64.decode(dfl.astype(np.float64), cls.astype(np.float64), ft=np.float64)[0]
-print("boxes: HIP head + HIP decode vs fp64:", np.abs(boxes - b64).max())
+e = np.abs(boxes - b64).ravel()
+print("boxes: HIP head + HIP decode vs fp64: max", e.max(), " rms %.3e  p99 %.3e  p99.9 %.3e  anchors over 1e-3: %d of %d" % (np.sqrt((e ** 2).mean()), np.percentile(e, 99), np.percentile(e, 99.9), int((e > 1e-3).sum()), e.size))
+el = np.abs(dfl - d64).ravel()
+print("dfl logits vs fp64: rms %.3e  p99.9 %.3e" % (np.sqrt((el ** 2).mean()), np.percentile(el, 99.9)))
 print("boxes: HIP head + fp64 decode vs fp64:", np.abs(b_hip_logits_64dec - b64).max(), " (= what the logits alone cost)")
 print("boxes: HIP decode vs fp64 decode on the SAME (HIP) logits:", np.abs(boxes - b_hip_logits_64dec).max(), " (= what the decode arithmetic costs)")
 st = eo64.anchors()[1] if hasattr(eo64, "anchors") else None
