@@ -724,6 +724,8 @@ inline int conv_impl() {   // AICAM_CONV=v1 selects the register-staged kernel (
 
 // ---- host entry points of the other conv units; each returns false when the layer is not one of its shapes
 bool conv_try_pp_patch(int dtype, const ConvArgs& a, hipStream_t s);   // kernels_conv_pp.hip: v5 ping-pong patch (3x3/s1, Cout 128 / 256k)
+int conv_s2_patch_shape(const ConvArgs& a);                             // kernels_conv_sp.hip: != 0 for the 3x3 / stride-2 layers the space-to-depth patch kernel takes (k_order 3)
+bool conv_try_s2_patch(const ConvArgs& a, hipStream_t s);
 bool conv_try_sp_patch(const ConvArgs& a, int shape, hipStream_t s);    // kernels_conv_sp.hip: v6 software-pipelined patch (fp16; the shapes of v5 without a second source)
 int conv_pp_patch_shape(int dtype, const ConvArgs& a);                 // != 0 (the tile shape, pp_patch_shape) when conv_try_pp_patch would take this layer at a large enough batch
 bool conv_try_pp(int dtype, const ConvArgs& a, hipStream_t s);         // kernels_conv_pp.hip: v4 ping-pong im2col (long K, Cout 128 / 256k)

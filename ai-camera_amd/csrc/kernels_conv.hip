@@ -351,7 +351,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const Conv
             wptr[j] = okr ? wg + (size_t)(n0 + r0 + RP * j) * a.Kp + kc * CH : zero;   // weights carry NSTAGE K-steps of slack
             winc[j] = okr ? BKE : 0;
         }
-        int tap = 0, kh = 0, kw = 0, cc = 0;
+        int tap = 0, kh = 0, kw = 0, cc = 0, ti3 = 0;
         const int kord = a.k_order;                 // != 0: K-steps in another order than memory's, source pointers rebuilt every step
         const bool cmaj = kord != 0;
         // split source (ConvArgs::xs; 1x1 / 1 / 0, memory order only): K-steps 0 .. ssteps - 1 read the half-resolution tensor
@@ -419,6 +419,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const Conv
                         xs = false;
                         if (++kw == a.KW) { kw = 0; if (++kh == a.KH) { kh = 0; ++cc; } }
                     }
+                } else if (kord == 3) {                 // (cc, then the nine taps plane by plane: 0 2 6 8 | 1 7 | 3 5 | 4 -- conv3x3s2_sp_patch_kernel's order)
+                    if (++ti3 == 9) { ti3 = 0; ++cc; }
+                    const int tp = (int)((0x453718620ull >> (4 * ti3)) & 15);
+                    kh = tp / 3, kw = tp - 3 * kh;
                 } else {                                // (kw, cc, kh)
                     if (++kh == a.KH) { kh = 0; if (++cc == csteps) { cc = 0; ++kw; } }
                     if (kw == a.KW) { kw = 0; cc = csteps; }          // past the last step: zero page from here on
@@ -689,7 +693,7 @@ void launch_conv_igemm(int dtype, const ConvArgs& a0, hipStream_t s) {
         const bool c64 = dtype == AIC_F16 && a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.Cin == 64 && a.Cout == 64 && a.Kp == 576 &&
                          a.act == 2 && a.res_mode <= 1 && !a.out_f32 && !a.w_tail &&
                          a.Ho == a.H && a.Wo == a.W && ((a.W % 32 == 0 && a.H % 8 == 0) || (a.W == 32 && a.H % 4 == 0));
-        a.k_order = conv_pp_patch_shape(dtype, a) ? 1 : (c64 ? 2 : 0);
+        a.k_order = conv_pp_patch_shape(dtype, a) ? 1 : (c64 ? 2 : (conv_s2_patch_shape(a) ? 3 : 0));      // 3: the stride-2 patch kernel's order (kernels_conv_sp.hip)
     }
     if (a.x2) AIC_REQUIRE(a.k_order == 1 && a.Cout % 128 == 0 && !a.w_tail, AIC_ERR_INVALID, "conv with a second source: unsupported shape (check conv_x2_supported)");
     if (a.xs) AIC_REQUIRE(a.k_order == 0 && a.KH == 1 && a.KW == 1 && !a.w_tail && a.Kp < 16 * (dtype == AIC_F16 ? 32 : 16), AIC_ERR_INVALID,

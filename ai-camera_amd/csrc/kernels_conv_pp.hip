@@ -112,7 +112,7 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(const ConvArgs a) {
         wptr[j] = okr ? wg + (size_t)(n0 + r0 + RP * j) * a.Kp + kc * CH : zero;
         winc[j] = okr ? BKE : 0;
     }
-    int tap = 0, kh = 0, kw = 0, cc = 0;
+    int tap = 0, kh = 0, kw = 0, cc = 0, ti3 = 0;
     const int kord = a.k_order;                 // != 0: K-steps in another order than memory's, source pointers rebuilt every step
     const bool cmaj = kord != 0;
     // second source (ConvArgs::x2, chunk-major walks only): its channel chunk e is accumulated right after tap (0, 0) of the window's chunk
@@ -166,7 +166,11 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(const ConvArgs a) {
                     xs = false;
                     if (++kw == a.KW) { kw = 0; if (++kh == a.KH) { kh = 0; ++cc; } }
                 }
-            } else {                                // (kw, cc, kh)
+            } else if (kord == 3) {                 // (cc, then the nine taps plane by plane: 0 2 6 8 | 1 7 | 3 5 | 4 -- conv3x3s2_sp_patch_kernel's order)
+                if (++ti3 == 9) { ti3 = 0; ++cc; }
+                const int tp = (int)((0x453718620ull >> (4 * ti3)) & 15);
+                kh = tp / 3, kw = tp - 3 * kh;
+            } else {                            // (kw, cc, kh)
                 if (++kh == a.KH) { kh = 0; if (++cc == csteps) { cc = 0; ++kw; } }
                 if (kw == a.KW) { kw = 0; cc = csteps; }          // past the last step: zero page from here on
             }
@@ -775,6 +779,10 @@ static bool try_pp(const ConvArgs& a, hipStream_t s) {
     constexpr int BKE_ = 64 / (int)sizeof(T);
     const int c = a.Cout;
     if (!pp || a.Cin % BKE_ != 0 || !(a.Kp >= 16 * BKE_ || pp_min == 0)) return false;
+    if constexpr (sizeof(T) == 2) {                 // stride-2 3x3 layers of the patch kernels' maps: the space-to-depth patch form (kernels_conv_sp.hip)
+        if (a.k_order == 3 && ((c % 256 == 0 && (long)ceil_div(a.M, 256) * (c / 256) >= pp_min) || (c == 128 && ceil_div(a.M, 512) >= pp_min)))
+            if (conv_try_s2_patch(a, s)) return true;
+    }
     if (c % 256 == 0 && (long)ceil_div(a.M, 256) * (c / 256) >= pp_min) {                                  // 256 px x 256 ch
         launch_pp<T, 8, 4, 2, 4, 4>(a, s);
         return true;

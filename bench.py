@@ -150,12 +150,13 @@ def cpu_baseline(args, ypath, rpath):
                            "ms_per_frame_by_stage": stages1}}
 
 
-def plugin_loop(args, ypath, rpath, sc, dev, n_frames=240):
+def plugin_loop(args, ypath, rpath, sc, dev, n_frames=240, own=False):
     """The reference's OWN calling pattern (src/aicamera_tracker.py:169-207): one frame at a time, synchronously, through the plugin
     classes -- YOLODetector.detect(frame) then DeepSORT.update(boxes, scores, classes, frame) -- each call returning host NumPy / tuples
-    before the next starts.  The detector runs in full on every frame; DeepSORT.update receives the planted boxes (inject, SURVEY D7:
-    seeded weights cannot see the persons) so crop + ReID + association carry the headline's 30-person load.  Frames rendered ahead
-    (cap.read() is outside the reference's FPS span too, :170 vs :175)."""
+    before the next starts.  own = True (the trained detector): update() receives detect()'s output, exactly the reference's loop;
+    own = False (seeded weights, which cannot see the persons): update() receives the planted boxes (inject) so that crop +
+    ReID + association carry the headline's 30-person load.  Frames rendered ahead (cap.read() is outside the reference's FPS span
+    too, :170 vs :175)."""
     import contextlib
     import io
     det_mod = importlib.import_module("ai-camera_amd.detector")
@@ -174,7 +175,7 @@ def plugin_loop(args, ypath, rpath, sc, dev, n_frames=240):
         boxes, conf, cids, _ = sc.detections(f)
         t0 = time.perf_counter()
         d = det.detect(frames[f])
-        out = trk.update(boxes, conf, cids, frames[f])
+        out = trk.update(d[0], d[1], d[2], frames[f].copy()) if own else trk.update(boxes, conf, cids, frames[f])      # (:194 passes frame.copy())
         t1 = time.perf_counter()
         if f >= warm:
             lat.append(t1 - t0)
@@ -182,8 +183,9 @@ def plugin_loop(args, ypath, rpath, sc, dev, n_frames=240):
             nt_tot += len(out)
     wall = time.perf_counter() - t_all
     lat = np.sort(np.asarray(lat))
-    return {"what": "per-frame plugin loop of src/aicamera_tracker.py:169-207: YOLODetector.detect(frame) + DeepSORT.update(planted boxes, frame), synchronous, "
-                    "host arrays in and out of every call",
+    return {"what": ("per-frame plugin loop of src/aicamera_tracker.py:169-207: YOLODetector.detect(frame) + DeepSORT.update(" +
+                     ("the detector's boxes, frame.copy()" if own else "planted boxes, frame") + "), synchronous, host arrays in and out of every call"),
+            "detector": "trained on the synthetic workload (weights/yolov8n_synth.onnx)" if own else "seeded",
             "frames": n_frames, "fps": round(n_frames / float(lat.sum()), 1), "fps_wall(incl. the loop's own Python)": round(n_frames / wall, 1),
             "latency_ms_p50": round(1e3 * float(lat[len(lat) // 2]), 3), "latency_ms_p99": round(1e3 * float(lat[min(len(lat) - 1, int(0.99 * len(lat)))]), 3),
             "detector_boxes_per_frame": round(nd_tot / n_frames, 1), "confirmed_tracks_per_frame": round(nt_tot / n_frames, 1)}
@@ -548,7 +550,7 @@ def main():
     plug = None
     if rank == 0 and world == 1 and not args.no_plugin:
         try:
-            plug = plugin_loop(args, ypath, rpath, sc, dev)
+            plug = plugin_loop(args, ypath_trained, rpath, sc, dev, own=True) if ypath_trained else plugin_loop(args, ypath, rpath, sc, dev)
         except Exception as e:
             plug = {"error": str(e)}
 
