@@ -383,10 +383,10 @@ __global__ __launch_bounds__(512) void conv3x3s2_sp_patch_kernel(const ConvArgs 
     const T* zero = reinterpret_cast<const T*>(a.zero);
 
     // per-lane LDS-DMA sources: patch pixel (py, px) = view pixel (a, b) = (py - 1, px - 1) of plane (0, 0), channel chunk 0, image 0 of the
-    // tensor -- or the zero page for the halo and the padding slots -- and the pixel's image within the tile
+    // tensor as a 32-bit BYTE offset from the input (launch_s2_patch: the tensor fits 2^32 bytes), or ~0 for the halo and the padding slots
+    // (they fetch the zero page).  One register per pass: with 64-bit pointers and the pixel's image kept as well the kernel spilled.
     const int plane = wv & 3;
-    const T* pptr[NPASS];
-    int pil[NPASS];
+    unsigned poff[NPASS];
 #pragma unroll
     for (int i = 0; i < NPASS; ++i) {
         const int p = i * 128 + (wv >> 2) * 64 + lane;
@@ -394,8 +394,7 @@ __global__ __launch_bounds__(512) void conv3x3s2_sp_patch_kernel(const ConvArgs 
         const int py = rem / PW, px = rem - py * PW;
         const int va = py - 1, vb = px - 1;
         const bool ok = p < NPIX && rem < IPIX && (unsigned)va < (unsigned)TH && (unsigned)vb < (unsigned)TW;
-        pptr[i] = ok ? xg + ((size_t)((il * H + 2 * va) * W + 2 * vb) * a.x_cs + a.x_coff + plane * CH) : zero;
-        pil[i] = ok ? il : 0x40000000;
+        poff[i] = ok ? (unsigned)((((il * H + 2 * va) * W + 2 * vb) * a.x_cs + a.x_coff + plane * CH) * 2) : 0xffffffffu;
     }
     char* const pdst = smem + PATCH0 + plane * PLANE + (wv >> 2) * 1024;
     const unsigned img_bytes = (unsigned)(H * W) * a.x_cs * 2u;
@@ -420,7 +419,8 @@ __global__ __launch_bounds__(512) void conv3x3s2_sp_patch_kernel(const ConvArgs 
 
     // weights of K-step (period h, body b) of channel tile nn -> ring stage st
     auto issue_w = [&](int st, int nn, int hh, int tapi) {
-        const unsigned long long w_off = (unsigned long long)(nn / BN) * tile_wbytes + (unsigned long long)tapi * tap_bytes + (unsigned)hh * 64u;
+        unsigned long long w_off = (unsigned long long)(nn / BN) * tile_wbytes + (unsigned long long)tapi * tap_bytes + (unsigned)hh * 64u;
+        asm volatile("" : "+s"(w_off));            // opaque: or the nine wptr + tap * tap_bytes sums become loop invariants that do not fit the register file
 #pragma unroll
         for (int j = 0; j < B_PER; ++j) {
             const T* src = reinterpret_cast<const T*>(reinterpret_cast<const char*>(wptr[j]) + w_off);
@@ -429,12 +429,18 @@ __global__ __launch_bounds__(512) void conv3x3s2_sp_patch_kernel(const ConvArgs 
         }
     };
     // pass i of chunk (plane (pi, pj), period hh) of the tile at image im into patch buffer `buf`; lim: images of that tile that exist (0: none)
+    auto udiv24 = [](int x, auto dc) { constexpr int D = decltype(dc)::value; constexpr unsigned Mg = (1u << 24) / D + 1u; return (int)(__umul24((unsigned)x, Mg) >> 24); };
     auto issue_patch = [&](auto ic, int buf, int im, int lim, int pi, int pj, int hh) {
         constexpr int i = decltype(ic)::value;
-        const unsigned long long p_off = (unsigned long long)im * img_bytes + (unsigned long long)(((pi * W + pj) * a.x_cs + hh * BKE) * 2);
-        const bool live = pil[i] < lim;
-        const unsigned lo = live ? (unsigned)p_off : 0u, hi = live ? (unsigned)(p_off >> 32) : 0u;
-        const T* src = reinterpret_cast<const T*>(reinterpret_cast<const char*>(pptr[i]) + (((unsigned long long)hi << 32) | lo));
+        unsigned long long base = (unsigned long long)reinterpret_cast<uintptr_t>(xg) + (unsigned long long)im * img_bytes +
+                                  (unsigned long long)(((pi * W + pj) * a.x_cs + hh * BKE) * 2);                // scalar
+        asm volatile("" : "+s"(base));             // (opaque, as in issue_w)
+        int il = 0;                                            // the pixel's image within the tile, worked out here (not kept)
+        if constexpr (NI > 1) il = udiv24(i * 128 + (wv >> 2) * 64 + lane_here(), std::integral_constant<int, IPIXP>{});
+        const bool live = poff[i] != 0xffffffffu && il < lim;
+        const unsigned long long addr = base + poff[i];
+        const unsigned long long zaddr = (unsigned long long)reinterpret_cast<uintptr_t>(zero);
+        const T* src = reinterpret_cast<const T*>(live ? addr : zaddr);
         asm volatile("" : "+v"(src));
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(pdst + buf * PBUF + i * 2048), 16, 0, 0);
     };
