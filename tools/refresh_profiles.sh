@@ -5,7 +5,7 @@
 #   tools/refresh_profiles.sh [tag]      tag (default r02) prefixes every file copied into profiles/
 set -e
 R=$PWD
-TAG=${1:-r04}
+TAG=${1:-r05}
 O=$R/gpurun_out/refresh_$TAG
 rm -rf $O && mkdir -p $O
 B="--cpu-frames 0 --no-curve --no-own --no-plugin"     # the traces describe the headline workload only
