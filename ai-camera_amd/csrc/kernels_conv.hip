@@ -558,6 +558,13 @@ static void launch_dma(const ConvArgs& a, hipStream_t s) {
 
 template <typename T, int MT, int NT, int WM, int WN>
 static void launch_variant(const ConvArgs& a, hipStream_t s) {
+    // (A lean K-step for these small-tile launches -- kernels_conv_sp.hip's: per-lane row pointers + one scalar offset per step, next step's
+    //  fragments read under this step's MFMAs, immediates for ring stage and fragment set; bit-identical to this kernel, 31 net tests green --
+    //  was built and measured in round 5: the per-frame plugin loop's conv time 1 070 -> 1 030 us per frame (4 or 8 ring stages alike), but
+    //  16- / 64-frame launch groups 7 100 -> 6 320 and 10 300 -> 9 900 frames/s and the headline -0.4 %.  Removed.  Found on the way: with
+    //  inline-asm MFMAs and early loop exits the allocator copies accumulators between bodies -- VALU reads of matrix-pipe results the
+    //  compiler does not know are such -- and the ReID layers came out non-deterministic; in-place asm MFMAs are safe only where the
+    //  accumulators provably stay put, as in kernels_conv_sp.hip.)
     if (conv_impl() == 2) {
         // ring depth by K: a layer whose whole K is 2 .. 6 steps (YOLOv8n's 1x1 convs: K = 64 .. 192) gains nothing from a 4-deep ring, and
         // the LDS it costs halves the blocks a CU holds (80 KB per 256 x 64 tile: 2 blocks; 2 stages: 40 KB, 4 blocks).  AICAM_DMA_NSTAGE=n
