@@ -38,10 +38,10 @@ def conv_class(name):
 num = sum(a[k].get("SQ_VALU_MFMA_BUSY_CYCLES", 0) * a[k]["_n"] for k in a if conv_class(k[0]))
 den = sum(a[k].get("SQ_BUSY_CYCLES", 0) * a[k]["_n"] for k in a if conv_class(k[0]))
 nl = sum(int(a[k]["_n"]) for k in a if conv_class(k[0]))
-reid = lambda k: conv_class(k[0]) and ("c64_block" in k[0] or "pp_patch" in k[0] or "igemm_pp" in k[0])
+reid = lambda k: conv_class(k[0]) and ("c64_block" in k[0] or "pp_patch" in k[0] or "sp_patch" in k[0] or "igemm_pp" in k[0])
 num_r = sum(a[k].get("SQ_VALU_MFMA_BUSY_CYCLES", 0) * a[k]["_n"] for k in a if reid(k))
 den_r = sum(a[k].get("SQ_BUSY_CYCLES", 0) * a[k]["_n"] for k in a if reid(k))
 if den:
     print(f"\nconv class, time-weighted over {nl} launches: MFMA busy {100 * num / den / 32:.1f} % of the busy cycles "
-          f"(ReID trunk kernels c64_block / pp_patch / igemm_pp alone: {100 * num_r / max(den_r, 1) / 32:.1f} %, "
+          f"(ReID trunk kernels c64_block / pp_patch / sp_patch / s2_sp_patch / igemm_pp alone: {100 * num_r / max(den_r, 1) / 32:.1f} %, "
           f"{100 * den_r / den:.0f} % of the class's time)")
