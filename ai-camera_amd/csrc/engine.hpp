@@ -2,6 +2,7 @@
 #pragma once
 #include "kernels.hpp"
 
+#include <algorithm>
 #include <memory>
 #include <vector>
 
@@ -62,6 +63,19 @@ struct Model {
     bool reduce_cls = false;
     unsigned cls_reduced = 0, box_decoded = 0;
     bool input_pix4_ok() const;
+    // The largest launch (<= max_items) every activation tensor of which stays below 2^31 elements: the patch / block / space-to-depth conv
+    // kernels address with 32-bit offsets and hand a larger tensor to the general kernels (conv_try_c64_block & co. check M * cs < 2^31).
+    // A caller that is free to choose its launch size (the pipeline's bounded ReID round) stays at or below this: 16 384 crops of the
+    // ReID engine put layer1's 64 x 32 x 64-channel tensors at exactly 2^31 and cost 3.8 ms per launch group on the slower kernels.
+    int fast_items() const {
+        size_t per = 1;
+        for (const OpDesc& o : ops) {          // tensors a conv kernel of its own reads or writes (a fused stem's pre-pool output never exists)
+            if (o.v[0] != OP_CONV || o.fuse != 0) continue;
+            for (int bi : {o.v[1], o.v[4]}) per = std::max(per, bufs[bi].per_item / (size_t)std::max(bufs[bi].esize, 1));
+        }
+        const size_t n = std::min<size_t>((size_t)max_items, ((1ull << 31) - 1) / per);
+        return (int)(n > 64 && n < (size_t)max_items ? n / 64 * 64 : n);          // a round count: whole tiles in every layer
+    }
     void run(int n_items, hipStream_t s);
     // u8 BGR frames -> letterbox -> the whole graph; fp16 YOLO engines fuse the letterbox into the stem conv
     void run_frames(const uint8_t* frames, int n, const LetterboxGeom& g, hipStream_t s);

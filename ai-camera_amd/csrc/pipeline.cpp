@@ -400,8 +400,9 @@ struct Pipeline {
             std::lock_guard<std::mutex> lk(reid_mu);
             c.ln->reid->in_pix4 = c.ln->reid->input_pix4_ok();
             static const bool fuse_crop = getenv("AICAM_NO_FUSE_CROP") == nullptr;
-            for (int c0 = 0; c0 < nc; c0 += c.ln->reid->max_items) {   // more crops than the ReID arena holds: several launch groups, nothing dropped
-                const int k = std::min(c.ln->reid->max_items, nc - c0);
+            const int round = c.ln->reid->fast_items();
+            for (int c0 = 0; c0 < nc; c0 += round) {   // more crops than the ReID arena holds (or than its fast kernels address): several launch groups, nothing dropped
+                const int k = std::min(round, nc - c0);
                 if (fuse_crop && c.ln->reid->in_pix4) {
                     // crop + resize + normalise inside the ReID stem kernel: the crop tensor (1 GB per 15 360 crops) never exists
                     c.ln->reid->crop_src = CropSrc{f0, prm.frame_h, prm.frame_w, c.d_boxes.p + (size_t)c0 * 4, c.d_frame_of.p + c0, c.d_valid.p + c0};
@@ -476,7 +477,9 @@ struct Pipeline {
         hipStream_t sr = split_streams ? c.ln->s_reid : s;
         c.s_reid_used = sr;
         if (sr != s) HIP_CHECK(hipStreamWaitEvent(sr, c.ev_det, 0));
-        const int bound = std::min(c.ln->reid->max_items, frames * prm.max_det);
+        // (fast_items: a bound of 16 384 crops would put layer1's tensors at 2^31 elements, past what the fused block / patch kernels address;
+        // rows beyond the bound get their overflow rounds from prepare_b like any crowded group's)
+        const int bound = std::min(c.ln->reid->fast_items(), frames * prm.max_det);
         c.reid_rows = bound;
         {
             std::lock_guard<std::mutex> lk(reid_mu);
@@ -521,8 +524,9 @@ struct Pipeline {
             const uint8_t* f0 = ring.p + (size_t)c.first_slot * frame_bytes;
             std::lock_guard<std::mutex> lk(reid_mu);
             dev->use();
-            for (int c0 = c.reid_rows; c0 < total; c0 += c.ln->reid->max_items) {
-                const int k = std::min(c.ln->reid->max_items, total - c0);
+            const int round = c.ln->reid->fast_items();
+            for (int c0 = c.reid_rows; c0 < total; c0 += round) {
+                const int k = std::min(round, total - c0);
                 c.ln->reid->in_pix4 = true;
                 c.ln->reid->crop_src = CropSrc{f0, prm.frame_h, prm.frame_w, c.d_boxes.p + (size_t)c0 * 4, c.d_frame_of.p + c0, c.d_valid.p + c0};
                 c.ln->reid->run(k, s);

@@ -52,5 +52,41 @@ def main():
     print(f"\nall queues: union busy {union(alliv) / 1e6:.1f} ms = {union(alliv) / 1e6 / span:.3f} of the span")
 
 
+
+
+def timeline(path):
+    """Marker kernels of a trace, in time order: where each launch group's detector, NMS, filter and ReID rounds begin and end, and the busy
+    stretches of the tracker kernels (launches less than 0.3 ms apart merged)."""
+    marks = {"yolo_stem_fused": "YOLO begin", "select_sort_nms": "NMS", "det_filter_scatter": "filter", "reid_stem_pool2": "ReID begin",
+             "avgpool8": "ReID end (avgpool)"}
+    rows = list(csv.DictReader(open(path)))
+    t0 = min(int(r["Start_Timestamp"]) for r in rows)
+    ev, trk = [], []
+    for r in rows:
+        s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+        if "trk_epoch" in r["Kernel_Name"] or "gallery_commit" in r["Kernel_Name"]:
+            trk.append((s, e))
+        for k, lab in marks.items():
+            if k in r["Kernel_Name"]:
+                ev.append((s, e, lab, r["Queue_Id"], r.get("Grid_Size", r.get("Grid_Size_X", "?"))))
+    trk.sort()
+    cs = ce = None
+    for s, e in trk:
+        if cs is None:
+            cs, ce = s, e
+        elif s - ce < 300000:
+            ce = max(ce, e)
+        else:
+            ev.append((cs, ce, "tracker busy", "-", "-"))
+            cs, ce = s, e
+    if cs is not None:
+        ev.append((cs, ce, "tracker busy", "-", "-"))
+    ev.sort()
+    for s, e, lab, q, g in ev:
+        print(f"  t = {(s - t0) / 1e6:9.2f} .. {(e - t0) / 1e6:9.2f} ms  queue {q}  {lab:20s} grid {g}")
+
+
 if __name__ == "__main__":
     main()
+    if len(sys.argv) > 3 and sys.argv[3] == "timeline":
+        timeline(sys.argv[1])
