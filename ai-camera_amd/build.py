@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libaicam.so")
 SOURCES = ["runtime.cpp", "lsap.cpp", "assoc_host.cpp", "global_id.cpp", "tracker.cpp", "engine.cpp", "pipeline.cpp",
-           "kernels_conv.hip", "kernels_conv_pp.hip", "kernels_conv_sp.hip", "kernels_conv_direct.hip", "kernels_conv_block.hip", "kernels_conv_c2f.hip", "kernels_elt.hip",
+           "kernels_conv.hip", "kernels_conv_pp.hip", "kernels_conv_sp.hip", "kernels_conv_wide.hip", "kernels_conv_direct.hip", "kernels_conv_block.hip", "kernels_conv_c2f.hip", "kernels_elt.hip",
            "kernels_pre.hip", "kernels_det.hip", "kernels_trk.hip", "kernels_trk_dev.hip", "kernels_overlay.hip"]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-Wall",
          "-Wno-unused-function", "-Wno-unused-variable", "-DNDEBUG"] + os.environ.get("AICAM_EXTRA_FLAGS", "").split()

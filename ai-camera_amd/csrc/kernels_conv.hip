@@ -565,6 +565,10 @@ static void launch_variant(const ConvArgs& a, hipStream_t s) {
     //  inline-asm MFMAs and early loop exits the allocator copies accumulators between bodies -- VALU reads of matrix-pipe results the
     //  compiler does not know are such -- and the ReID layers came out non-deterministic; in-place asm MFMAs are safe only where the
     //  accumulators provably stay put, as in kernels_conv_sp.hip.)
+    if constexpr (sizeof(T) == 2 && WM * WN == 4) {
+        // launches of a few tiles (the per-frame plugin loop): one synchronisation per group of K-steps, bit-identical (kernels_conv_wide.hip)
+        if (conv_impl() == 2 && conv_try_wide<MT, NT, WM, WN>(a, s)) return;
+    }
     if (conv_impl() == 2) {
         // ring depth by K: a layer whose whole K is 2 .. 6 steps (YOLOv8n's 1x1 convs: K = 64 .. 192) gains nothing from a 4-deep ring, and
         // the LDS it costs halves the blocks a CU holds (80 KB per 256 x 64 tile: 2 blocks; 2 stages: 40 KB, 4 blocks).  AICAM_DMA_NSTAGE=n

@@ -1,0 +1,214 @@
+// kernels_conv_wide.hip -- the implicit GEMM for launches of a FEW tiles (fp16, round 5): one frame of YOLOv8n, thirty ReID crops -- the
+// per-frame plugin loop (src/aicamera_tracker.py:169-207 calls the engines one frame at a time).
+//
+// At those sizes a layer is 6 .. 150 blocks on 256 CUs, one block per CU, one wave per SIMD, and its time is its K loop run once:
+// conv_igemm_dma_kernel (v2) takes ~0.43 us per 32-deep K-step whatever its instruction count (a lean K-step: -4 %) and whatever its ring
+// depth (8 stages: no change) -- every step ends in "my loads have landed" + a block barrier, and with nothing else on the CU that round trip
+// is paid in full, 144 times for a ReID layer4 conv (62 us for 0.13 GFLOP).  This kernel keeps v2's tile, LDS row layout, K orders and MFMA
+// sequence per accumulator -- bit-identical outputs -- and synchronises once per GROUP of G K-steps: the ring holds NG groups of G
+// sub-stages, a group's LDS-DMA is issued NG - 1 groups ahead, one wait + one barrier per group.  3x3 (pad 1) and 1x1 (pad 0) convs of any
+// stride with Cin a multiple of 32 in memory order or the chunk-major orders (ConvArgs::k_order 0 / 1 / 3); no split / second source, no
+// 1x1 tail, no device-side item count, no bias-first (those stay on v2).
+#include "conv_common.hpp"
+
+namespace aic {
+
+// s_waitcnt vmcnt(N) alone, any N < 64 (gfx9 encoding: vmcnt in bits 3:0 and 15:14; expcnt 6:4 and lgkmcnt 11:8 left at their maxima)
+template <int N> __device__ __forceinline__ void wait_vm() { __builtin_amdgcn_s_waitcnt((N & 15) | ((N >> 4) << 14) | 0x0F70); }
+
+template <int MT, int NT, int WM, int WN, int G, int NG>
+__global__ __launch_bounds__(256) void conv_wide_kernel(const ConvArgs a) {
+    typedef half_t T;
+    constexpr int CH = 8, BKE = 32, RP = 64;
+    constexpr int BM = WM * MT * 16, BN = WN * NT * 16, BNP = (BN + RP - 1) / RP * RP;
+    constexpr int A_PER = BM / RP, B_PER = BNP / RP, LPS = A_PER + B_PER;
+    constexpr int STAGE = (BM + BNP) * 64;
+    static_assert(WM * WN == 4 && BM % RP == 0 && NG >= 2 && NG * G * STAGE <= 160 * 1024 && LPS * G * (NG - 1) < 64, "geometry");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int t = threadIdx.x;
+    const int lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int slot = t & 3, r0 = t >> 2;
+    const int kc = slot ^ lds_swz(r0);
+    const int M = a.M;
+    int tbx, tby;
+    xcd_tile_xy(a.xcd_map, tbx, tby);
+    const int m0 = tbx * BM, n0 = tby * BN;
+
+    const T* __restrict__ xg = reinterpret_cast<const T*>(a.x);
+    const T* __restrict__ wg = reinterpret_cast<const T*>(a.w);
+    const T* zero = reinterpret_cast<const T*>(a.zero);
+    const int HoWo = a.Ho * a.Wo;
+    const float inv_howo = 1.0f / (float)HoWo, inv_wo = 1.0f / (float)a.Wo;
+
+    // rows of the pixel operand this thread fetches: pointer at tap (0, 0), channel 0 (+ its 16-byte slot), and the taps inside the image
+    const char* rowp[A_PER];
+    unsigned vmask[A_PER];
+#pragma unroll
+    for (int i = 0; i < A_PER; ++i) {
+        const int m = m0 + r0 + RP * i;
+        unsigned mk = 0;
+        const char* rp = reinterpret_cast<const char*>(zero);
+        if (m < M) {
+            int img, rem, oh, ow;
+            fast_divmod(m, HoWo, inv_howo, img, rem);
+            fast_divmod(rem, a.Wo, inv_wo, oh, ow);
+            const int ih0 = oh * a.stride - a.pad, iw0 = ow * a.stride - a.pad;
+            rp = reinterpret_cast<const char*>(xg + (((long)img * a.H + ih0) * a.W + iw0) * a.x_cs + a.x_coff + kc * CH);
+            const int lo_w = max(0, -iw0), hi_w = min(a.KW, a.W - iw0);
+            const int lo_h = max(0, -ih0), hi_h = min(a.KH, a.H - ih0);
+            if (hi_w > lo_w && hi_h > lo_h) {
+                const unsigned vw = ((1u << hi_w) - 1u) & ~((1u << lo_w) - 1u);
+                const unsigned rows = (((1u << (hi_h * a.KW)) - 1u) & ~((1u << (lo_h * a.KW)) - 1u)) & a.tap_rows;
+                mk = vw * rows;
+            }
+        }
+        rowp[i] = rp;
+        vmask[i] = mk;
+    }
+    const char* wptr[B_PER];
+#pragma unroll
+    for (int j = 0; j < B_PER; ++j) {
+        const bool okr = r0 + RP * j < BN && n0 + r0 + RP * j < a.cout_pad;      // rows past the channel tile / the padded weight matrix: any in-bounds row (never read by an MFMA whose result is stored)
+        wptr[j] = reinterpret_cast<const char*>(wg + (size_t)(okr ? n0 + r0 + RP * j : 0) * a.Kp + kc * CH);
+    }
+    char* const sdst = smem + (16 * wv) * 64;
+    const int csteps = a.Cin / BKE, ntap = a.KH * a.KW, nsteps = ntap * csteps;
+    const int kord = a.k_order;
+
+    // ---- the LDS-DMA stream: K-step s_k = (tap sequence index s_ti, chunk s_cc) in the layer's K order (v2's walks, kernels_conv.hip)
+    int s_k = 0, s_ti = 0, s_cc = 0;
+    auto issue = [&](int st) {
+        const bool live = s_k < nsteps;
+        const int tap = kord == 3 ? (int)((0x453718620ull >> (4 * s_ti)) & 15) : s_ti;
+        const int kh = ntap == 1 ? 0 : (tap * 11) >> 5, kw = tap - 3 * kh;          // tap / 3 for tap < 9
+        const unsigned bit = live ? 1u << tap : 0u;
+        // (byte offsets inside one pixel window / one weight row: small.  readfirstlane: uniform by construction, and opaque -- no per-tap pointer sums kept as loop invariants)
+        const int x_off = __builtin_amdgcn_readfirstlane(((kh * a.W + kw) * a.x_cs + s_cc * BKE) * 2);
+        const int w_off = __builtin_amdgcn_readfirstlane(live ? (tap * a.Cin + s_cc * BKE) * 2 : 0);   // past the last step: step 0's weights again (in bounds, never multiplied)
+        char* const dst = sdst + st * STAGE;
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) {
+            const bool ok = (vmask[i] & bit) != 0;
+            const char* p = rowp[i] + x_off;
+            const T* src = ok ? reinterpret_cast<const T*>(p) : zero;
+            asm volatile("" : "+v"(src));
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + i * (RP * 64)), 16, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < B_PER; ++j) {
+            const T* src = reinterpret_cast<const T*>(wptr[j] + w_off);
+            asm volatile("" : "+v"(src));
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + BM * 64 + j * (RP * 64)), 16, 0, 0);
+        }
+        ++s_k;
+        if (kord == 0) { if (++s_cc == csteps) { s_cc = 0; ++s_ti; } }               // memory order: tap outer, chunk inner
+        else { if (++s_ti == ntap) { s_ti = 0; ++s_cc; } }                           // chunk-major (1: taps in order, 3: plane by plane)
+        if (s_ti >= ntap) s_ti = 0;                                                   // (past the end: any valid tap)
+    };
+    auto issue_group = [&](int gslot) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) issue(gslot * G + g);
+    };
+
+    const int wm = wv / WN, wn = wv % WN;
+    const int q = lane >> 4, r = lane & 15;
+    int xoff[MT], woff[NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) xoff[i] = lds_off((wm * MT + i) * 16 + r, q);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) woff[j] = BM * 64 + lds_off(wn * NT * 16 + perm_row<NT>(j, r), q);
+
+    floatx4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    const int ngroups = (nsteps + G - 1) / G;
+#pragma unroll
+    for (int p = 0; p < NG - 1; ++p) issue_group(p);
+    wait_vm<LPS * G * (NG - 2)>();           // group 0 has landed (this wave's part) ...
+    __builtin_amdgcn_s_barrier();               // ... and every other wave's
+    int gs = 0;                                 // ring slot of the group being multiplied
+    for (int S = 0; S < ngroups; ++S) {
+        issue_group(gs == 0 ? NG - 1 : gs - 1); // group S + NG - 1 into the slot group S - 1 left (every wave is past the barrier that closed it)
+        const char* base = smem + gs * (G * STAGE);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            if (S * G + g < nsteps) {           // (uniform; a sub-step past the end holds zeros x step 0's weights: not multiplied, -0 stays -0)
+                half8 xf[MT], wf[NT];
+#pragma unroll
+                for (int i = 0; i < MT; ++i) xf[i] = *reinterpret_cast<const half8*>(base + g * STAGE + xoff[i]);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) wf[j] = *reinterpret_cast<const half8*>(base + g * STAGE + woff[j]);
+                mma_tiles<T, MT, NT>(acc, wf, xf);
+            }
+        }
+        wait_vm<LPS * G * (NG - 2)>();       // group S + 1 has landed; the NG - 2 groups behind it may stay in flight
+        __builtin_amdgcn_s_barrier();
+        gs = gs == NG - 1 ? 0 : gs + 1;
+    }
+    wait_vmcnt<0>();
+
+    int mrow[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int m = m0 + (wm * MT + i) * 16 + r;
+        mrow[i] = m < M ? m : -1;
+    }
+    epilogue_dispatch<T, MT, NT, true, false>(a, acc, mrow, n0 + wn * NT * 16, q);
+}
+
+// The layers this kernel takes; `blocks`: the grid v2 would launch for the same tile.  AICAM_WIDE_BLOCKS: the largest grid (0: off)
+static bool conv_wide_ok(const ConvArgs& a, long blocks) {
+    static const int max_blocks = [] { const char* e = getenv("AICAM_WIDE_BLOCKS"); return e ? atoi(e) : 256; }();
+    if (blocks > max_blocks) return false;
+    if (a.xs || a.x2 || a.w_tail || a.n_dev || a.bias_init) return false;
+    if (a.k_order != 0 && a.k_order != 1 && a.k_order != 3) return false;
+    if (a.KH != a.KW || (a.KH != 1 && a.KH != 3) || a.pad != a.KH / 2 || a.Cin % 32 || a.Kp != a.KH * a.KW * a.Cin) return false;
+    if (a.KH == 3 && a.tap_rows != 0x49u) return false;
+    if (a.Kp / 32 < 8) return false;                             // a K loop of a few steps has nothing to group
+    return true;
+}
+
+template <int MT, int NT, int WM, int WN, int G, int NG>
+static void launch_wide(const ConvArgs& a, dim3 grid, hipStream_t s) {
+    constexpr int BM = WM * MT * 16, BN = WN * NT * 16, BNP = (BN + 63) / 64 * 64;
+    constexpr size_t lds = (size_t)NG * G * (BM + BNP) * 64;
+    auto kfn = conv_wide_kernel<MT, NT, WM, WN, G, NG>;
+    static bool attr = false;
+    if (!attr) {
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = true;
+    }
+    hipLaunchKernelGGL(kfn, grid, dim3(256), lds, s, a);
+    KCHECK();
+}
+
+template <int MT, int NT, int WM, int WN>
+bool conv_try_wide(const ConvArgs& a, hipStream_t s) {
+    constexpr int BM = WM * MT * 16, BN = WN * NT * 16, BNP = (BN + 63) / 64 * 64;
+    constexpr int STAGE = (BM + BNP) * 64;
+    dim3 grid(ceil_div(a.M, BM), ceil_div(a.Cout, BN));
+    if (!conv_wide_ok(a, (long)grid.x * grid.y)) return false;
+    // Ring shape (tools/ab_wide.sh, ReID layer4 at 28 crops, 60.7 us on v2): G = 4 with 3 or 5 groups in the ring 32.3 / 32.8 us, G = 2 with 10
+    // groups 34.3 us -- the depth does not matter, the number of synchronisations does; what is left (~0.22 us per 32-deep step of a 64 x 64
+    // tile) is the CU's LDS-DMA rate on half-line segments, the same ~40 GB/s per CU the large kernels see.  At most 96 .. 120 KB of LDS, so
+    // that a block of another stream's kernel still fits beside it.
+    if constexpr (STAGE <= 8 * 1024) launch_wide<MT, NT, WM, WN, 4, 3>(a, grid, s);
+    else launch_wide<MT, NT, WM, WN, 2, 3>(a, grid, s);
+    return true;
+}
+
+// the 4-wave tiles launch_variant() hands out to fp16 layers (kernels_conv.hip)
+template bool conv_try_wide<4, 4, 2, 2>(const ConvArgs&, hipStream_t);
+template bool conv_try_wide<2, 2, 2, 2>(const ConvArgs&, hipStream_t);
+template bool conv_try_wide<2, 5, 4, 1>(const ConvArgs&, hipStream_t);
+template bool conv_try_wide<4, 4, 4, 1>(const ConvArgs&, hipStream_t);
+template bool conv_try_wide<2, 4, 4, 1>(const ConvArgs&, hipStream_t);
+template bool conv_try_wide<2, 3, 4, 1>(const ConvArgs&, hipStream_t);
+template bool conv_try_wide<4, 2, 4, 1>(const ConvArgs&, hipStream_t);
+template bool conv_try_wide<4, 1, 4, 1>(const ConvArgs&, hipStream_t);
+
+}  // namespace aic

@@ -175,7 +175,7 @@ struct Pipeline {
     const uint8_t* host_frames = nullptr;   // run_from_host: frames of the current call in (pinned) host memory
     hipStream_t s_copy = nullptr;
     static constexpr int NCOPY = 8;   // H2D copies in flight: a group's frames cross PCIe up to COPY_AHEAD groups before its launch group is issued
-    static constexpr int COPY_AHEAD = 2;
+    int copy_ahead = [] { const char* e = getenv("AICAM_COPY_AHEAD"); return e ? std::min(std::max(atoi(e), 1), NCOPY - 2) : 2; }();
     hipEvent_t ev_copy[NCOPY] = {};
     std::vector<int> plan_off, plan_len;   // launch groups of the running call (ring slot offset, frames)
     int plan_slot = 0, copies_issued = 0;
@@ -298,7 +298,7 @@ struct Pipeline {
         hipStream_t s = c.ln->s_main;
         c.frames = frames, c.first_slot = slot;
         if (host_frames) {   // the reference's span: H2D of the group's frames on the copy stream, under the previous groups' compute
-            issue_copies(group_index + COPY_AHEAD);
+            issue_copies(group_index + copy_ahead);
             HIP_CHECK(hipStreamWaitEvent(s, ev_copy[group_index % NCOPY], 0));
             if (split_streams) HIP_CHECK(hipStreamWaitEvent(c.ln->s_reid, ev_copy[group_index % NCOPY], 0));
         }
