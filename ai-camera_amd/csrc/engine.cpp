@@ -638,8 +638,15 @@ DetArgs Model::det_args(int batch, float conf, float iou, int max_det, const Let
     return a;
 }
 
-void Model::decode_nms(int batch, float conf, float iou, int max_det, const LetterboxGeom* g, hipStream_t s) {
-    const DetArgs a = det_args(batch, conf, iou, max_det, g);
+void Model::decode_nms(int batch, float conf, float iou, int max_det, const LetterboxGeom* g, hipStream_t s, char* host_out) {
+    DetArgs a = det_args(batch, conf, iou, max_det, g);
+    if (host_out) {
+        AIC_REQUIRE(g != nullptr, AIC_ERR_INVALID, "decode_nms: host output wants the letterbox geometry");
+        a.num_dets = reinterpret_cast<int*>(host_out);
+        a.out_boxes_orig = reinterpret_cast<float*>(host_out + (size_t)batch * 4);
+        a.out_scores = reinterpret_cast<float*>(host_out + (size_t)batch * 4 + (size_t)batch * max_det * 16);
+        a.out_labels = reinterpret_cast<int*>(host_out + (size_t)batch * 4 + (size_t)batch * max_det * 20);
+    }
     Prof pr(*dev, PROF_DET, s, 0, (double)batch * n_anchors * (4 * meta[1] + meta[0]) * 4);
     launch_decode(a, s);
     launch_select_sort_nms(a, s);
@@ -930,6 +937,26 @@ int aic_detect(aic_model* mm, const uint8_t* frames, int batch, int h, int w, in
         const LetterboxGeom g = letterbox_geometry(h, w, m.in_h, m.in_w);
         m.reduce_cls = true;
         m.run_frames(df, batch, g, s);
+        static const bool direct = getenv("AICAM_NO_DET_HOST_OUT") == nullptr;
+        if (direct && batch <= 4 && num_dets && boxes && scores && labels) {
+            // the per-frame plugin loop: the NMS kernel stores what it keeps into page-locked host memory itself
+            const size_t per = (size_t)max_det * 24;
+            m.h_det.ensure((size_t)batch * (4 + per) + 16);
+            m.decode_nms(batch, conf, iou, max_det, &g, s, m.h_det.p);
+            HIP_CHECK(hipStreamSynchronize(s));
+            const int32_t* hn = reinterpret_cast<const int32_t*>(m.h_det.p);
+            const char* hb = m.h_det.p + (size_t)batch * 4;
+            const char* hs = hb + (size_t)batch * max_det * 16;
+            const char* hl = hb + (size_t)batch * max_det * 20;
+            for (int b = 0; b < batch; ++b) {          // rows past a frame's count are left as the caller passed them
+                const int n = std::min(std::max(hn[b], 0), max_det);
+                num_dets[b] = hn[b];
+                std::memcpy(boxes + (size_t)b * max_det * 4, hb + (size_t)b * max_det * 16, (size_t)n * 16);
+                std::memcpy(scores + (size_t)b * max_det, hs + (size_t)b * max_det * 4, (size_t)n * 4);
+                std::memcpy(labels + (size_t)b * max_det, hl + (size_t)b * max_det * 4, (size_t)n * 4);
+            }
+            return;
+        }
         m.decode_nms(batch, conf, iou, max_det, &g, s);
         copy_out(num_dets, m.d_numdets.p, (size_t)batch * 4, AIC_HOST, s);
         copy_out(boxes, m.d_out_boxes_orig.p, (size_t)batch * max_det * 16, AIC_HOST, s);

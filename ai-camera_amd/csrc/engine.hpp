@@ -84,7 +84,11 @@ struct Model {
     int sub_items = 0;
     // YOLO post-processing on the buffers left by run()
     DetArgs det_args(int batch, float conf, float iou, int max_det, const LetterboxGeom* g);
-    void decode_nms(int batch, float conf, float iou, int max_det, const LetterboxGeom* g, hipStream_t s);
+    // host_out: the kept detections (counts, original-pixel boxes, scores, labels) are stored straight into this page-locked host block by
+    // the NMS kernel -- [batch] int32 | [batch, max_det, 4] f32 | [batch, max_det] f32 | [batch, max_det] int32 -- instead of the device
+    // arrays: aic_detect's per-frame calls then end in one stream sync and no copy (four pageable D2H copies cost ~60 us of a 1.65 ms frame)
+    void decode_nms(int batch, float conf, float iou, int max_det, const LetterboxGeom* g, hipStream_t s, char* host_out = nullptr);
+    PinBuf<char> h_det;
     const float* embeddings() const { return reinterpret_cast<const float*>(bufs[outs[0].v[0]].p); }
 };
 
