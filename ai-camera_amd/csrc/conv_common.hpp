@@ -729,6 +729,7 @@ bool conv_try_s2_patch(const ConvArgs& a, hipStream_t s);
 bool conv_try_sp_patch(const ConvArgs& a, int shape, hipStream_t s);    // kernels_conv_sp.hip: v6 software-pipelined patch (fp16; the shapes of v5 without a second source)
 // kernels_conv_wide.hip: the 4-wave LDS-DMA implicit GEMM with one wait + barrier per GROUP of K-steps, for launches of a few tiles (fp16)
 template <int MT, int NT, int WM, int WN> bool conv_try_wide(const ConvArgs& a, hipStream_t s);
+template <int MT, int NT> bool conv_try_wide_tail(const ConvArgs& a, hipStream_t s);      // 4 x 1 waves, the lead of a (conv, 1x1) pair (ConvArgs::w_tail)
 int conv_pp_patch_shape(int dtype, const ConvArgs& a);                 // != 0 (the tile shape, pp_patch_shape) when conv_try_pp_patch would take this layer at a large enough batch
 bool conv_try_pp(int dtype, const ConvArgs& a, hipStream_t s);         // kernels_conv_pp.hip: v4 ping-pong im2col (long K, Cout 128 / 256k)
 bool conv_try_patch(int dtype, const ConvArgs& a, hipStream_t s);      // kernels_conv_direct.hip: 4-wave patch kernel (Cout 64 / 32)

@@ -596,6 +596,7 @@ void Model::run_range(size_t op0, size_t op1, int i0, int n, hipStream_t s) {
         } else {
             EltArgs a{};
             a.src = sb.p, a.dst = db.p, a.n = n, a.h = sb.h, a.w = sb.w, a.c = v[3];
+            if (emb_host_out && oi + 1 == ops.size() && v[0] == OP_L2NORM && i0 == 0 && v[4] == outs[0].v[0]) a.dst = emb_host_out;
             a.s_cs = sb.c, a.s_coff = v[2], a.d_cs = db.c, a.d_coff = v[5];
             a.n_dev = n_items_dev;
             Prof pr(*dev, PROF_MISC, s, 0, 0);
@@ -981,9 +982,31 @@ int aic_reid_embed(aic_model* mm, const uint8_t* frame, int h, int w, int mem, c
         m.d_valid.ensure(n);
         HIP_CHECK(hipMemcpyAsync(m.d_crop_boxes.p, boxes, (size_t)n * 16, hipMemcpyHostToDevice, s));
         m.in_pix4 = m.input_pix4_ok();
+        static const bool fuse_crop = getenv("AICAM_NO_FUSE_CROP") == nullptr;
+        static const bool direct = getenv("AICAM_NO_EMB_HOST_OUT") == nullptr;
+        const BufDesc& eb = m.bufs[m.outs[0].v[0]];
+        if (direct && fuse_crop && n <= m.max_items && n <= 512 && m.in_pix4 && m.in_h <= 192 && mem != AIC_DEVICE && eb.f32 &&
+            eb.c == m.out_dim && m.outs[0].v[2] == 0 && m.ops.back().v[0] == OP_L2NORM && m.ops.back().v[5] == 0) {
+            // the per-frame plugin loop: embeddings and crop validity are stored into page-locked host memory by the kernels that produce them
+            const size_t eb_bytes = (size_t)n * m.out_dim * 4;
+            m.h_emb.ensure(eb_bytes + (size_t)n * 4 + 16);
+            int* hv = reinterpret_cast<int*>(m.h_emb.p + eb_bytes);
+            m.crop_src = CropSrc{df, h, w, m.d_crop_boxes.p, nullptr, hv};
+            m.emb_host_out = reinterpret_cast<float*>(m.h_emb.p);
+            try {
+                m.run(n, s);
+            } catch (...) {
+                m.crop_src.frames = nullptr, m.emb_host_out = nullptr;
+                throw;
+            }
+            m.crop_src.frames = nullptr, m.emb_host_out = nullptr;
+            HIP_CHECK(hipStreamSynchronize(s));
+            std::memcpy(emb, m.h_emb.p, eb_bytes);
+            if (valid) std::memcpy(valid, hv, (size_t)n * 4);
+            return;
+        }
         for (int c0 = 0; c0 < n; c0 += m.max_items) {   // launch groups of max_items: every detection is embedded (deepsort_tracker.py:104-113)
             const int k = std::min(m.max_items, n - c0);
-            static const bool fuse_crop = getenv("AICAM_NO_FUSE_CROP") == nullptr;
             if (fuse_crop && m.in_pix4 && m.in_h <= 192 && mem != AIC_DEVICE) {
                 // crop + resize + normalise inside the stem kernel, as the pipeline does it (same arithmetic, pixel for pixel): one launch fewer
                 // per call of the per-frame plugin loop, and no crop tensor.  (A caller's own device buffer keeps the separate crop kernel:

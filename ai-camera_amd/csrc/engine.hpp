@@ -89,6 +89,10 @@ struct Model {
     // arrays: aic_detect's per-frame calls then end in one stream sync and no copy (four pageable D2H copies cost ~60 us of a 1.65 ms frame)
     void decode_nms(int batch, float conf, float iou, int max_det, const LetterboxGeom* g, hipStream_t s, char* host_out = nullptr);
     PinBuf<char> h_det;
+    // set around run() by aic_reid_embed's per-frame calls: the graph's LAST op (the embedding's L2 normalisation) stores into this
+    // page-locked host block instead of its arena buffer -- no copy behind the run, one stream sync
+    float* emb_host_out = nullptr;
+    PinBuf<char> h_emb;
     const float* embeddings() const { return reinterpret_cast<const float*>(bufs[outs[0].v[0]].p); }
 };
 

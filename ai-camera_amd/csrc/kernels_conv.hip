@@ -622,12 +622,13 @@ static void launch_conv_t(const ConvArgs& a_in, hipStream_t s) {
         if (t256 && conv_impl() == 2 && c % 256 == 0 && (long)ceil_div(a.M, 256) * (c / 256) >= 200) launch_dma<T, 8, 4, 2, 4, 4>(a, s);   // 8 waves: 256 px x 256 ch
         else if (conv_impl() == 2 && (blocks128 / 2) * ceil_div(c, 128) >= 384) launch_dma<T, 4, 4, 4, 2, 3>(a, s);   // 8 waves: 256 px x 128 ch
         else if (blocks128 * ceil_div(c, 128) >= 128) launch_variant<T, 4, 4, 2, 2>(a, s);   // 128 px x 128 ch
+        else if ((long)ceil_div(a.M, 64) * ceil_div(c, 64) > 256 && conv_impl() == 2 && conv_try_wide<4, 4, 2, 2>(a, s)) return;   // too many 64 x 64 tiles for the wide-step kernel, few enough 128 x 128 ones
         else launch_variant<T, 2, 2, 2, 2>(a, s);                                       // 64 px x 64 ch (small maps)
     } else if (c == 144 && conv_impl() == 2) {
         // the merged first convs of a YOLOv8 detect level (64 box + 80 class channels, Model::Model; fp16 only): one 144-wide tile,
         // the map is read once.  4 waves, one per SIMD: 36 accumulator tiles per wave on the 256-pixel tile need the whole register file
         if (ceil_div(a.M, 256) >= 512) launch_dma<T, 4, 9, 4, 1, 4>(a, s);          // 256 px x 144 ch
-        else launch_dma<T, 2, 9, 4, 1, 4>(a, s);                                    // 128 px x 144 ch
+        else if (!conv_try_wide<2, 9, 4, 1>(a, s)) launch_dma<T, 2, 9, 4, 1, 4>(a, s);   // 128 px x 144 ch (a few tiles: kernels_conv_wide.hip)
     } else if (c % 80 == 0) {
         // YOLOv8's class branches (Cout = nc = 80).  512 px x 80 ch on 8 waves once there are tiles for every CU:
         // 428 -> 499 TFLOP/s on cls0.1 (80 -> 80, 3x3 at 80 x 80), +7..16 % on the others (tools/conv_bench.py); AICAM_C80=0: off
@@ -636,6 +637,7 @@ static void launch_conv_t(const ConvArgs& a_in, hipStream_t s) {
         else launch_variant<T, 2, 5, 4, 1>(a, s);                                       // 128 px x 80 ch
     } else if (c % 64 == 0) {
         if (blocks128 >= 512) launch_variant<T, 4, 4, 4, 1>(a, s);                      // 256 px x 64 ch
+        else if (blocks128 * ceil_div(c, 64) > 256 && conv_impl() == 2 && conv_try_wide<4, 4, 4, 1>(a, s)) return;   // (as above: 256 px tiles where the 128 px grid is too large for the wide-step kernel)
         else launch_variant<T, 2, 4, 4, 1>(a, s);                                       // 128 px x 64 ch
     } else if (c % 48 == 0) {
         launch_variant<T, 2, 3, 4, 1>(a, s);                                            // 128 px x 48 ch
@@ -688,10 +690,10 @@ static void launch_conv_tail(const ConvArgs& a, hipStream_t s) {
     if (a.Cout == 64) {
         if (conv_try_patch_tail(a, s)) return;
         if ((long)ceil_div(a.M, 128) >= 512) launch_dma<half_t, 4, 4, 4, 1, 4, true>(a, s);   // 256 px x 64 ch
-        else launch_dma<half_t, 2, 4, 4, 1, 4, true>(a, s);                                   // 128 px x 64 ch
+        else if (!conv_try_wide_tail<2, 4>(a, s)) launch_dma<half_t, 2, 4, 4, 1, 4, true>(a, s);   // 128 px x 64 ch (a few tiles: kernels_conv_wide.hip)
     } else {                                                                                  // 80
         if (ceil_div(a.M, 512) >= 256) launch_dma<half_t, 4, 5, 8, 1, 3, true>(a, s);          // 512 px x 80 ch
-        else launch_dma<half_t, 2, 5, 4, 1, 4, true>(a, s);                                   // 128 px x 80 ch
+        else if (!conv_try_wide_tail<2, 5>(a, s)) launch_dma<half_t, 2, 5, 4, 1, 4, true>(a, s);   // 128 px x 80 ch
     }
 }
 
