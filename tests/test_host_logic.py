@@ -213,6 +213,7 @@ def test_no_conv_kernel_spills():
     assert len(hot) > 60, len(hot)
     # fp32 and fp16 instantiations (fp32 engines run the LDS-DMA implicit GEMM only since round 5; the patch kernels are fp16)
     assert any("conv_igemm_dma_kernelIf" in k for k in hot) and any("patch_kernelIDF16_" in k for k in hot) and any("sp_patch_kernel" in k for k in hot)
+    assert sum("conv_wide_kernel" in k for k in hot) >= 12           # the few-tiles kernel: plain, second-source and tail forms (kernels_conv_wide.hip)
     # (up to four dwords parked ONCE per block across the K loop -- an address pair that is written before the loop and read by the
     # epilogue -- are tolerated: the 512 x 128 ping-pong patch kernel sits exactly at its 256-register cap; anything inside a loop shows up as far more)
     bad = {k: r for k, r in hot.items() if r["scratch"] > 16 or r["vgpr_spills"] > 4}
