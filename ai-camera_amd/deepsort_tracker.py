@@ -8,6 +8,19 @@ from .core.tracker_core import TrackerCore
 from .reid_model import ReIDModel
 
 
+def _tracked_lut():
+    """Boolean table over class ids: is the id's name in config.CLASSES_TO_TRACK (rebuilt when either is replaced or resized)."""
+    key = (id(config.CLASSES), len(config.CLASSES), frozenset(config.CLASSES_TO_TRACK))
+    if _tracked_lut.key != key:
+        _tracked_lut.lut = np.array([n in config.CLASSES_TO_TRACK for n in config.CLASSES], dtype=bool)
+        _tracked_lut.key = key
+    return _tracked_lut.lut
+
+
+_tracked_lut.key = None
+_tracked_lut.lut = None
+
+
 class DeepSORT:
     def __init__(self, reid_model_path=str(config.REID_ENGINE_PATH), reid_input_shape=config.REID_INPUT_SHAPE,
                  max_cosine_distance=config.DEEPSORT_MAX_DIST, nn_budget=config.DEEPSORT_NN_BUDGET,
@@ -35,9 +48,11 @@ class DeepSORT:
         boxes = np.asarray(yolo_bboxes_xyxy, dtype=np.float32).reshape(-1, 4)
         confs = np.asarray(yolo_confidences, dtype=np.float32).reshape(-1)
         cids = np.asarray(yolo_class_ids).reshape(-1).astype(np.int64)
-        keep = [i for i in range(len(boxes))                                          # :88-95
-                if confs[i] >= self.min_detection_confidence and config.class_name(int(cids[i])) in config.CLASSES_TO_TRACK]
-        if keep:
+        # :88-95 for all detections at once: confidence floor, and the class NAME (out-of-range ids are "Unknown") among the tracked ones
+        lut = _tracked_lut()
+        known = (cids >= 0) & (cids < len(lut))
+        keep = np.nonzero((confs >= self.min_detection_confidence) & known & lut[np.where(known, cids, 0)])[0]
+        if len(keep):
             b, c, k = boxes[keep], confs[keep], cids[keep].astype(np.int32)
             feats, valid = self.reid_model.embed_boxes(original_frame_bgr, b)         # :104-113 fused
             tlwh = np.stack([b[:, 0], b[:, 1], b[:, 2] - b[:, 0], b[:, 3] - b[:, 1]], axis=1).astype(np.float32)  # :185-186
@@ -45,5 +60,4 @@ class DeepSORT:
         else:
             self.tracker_core.update_arrays(np.zeros((0, 4), np.float32), np.zeros(0, np.float32), np.zeros(0, np.int32), None)
         rows, conf = self.tracker_core.outputs()
-        return [(int(r[0]), int(r[1]), int(r[2]), int(r[3]), int(r[4]), config.class_name(int(r[5])), float(cf))
-                for r, cf in zip(rows, conf)]
+        return [(r[0], r[1], r[2], r[3], r[4], config.class_name(r[5]), cf) for r, cf in zip(rows.tolist(), conf.tolist())]
