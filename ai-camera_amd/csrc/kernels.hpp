@@ -33,8 +33,6 @@ struct ConvArgs {
                         //   0 = (kh, kw, cc)  tap-major, the memory order of the packed weights (default);
                         //   1 = (cc, kh, kw)  the order of the ping-pong patch kernel (conv3x3_pp_patch_kernel);
                         //   2 = (kw, cc, kh)  the order of the weights-resident 64-channel kernels (conv3x3_c64_resident / _block).
-                        //   3 = (cc, taps plane by plane) the stride-2 space-to-depth patch kernel's; 5 = order 1 with the second source's chunks
-                        //       (ConvArgs::x2) behind the whole window instead of interleaved (round 5: conv3x3_sp_patch_kernel's phase for them)
                         // Set by launch_conv_igemm from the layer SHAPE: a layer one of those kernels can take is accumulated in that
                         // kernel's order by EVERY kernel its batch size may select, so embeddings do not depend on the batch
     // ---- optional SECOND SOURCE: a 1x1 conv of another tensor accumulated into the same outputs (ResNet's downsample branch folded into

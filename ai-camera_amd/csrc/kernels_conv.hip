@@ -366,11 +366,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const Conv
         };
         // second source (ConvArgs::x2, chunk-major walks only): its channel chunk e is accumulated right after tap (0, 0) of the window's chunk
         // e + 1 -- the place conv3x3_pp_patch_kernel has for it; every kernel walks the same order.  xs: the step being set up is that chunk, e = cc - 1
-        const int csteps2 = (a.x2 && (kord == 1 || kord == 5)) ? a.Cin2 / BKE : 0;      // order 5: the second source's chunks come LAST (after every window chunk)
+        const int csteps2 = (a.x2 && kord == 1) ? a.Cin2 / BKE : 0;
         bool xs = false;
         auto set_tap = [&] {
             if (xs) {
-                const int c2 = kord == 5 ? cc - csteps : cc - 1;
+                const int c2 = cc - 1;
 #pragma unroll
                 for (int i = 0; i < A_PER; ++i) {
                     const int m = m0 + r0 + RP * i;
@@ -406,10 +406,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const Conv
                 aptr[i] += ainc[i];
             }
             if (cmaj) {
-                const int koff = xs ? ntap * a.Cin + (kord == 5 ? cc - csteps : cc - 1) * BKE : tap * a.Cin + cc * BKE;
+                const int koff = xs ? ntap * a.Cin + (cc - 1) * BKE : tap * a.Cin + cc * BKE;
 #pragma unroll
                 for (int j = 0; j < B_PER; ++j) {
-                    const T* src = (winc[j] && (cc < csteps || xs)) ? wptr[j] + koff : zero;
+                    const T* src = (winc[j] && cc < csteps) ? wptr[j] + koff : zero;
                     asm volatile("" : "+v"(src));
                     __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sbase + BM * 64 + j * (RP * 64)), 16, 0, 0);
                 }
@@ -419,9 +419,6 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_dma_kernel(const Conv
                         xs = false;
                         if (++kw == a.KW) { kw = 0; if (++kh == a.KH) { kh = 0; ++cc; } }
                     }
-                } else if (kord == 5) {                 // (cc, kh, kw) over the window, THEN the second source's chunks 0 .. csteps2 - 1 (cc = csteps + e)
-                    if (xs) { if (++cc - csteps >= csteps2) xs = false; }
-                    else if (++kw == a.KW) { kw = 0; if (++kh == a.KH) { kh = 0; if (++cc == csteps && csteps2) xs = true; } }
                 } else if (kord == 3) {                 // (cc, then the nine taps plane by plane: 0 2 6 8 | 1 7 | 3 5 | 4 -- conv3x3s2_sp_patch_kernel's order)
                     if (++ti3 == 9) { ti3 = 0; ++cc; }
                     const int tp = (int)((0x453718620ull >> (4 * ti3)) & 15);
@@ -713,12 +710,8 @@ void launch_conv_igemm(int dtype, const ConvArgs& a0, hipStream_t s) {
                          a.act == 2 && a.res_mode <= 1 && !a.out_f32 && !a.w_tail &&
                          a.Ho == a.H && a.Wo == a.W && ((a.W % 32 == 0 && a.H % 8 == 0) || (a.W == 32 && a.H % 4 == 0));
         a.k_order = conv_pp_patch_shape(dtype, a) ? 1 : (c64 ? 2 : (conv_s2_patch_shape(a) ? 3 : 0));      // 3: the stride-2 patch kernel's order (kernels_conv_sp.hip)
-        // a second source: its chunks LAST (order 5) -- the software-pipelined patch kernel runs them as a short phase of its own behind
-        // its unrolled K loop (kernels_conv_sp.hip); AICAM_X2_ORDER1=1: round 3's place (behind tap (0, 0) of the next window chunk, v5's)
-        static const bool x2_last = getenv("AICAM_X2_ORDER1") == nullptr;
-        if (a.x2 && a.k_order == 1 && x2_last) a.k_order = 5;
     }
-    if (a.x2) AIC_REQUIRE((a.k_order == 1 || a.k_order == 5) && a.Cout % 128 == 0 && !a.w_tail, AIC_ERR_INVALID, "conv with a second source: unsupported shape (check conv_x2_supported)");
+    if (a.x2) AIC_REQUIRE(a.k_order == 1 && a.Cout % 128 == 0 && !a.w_tail, AIC_ERR_INVALID, "conv with a second source: unsupported shape (check conv_x2_supported)");
     if (a.xs) AIC_REQUIRE(a.k_order == 0 && a.KH == 1 && a.KW == 1 && !a.w_tail && a.Kp < 16 * (dtype == AIC_F16 ? 32 : 16), AIC_ERR_INVALID,
                           "conv with a split source: unsupported shape (check conv_xs_supported)");
     if (a.w_tail) {

@@ -117,11 +117,11 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(const ConvArgs a) {
     const bool cmaj = kord != 0;
     // second source (ConvArgs::x2, chunk-major walks only): its channel chunk e is accumulated right after tap (0, 0) of the window's chunk
     // e + 1 -- the place conv3x3_pp_patch_kernel has for it; every kernel walks the same order.  xs: the step being set up is that chunk, e = cc - 1
-    const int csteps2 = (a.x2 && (kord == 1 || kord == 5)) ? a.Cin2 / BKE : 0;      // order 5: the second source's chunks come LAST (after every window chunk)
+    const int csteps2 = (a.x2 && kord == 1) ? a.Cin2 / BKE : 0;
     bool xs = false;
     auto set_tap = [&] {
         if (xs) {
-            const int c2 = kord == 5 ? cc - csteps : cc - 1;
+            const int c2 = cc - 1;
 #pragma unroll
             for (int i = 0; i < A_PER; ++i) {
                 const int m = m0 + r0 + RP * i;
@@ -153,10 +153,10 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(const ConvArgs a) {
             aptr[i] += ainc[i];
         }
         if (cmaj) {
-            const int koff = xs ? ntap * a.Cin + (kord == 5 ? cc - csteps : cc - 1) * BKE : tap * a.Cin + cc * BKE;
+            const int koff = xs ? ntap * a.Cin + (cc - 1) * BKE : tap * a.Cin + cc * BKE;
 #pragma unroll
             for (int j = 0; j < B_PER; ++j) {
-                const T* src = (winc[j] && (cc < csteps || xs)) ? wptr[j] + koff : zero;
+                const T* src = (winc[j] && cc < csteps) ? wptr[j] + koff : zero;
                 asm volatile("" : "+v"(src));
                 __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sbase + BM * 64 + j * (RP * 64)), 16, 0, 0);
             }
@@ -166,9 +166,6 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(const ConvArgs a) {
                     xs = false;
                     if (++kw == a.KW) { kw = 0; if (++kh == a.KH) { kh = 0; ++cc; } }
                 }
-            } else if (kord == 5) {                 // (cc, kh, kw) over the window, THEN the second source's chunks 0 .. csteps2 - 1 (cc = csteps + e)
-                if (xs) { if (++cc - csteps >= csteps2) xs = false; }
-                else if (++kw == a.KW) { kw = 0; if (++kh == a.KH) { kh = 0; if (++cc == csteps && csteps2) xs = true; } }
             } else if (kord == 3) {                 // (cc, then the nine taps plane by plane: 0 2 6 8 | 1 7 | 3 5 | 4 -- conv3x3s2_sp_patch_kernel's order)
                 if (++ti3 == 9) { ti3 = 0; ++cc; }
                 const int tp = (int)((0x453718620ull >> (4 * ti3)) & 15);
@@ -742,14 +739,7 @@ static bool try_pp_patch(const ConvArgs& a, hipStream_t s) {
     if ((long)a.M * a.x_cs >= (1l << 31)) return false;                       // 32-bit element offsets inside the kernel
     const int c = a.Cout;
     const bool deep = ppp_mode() & 8;
-    if (a.x2 && a.k_order == 5) {                   // a second source whose chunks come last: the software-pipelined form has a phase for them
-        if constexpr (sizeof(T) == 2) {
-            if ((shape == 2 && a.M / 512 >= pp_min) || (shape >= 3 && (long)(a.M / 256) * (c / 256) >= pp_min))
-                if (conv_try_sp_patch(a, shape, s)) return true;
-        }
-        return false;                               // (else the implicit-GEMM kernels, which walk order 5 too)
-    }
-    if (a.x2) {                                     // a second source in round 3's place (conv_x2_supported: shapes 2, 3 and 4)
+    if (a.x2) {                                     // a second source (conv_x2_supported: shapes 2, 3 and 4)
         if (shape == 2 && a.M / 512 >= pp_min) return launch_pp_patch<T, 8, 4, 4, 2, 32, 16, 4, true>(a, s);
         if (shape == 3 && (long)(a.M / 256) * (c / 256) >= pp_min) return launch_pp_patch<T, 8, 4, 2, 4, 16, 8, 4, true>(a, s);
         if (shape == 4 && (long)(a.M / 256) * (c / 256) >= pp_min) return launch_pp_patch<T, 8, 4, 2, 4, 8, 4, 4, true>(a, s);

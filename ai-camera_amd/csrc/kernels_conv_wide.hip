@@ -190,7 +190,7 @@ struct KTab { const uint4* dev; int nsteps; };
 static KTab ktab_for(const ConvArgs& a) {
     static std::mutex mu;
     static std::map<std::array<int, 6>, KTab> cache;
-    const int cin2 = a.x2 ? a.Cin2 : 0;            // (k_order 5 only ever comes with a second source; without one it walks like 1)
+    const int cin2 = a.x2 ? a.Cin2 : 0;
     const std::array<int, 6> key{a.KH, a.W, a.x_cs, a.Cin, a.k_order, cin2};
     std::lock_guard<std::mutex> lk(mu);
     auto it = cache.find(key);
@@ -204,15 +204,10 @@ static KTab ktab_for(const ConvArgs& a) {
         const int tap = a.k_order == 3 ? (int)((0x453718620ull >> (4 * ti)) & 15) : ti;
         const int kh = ntap == 1 ? 0 : tap / 3, kw = tap - 3 * kh;
         uint4 e;
-        const int c2 = a.k_order == 5 ? cc - csteps : cc - 1;
-        if (xs) e = uint4{(unsigned)(c2 * 64), (unsigned)((ntap * a.Cin + c2 * 32) * 2), 1u << 16, 1u};
+        if (xs) e = uint4{(unsigned)((cc - 1) * 64), (unsigned)((ntap * a.Cin + (cc - 1) * 32) * 2), 1u << 16, 1u};
         else e = uint4{(unsigned)(((kh * a.W + kw) * a.x_cs + cc * 32) * 2), (unsigned)((tap * a.Cin + cc * 32) * 2), 1u << tap, 0u};
         t.push_back(e);
         if (a.k_order == 0) { if (++cc == csteps) { cc = 0; ++ti; } }
-        else if (a.k_order == 5) {                                                           // the second source's chunks behind the whole window
-            if (xs) ++cc;
-            else if (++ti == ntap) { ti = 0; if (++cc == csteps && csteps2) xs = true; }
-        }
         else if (!xs && ti == 0 && cc >= 1 && cc <= csteps2 && cc < csteps) xs = true;      // the second source's chunk cc - 1 comes next
         else { xs = false; if (++ti == ntap) { ti = 0; ++cc; } }
     }
@@ -230,8 +225,8 @@ static bool conv_wide_ok(const ConvArgs& a, long blocks, bool tail) {
     static const int max_blocks = [] { const char* e = getenv("AICAM_WIDE_BLOCKS"); return e ? atoi(e) : 256; }();
     if (blocks > max_blocks) return false;
     if (a.xs || a.n_dev || a.bias_init || (a.w_tail != nullptr) != tail) return false;
-    if (a.k_order != 0 && a.k_order != 1 && a.k_order != 3 && a.k_order != 5) return false;
-    if (a.x2 && ((a.k_order != 1 && a.k_order != 5) || tail || a.Cin2 <= 0 || a.Cin2 % 32 || a.Cin2 / 32 >= a.Cin / 32)) return false;
+    if (a.k_order != 0 && a.k_order != 1 && a.k_order != 3) return false;
+    if (a.x2 && (a.k_order != 1 || tail || a.Cin2 <= 0 || a.Cin2 % 32 || a.Cin2 / 32 >= a.Cin / 32)) return false;
     if (a.KH != a.KW || (a.KH != 1 && a.KH != 3) || a.pad != a.KH / 2 || a.Cin % 32 || a.Kp != a.KH * a.KW * a.Cin + (a.x2 ? a.Cin2 : 0)) return false;
     if (a.KH == 3 && a.tap_rows != 0x49u) return false;
     if ((long)(2 * a.W + 2) * a.x_cs * 2 + a.Cin * 2 >= (1l << 31) || (long)a.Kp * 2 >= (1l << 31)) return false;      // the table's 32-bit byte offsets
