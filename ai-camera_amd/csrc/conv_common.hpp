@@ -684,6 +684,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
     else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
     else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else if constexpr (N == 11) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
     else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     else if constexpr (N == 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
     else if constexpr (N == 15) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");

@@ -15,10 +15,9 @@ namespace aic {
 //  * input rows arrive by LDS-DMA in aligned groups of four rows, three steps ahead of their first use, into a ring of
 //    five groups; the mid ring holds four groups (written at step s, read at steps s+1 .. s+3); rows are pixel-major
 //    (34 pixels x 128 bytes, chunks XOR-swizzled by the column); the pad columns of the mid ring are zeroed once;
-//  * ONE barrier per step: everything a step reads was written at least one barrier earlier, everything it writes was
-//    last read at least one barrier earlier (ring arithmetic below).
-// vmcnt, oldest first, at the top of step s -- conv1 waves: group s+1 | group s+2: 3 may stay in flight; conv2 waves:
-// group s+1 | stores s-2 | group s+2 | stores s-1: 7 (3 in the first steps, which have no stores yet).
+//  * two barriers per step, the conv2 waves half a step behind the conv1 waves (round 5; one barrier per step with both in step
+//    before: 1 070 -> 1 125 TFLOP/s on the block alone); everything a half-step reads was written at least one barrier earlier,
+//    everything it writes was last read at least one barrier earlier (ring arithmetic and vmcnt accounting at the loop).
 struct BlockArgs {
     const void* x; void* y;                 // block input (also the residual) and output, NHWC fp16, W == 32
     const void* w1; const float* b1;        // [64][576] fp16 each, K = (kh, kw, cin)
@@ -119,14 +118,16 @@ __global__ __launch_bounds__(512) void conv3x3_c64_block_kernel(const BlockArgs 
     auto xwait = [&xf](auto n, auto ir) {
         asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(xf[decltype(ir)::value]) : "n"(decltype(n)::value));
     };
-    auto kloop = [&]() {                        // 6 (tap column, channel half) groups x 6 row fragments: see conv3x3_c64_resident_kernel
+    auto kfirst = [&]() {                       // the first group's six row fragments requested, the accumulators start from the bias
         static_for<6>([&](auto ir) { xread(std::integral_constant<int, 0>{}, ir); });
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) acc[i][j] = *reinterpret_cast<const floatx4*>(bias_l + 4 * j);
-        static_for<6>([&](auto gi) {
-            constexpr int g = decltype(gi)::value, kw = g >> 1, cc = g & 1;
+    };
+    auto kpart = [&](auto part) {               // (tap column, channel half) groups 3 part .. 3 part + 2, six row fragments each: 72 MFMAs; see conv3x3_c64_resident_kernel
+        static_for<3>([&](auto gi) {
+            constexpr int g = 3 * decltype(part)::value + decltype(gi)::value, kw = g >> 1, cc = g & 1;
             static_for<6>([&](auto ir_c) {
                 constexpr int ir = decltype(ir_c)::value;
                 xwait(std::integral_constant<int, (g == 5 ? 5 - ir : 5)>{}, ir_c);
@@ -143,76 +144,123 @@ __global__ __launch_bounds__(512) void conv3x3_c64_block_kernel(const BlockArgs 
             });
         });
     };
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+
+    // ---- the pieces of a step
+    auto rows1 = [&](int s) {                                           // conv1: ring rows of input stream rows 4s - 1 .. 4s + 4
+#pragma unroll
+        for (int ir = 0; ir < 6; ++ir) {
+            const int v = 4 * s - 1 + ir;                               // stream row; group v >> 2 (arithmetic: -1 -> group -1), ring slot mod 5
+            int gsl = (v >> 2) % 5; if (gsl < 0) gsl += 5;
+            rowb[ir] = (gsl * 4 + (v & 3)) * ROWB;
+        }
+    };
+    auto store_mid = [&](int s) {                                       // conv1: bias + ReLU, fp16, into the mid ring
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = act_fast<2>(acc[i][e >> 2][e & 3]);
+            const half8 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3], (half_t)v[4], (half_t)v[5], (half_t)v[6], (half_t)v[7]};
+            const int ad = MID_OFF + ((4 * s + i) & 15) * ROWB + mid_w;
+            asm volatile("ds_write_b128 %0, %1" :: "v"(ad), "v"(o) : "memory");
+        }
+    };
+    auto zero_mid = [&](int s) {                                        // separator rows of the mid stream: zeros
+        const half8 o = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ad = MID_OFF + ((4 * s + i) & 15) * ROWB + mid_w;
+            asm volatile("ds_write_b128 %0, %1" :: "v"(ad), "v"(o) : "memory");
+        }
+    };
+    auto load_res = [&](size_t pix0) {                                  // conv2: the block input of its four output rows (the residual)
+        const char* rb = reinterpret_cast<const char*>(xg) + pix0 * a.x_cs * 2;
+        unsigned rl = rl0;
+        asm volatile("" : "+v"(rl));            // form the four row offsets here, not as loop-invariant VGPRs
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(rv[i]) : "v"(rl + i * rstep), "s"(rb) : "memory");
+    };
+    auto rows2 = [&](int tt) {
+#pragma unroll
+        for (int ir = 0; ir < 6; ++ir) rowb[ir] = MID_OFF + ((4 * tt - 1 + ir) & 15) * ROWB;
+    };
+    auto store_out = [&](size_t pix0) {                                 // conv2: + input, ReLU, fp16, out
+        asm volatile("s_waitcnt vmcnt(3)" : "+v"(rv[0]), "+v"(rv[1]), "+v"(rv[2]), "+v"(rv[3]) :: "memory");   // residual landed; this step's row group may stay in flight
+        char* yb = reinterpret_cast<char*>(yg) + pix0 * a.y_cs * 2;
+        unsigned yl = yl0;
+        asm volatile("" : "+v"(yl));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = act_fast<2>(acc[i][e >> 2][e & 3] + (float)rv[i][e]);
+            const half8 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3], (half_t)v[4], (half_t)v[5], (half_t)v[6], (half_t)v[7]};
+            *reinterpret_cast<half8*>(yb + (size_t)(yl + i * ystep)) = o;
+        }
+    };
 
     issue(-1); issue(0); issue(1); issue(2);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // bias and the zeroed mid ring are in LDS before the first barrier
-    for (int s = 0; s < S_tot + 2; ++s) {
-        if (s < 4) wait_vmcnt<3>();
-        else if (grp == 0) wait_vmcnt<3>();
-        else wait_vmcnt<7>();
-        __builtin_amdgcn_s_barrier();
-        if (grp == 0) {
+    // Two barriers per step, the conv2 waves HALF A STEP behind the conv1 waves (they pass one extra barrier first, the conv1 waves
+    // one extra at the end).  A SIMD holds one wave of each conv: in step with each other both reach their epilogue, the barrier,
+    // the LDS-DMA issue and the first six fragment reads together and the matrix pipe idles; half a step apart those sit under the
+    // partner's 72-MFMA half (the weights-resident kernel's schedule, kernels_conv_direct.hip).  Barrier 2s: conv1 starts step s;
+    // barrier 2s + 1: conv2 starts its step s (mid rows of step s - 2).  Ring hazards: the mid rows conv1 writes at the end of
+    // half-step 2s + 1 replace rows conv2 last read in its step s - 1 (half-steps 2s - 1, 2s), and are first read in conv2's step
+    // s + 1 (from 2s + 3); an input row group issued in step s (by conv1 behind barrier 2s, by conv2 behind 2s + 1) replaces the group
+    // conv1 last read in step s - 1 and must have landed before barrier 2s + 4 -- conv2's mid-step barrier of its step s + 1.
+    // vmcnt, oldest first, at that wait of conv2's step s: group s + 2 | stores of step s - 1 | residual of step s | group s + 3 --
+    // 3, 7 or 11 may stay in flight according to which of the two steps are live ones (a count that assumed absent operations would not wait).
+    if (grp == 0) {
+        for (int s = 0; s < S_tot + 2; ++s) {
+            wait_vmcnt<3>();                                            // group s + 1 | group s + 2
+            __builtin_amdgcn_s_barrier();
             issue(s + 3);
-            if (s < S_tot) {
-                const int gy = s % gpi;
-                if (gy < gpi - 1) {
-#pragma unroll
-                    for (int ir = 0; ir < 6; ++ir) {
-                        const int v = 4 * s - 1 + ir;                   // stream row; group v >> 2 (arithmetic: -1 -> group -1), ring slot mod 5
-                        int gsl = (v >> 2) % 5; if (gsl < 0) gsl += 5;
-                        rowb[ir] = (gsl * 4 + (v & 3)) * ROWB;
-                    }
-                    kloop();
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        float v[8];
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = act_fast<2>(acc[i][e >> 2][e & 3]);
-                        const half8 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3], (half_t)v[4], (half_t)v[5], (half_t)v[6], (half_t)v[7]};
-                        const int ad = MID_OFF + ((4 * s + i) & 15) * ROWB + mid_w;
-                        asm volatile("ds_write_b128 %0, %1" :: "v"(ad), "v"(o) : "memory");
-                    }
-                } else {                                                // separator rows of the mid stream: zeros
-                    const half8 o = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int ad = MID_OFF + ((4 * s + i) & 15) * ROWB + mid_w;
-                        asm volatile("ds_write_b128 %0, %1" :: "v"(ad), "v"(o) : "memory");
-                    }
-                }
+            const bool live = s < S_tot, act1 = live && s % gpi < gpi - 1;
+            if (act1) {
+                rows1(s);
+                kfirst();
+                kpart(P0{});
+            }
+            __builtin_amdgcn_s_barrier();
+            if (live) {
+                if (act1) {
+                    kpart(P1{});
+                    store_mid(s);
+                } else zero_mid(s);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the rows are in LDS before the next barrier
             }
-        } else {
+        }
+        __builtin_amdgcn_s_barrier();
+    } else {
+        wait_vmcnt<3>();
+        __builtin_amdgcn_s_barrier();
+        bool prev = false;
+        for (int s = 0; s < S_tot + 2; ++s) {
+            __builtin_amdgcn_s_barrier();
             const int tt = s - 2;
             const bool act2 = tt >= 0 && tt < S_tot && (tt % gpi) < gpi - 1;
             const int jl = act2 ? tt / gpi : 0, gy = act2 ? tt % gpi : 0;
             const size_t pix0 = ((size_t)(img0 + jl) * a.H + gy * 4) * 32;
-            if (act2) {
-                const char* rb = reinterpret_cast<const char*>(xg) + pix0 * a.x_cs * 2;
-                unsigned rl = rl0;
-                asm volatile("" : "+v"(rl));            // form the four row offsets here, not as loop-invariant VGPRs
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(rv[i]) : "v"(rl + i * rstep), "s"(rb) : "memory");
-            }
+            if (act2) load_res(pix0);
             issue(s + 3);
             if (act2) {
-#pragma unroll
-                for (int ir = 0; ir < 6; ++ir) rowb[ir] = MID_OFF + ((4 * tt - 1 + ir) & 15) * ROWB;
-                kloop();
-                asm volatile("s_waitcnt vmcnt(3)" : "+v"(rv[0]), "+v"(rv[1]), "+v"(rv[2]), "+v"(rv[3]) :: "memory");   // residual landed; this step's row group may stay in flight
-                char* yb = reinterpret_cast<char*>(yg) + pix0 * a.y_cs * 2;
-                unsigned yl = yl0;
-                asm volatile("" : "+v"(yl));
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float v[8];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = act_fast<2>(acc[i][e >> 2][e & 3] + (float)rv[i][e]);
-                    const half8 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3], (half_t)v[4], (half_t)v[5], (half_t)v[6], (half_t)v[7]};
-                    *reinterpret_cast<half8*>(yb + (size_t)(yl + i * ystep)) = o;
-                }
+                rows2(tt);
+                kfirst();
+                kpart(P0{});
             }
+            if (act2 && prev) wait_vmcnt<11>();
+            else if (act2 || prev) wait_vmcnt<7>();
+            else wait_vmcnt<3>();
+            __builtin_amdgcn_s_barrier();
+            if (act2) {
+                kpart(P1{});
+                store_out(pix0);
+            }
+            prev = act2;
         }
     }
     wait_vmcnt<0>();
@@ -239,9 +287,20 @@ bool conv_try_c64_block(const ConvArgs& c1, const ConvArgs& c2, hipStream_t s) {
     // Default 16 images per block (960 blocks for a 15 360-crop group): same box, interleaved, round 3: 9 490 / 9 482 frames/s with one
     // persistent block per CU (0), 9 553 / 9 624 with 16 -- the NMS blocks of the side stream hold whole CUs for ~2 ms at the start of
     // the ReID trunk, and a persistent block that starts late finishes late; shorter-lived blocks just flow around them.
-    static const int ipb_env = [] { const char* e = getenv("AICAM_BLK_IPB"); return e ? atoi(e) : 16; }();
-    const int grid = std::min(conv_cu_budget(), a.n_img);
-    a.ipb = ipb_env > 0 ? ipb_env : (a.n_img + grid - 1) / grid;
+    // Round 5: 960 blocks are 3.75 rounds of 256 CUs -- the last round runs three quarters full.  12 .. 16 images per block, whichever
+    // wastes least of the last round (15 360 crops: 12 -> 1 280 blocks = 5 rounds; the layer alone 2 065 -> 2 000 us per conv, same box).
+    static const int ipb_env = [] { const char* e = getenv("AICAM_BLK_IPB"); return e ? atoi(e) : -1; }();
+    const int cus = conv_cu_budget();
+    if (ipb_env > 0) a.ipb = ipb_env;
+    else if (ipb_env == 0) a.ipb = (a.n_img + std::min(cus, a.n_img) - 1) / std::min(cus, a.n_img);
+    else {
+        long best = -1;
+        for (int ipb = 12; ipb <= 16; ++ipb) {
+            const long blocks = (a.n_img + ipb - 1) / ipb, rounds = (blocks + cus - 1) / cus;
+            const long waste = (rounds * cus - blocks) * 1000 / (rounds * cus);           // idle share of the CUs' block slots, per mille
+            if (best < 0 || waste < best) best = waste, a.ipb = ipb;
+        }
+    }
     constexpr size_t lds = (size_t)(20 + 16) * 34 * 128 + 1024 + 512;
     static bool attr = false;
     if (!attr) {
