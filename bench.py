@@ -62,6 +62,8 @@ def parse(argv=None):
     p.add_argument("--height", type=int, default=720)
     p.add_argument("--model", type=str, default="n", choices=("n", "m"))
     p.add_argument("--dtype", type=str, default="fp16", choices=("fp16", "fp32"))
+    p.add_argument("--detector", type=str, default="trained", choices=("seeded", "trained"),
+                   help="the headline's detector weights: the seeded engine, or weights/yolov8n_synth.onnx (YOLOv8n trained on the synthetic workload)")
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--no-prof", action="store_true", help="do not record HIP events in the timed region")
     p.add_argument("--cpu-frames", type=int, default=-1, help="frames of the all-cores CPU baseline leg (-1: 200, 0: skip)")
@@ -365,7 +367,8 @@ def main():
     sc = syn.Scene(seed=D.stream_seed(args.seed, rank), n_targets=args.persons, width=args.width, height=args.height)
     order = list(range(R)) + list(range(R - 1, -1, -1))          # forward then backward: continuous motion
     max_persons = max(32, ((args.persons + 7) // 8) * 8)
-    pipe = TP(ypath, rpath, (args.height, args.width), batch=args.batch, ring_frames=2 * R, max_persons=max_persons,
+    ypath_headline = ypath_trained if (args.detector == "trained" and ypath_trained) else ypath
+    pipe = TP(ypath_headline, rpath, (args.height, args.width), batch=args.batch, ring_frames=2 * R, max_persons=max_persons,
               device=dev, dtype=args.dtype, inject=True)
     frames_per_step = 2 * R
     # the clip in page-locked host memory: what cap.read() hands the reference loop (src/aicamera_tracker.py:170)
@@ -597,7 +600,7 @@ def main():
         cpu = None
         if world == 1 and args.cpu_frames != 0:
             try:
-                cpu = cpu_baseline(args, ypath, rpath)
+                cpu = cpu_baseline(args, ypath_headline, rpath)
             except Exception as e:   # the baseline must never hide the GPU number
                 cpu = {"value": None, "unit": "frames/s", "cores": host_cores(), "kind": "port", "sample": f"failed: {e}"}
         span = ("frames resident in HBM -> track tuples on host" if args.resident else
@@ -609,7 +612,8 @@ def main():
             "ms_per_step": round(1e3 * dt_max / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f16" if args.dtype == "fp16" else "f32", "data": "synthetic",
             "config": {"workload": f"{args.width}x{args.height}, {args.persons} planted persons/frame, YOLOv8{args.model}+ReID(512-d)+DeepSORT, "
-                                   f"1 stream per GPU, seeded weights, inject=planted",
+                                   f"1 stream per GPU, detector weights: {'trained on the synthetic workload (weights/yolov8n_synth.onnx through onnx_import)' if ypath_headline != ypath else 'seeded'}"
+                                   f", ReID weights seeded, inject=planted",
                        "frames_per_step": frames_per_step, "launch_group_frames": args.batch,
                        "confirmed_tracks_per_frame": round(n_tracks_total / (frames_per_step * args.steps), 2),
                        "timed_span": span,
