@@ -406,7 +406,129 @@ Model::Model(Device& d, const void* blob, size_t nbytes, int dtype_, int max_ite
         out_dim = outs[0].v[1];
         AIC_REQUIRE(bufs[outs[0].v[0]].f32, AIC_ERR_FORMAT, "embedding buffer must be fp32");
     }
+    plan_side_heads();
     HIP_CHECK(hipStreamSynchronize(d.s_main));
+}
+
+Model::~Model() {
+    for (int i = 0; i < 2; ++i) {
+        if (side_fork[i]) (void)hipEventDestroy(side_fork[i]);
+        if (side_join[i]) (void)hipEventDestroy(side_join[i]);
+        if (side_stream[i] && side_stream[i] != dev->s_det && side_stream[i] != dev->s_reid) (void)hipStreamDestroy(side_stream[i]);
+    }
+}
+
+// Which ops may leave the main stream (engine.hpp, side_heads).  An op's slices: what it reads (source, residual, second source, split
+// source) and the one it writes, as (buffer, first channel, channels); elementwise ops count with their whole buffers.  Level l's set =
+// the live ops from which output l and no other output is reachable through those slices; it has to be ONE run of consecutive live ops,
+// its fork point `cut` = one past the last op outside the set that writes something the set reads, and nothing that can run beside it
+// (any op at or behind `cut` outside the set) may write what the set reads or writes, or read what it writes.  Anything else: no plan.
+void Model::plan_side_heads() {
+    side_heads.clear();
+    static const int opt = [] { const char* e = getenv("AICAM_SIDE_HEADS"); return e ? atoi(e) : 2; }();
+    side_max_items = opt;
+    if (kind != KIND_YOLO || opt <= 0 || outs.size() < 2 || (lead_ops > 0 && sub_items > 0)) return;
+    struct Slice { int buf, c0, cn; };
+    const size_t no = ops.size();
+    std::vector<std::vector<Slice>> rd(no);
+    std::vector<Slice> wr(no);
+    auto whole = [&](int b) { return Slice{b, 0, 1 << 30}; };
+    for (size_t i = 0; i < no; ++i) {
+        const OpDesc& o = ops[i];
+        const int* v = o.v;
+        if (o.fuse == 2) continue;
+        if (o.fuse == 1) return;                          // (a fused stem + pool: not a detector)
+        if (v[0] == OP_CONV) {
+            rd[i].push_back(Slice{v[1], v[2], v[3] == 3 ? 8 : v[3]});
+            if (v[14]) rd[i].push_back(Slice{v[12], v[13], v[6]});
+            if (v[16]) rd[i].push_back(Slice{v[16] - 1, v[17], v[18]});
+            if (o.xs_buf >= 0) rd[i].push_back(Slice{o.xs_buf, o.xs_coff, o.xs_c});
+            wr[i] = Slice{v[4], v[5], v[6]};
+        } else {
+            rd[i].push_back(whole(v[1]));
+            wr[i] = whole(v[4]);
+        }
+    }
+    auto hit = [](const Slice& a, const Slice& b) { return a.buf == b.buf && a.c0 < b.c0 + b.cn && b.c0 < a.c0 + a.cn; };
+    auto live = [&](size_t i) { return ops[i].fuse != 2; };
+    // levels reachable from each op (backwards over the list: a later reader of what an op writes)
+    std::vector<unsigned> reach(no, 0u);
+    for (size_t ii = no; ii-- > 0;) {
+        if (!live(ii)) continue;
+        for (size_t l = 0; l < outs.size(); ++l)
+            if (wr[ii].buf == outs[l].v[0] || wr[ii].buf == outs[l].v[1]) reach[ii] |= 1u << l;
+        for (size_t j = ii + 1; j < no; ++j) {
+            if (!live(j)) continue;
+            for (const Slice& r : rd[j])
+                if (hit(r, wr[ii])) reach[ii] |= reach[j];
+        }
+    }
+    for (size_t l = 0; l + 1 < outs.size() && side_heads.size() < 2; ++l) {
+        size_t a = no, b = 0;
+        for (size_t i = 0; i < no; ++i)
+            if (live(i) && reach[i] == (1u << l)) { a = std::min(a, i); b = std::max(b, i + 1); }
+        if (a >= b) continue;
+        bool ok = true;
+        for (size_t i = a; i < b; ++i)
+            if (live(i) && reach[i] != (1u << l)) ok = false;             // one run of consecutive live ops
+        size_t cut = 0;
+        for (size_t i = a; i < b && ok; ++i) {
+            if (!live(i)) continue;
+            for (size_t k = 0; k < a; ++k) {
+                if (!live(k)) continue;
+                for (const Slice& r : rd[i])
+                    if (hit(r, wr[k])) cut = std::max(cut, k + 1);
+            }
+        }
+        if (!ok || cut == 0 || cut > a) continue;
+        if (ops[cut - 1].fuse == 3) continue;                             // (never between a lead and the 1x1 it may take as its tail)
+        for (size_t k = cut; k < no && ok; ++k) {                         // whoever may run beside the set
+            if (!live(k) || (k >= a && k < b)) continue;
+            for (size_t i = a; i < b && ok; ++i) {
+                if (!live(i)) continue;
+                if (hit(wr[k], wr[i])) ok = false;
+                for (const Slice& r : rd[i])
+                    if (hit(r, wr[k])) ok = false;
+                for (const Slice& r : rd[k])
+                    if (hit(r, wr[i])) ok = false;
+            }
+        }
+        if (!ok) continue;
+        if (!side_heads.empty() && (cut < side_heads.back().cut || a < side_heads.back().b || cut > side_heads[0].a)) continue;   // forks and sets in list order, every fork in front of every set
+        side_heads.push_back(SideHead{a, b, cut});
+    }
+    if (getenv("AICAM_SIDE_DBG"))
+        for (const SideHead& h : side_heads) fprintf(stderr, "[aicam] side head: ops [%zu, %zu) of %zu fork behind op %zu\n", h.a, h.b, no, h.cut);
+    for (size_t i = 0; i < side_heads.size(); ++i) {
+        side_stream[i] = getenv("AICAM_SIDE_OWN") ? nullptr : (i == 0 ? dev->s_det : dev->s_reid);
+        if (!side_stream[i]) HIP_CHECK(hipStreamCreateWithFlags(&side_stream[i], hipStreamNonBlocking));
+        HIP_CHECK(hipEventCreateWithFlags(&side_fork[i], hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&side_join[i], hipEventDisableTiming));
+    }
+}
+
+void Model::run_ops(size_t op0, int n, hipStream_t s) {
+    const bool prof_conv = (dev->prof_mask >> PROF_CONV) & 1u;            // the HIP-event brackets describe one stream: measured runs stay on it
+    if (!side_ok || side_heads.empty() || n > side_max_items || prof_conv || n_items_dev || op0 > side_heads[0].cut || s != dev->s_main) {
+        run_range(op0, ops.size(), 0, n, s);
+        return;
+    }
+    size_t at = op0;
+    for (size_t i = 0; i < side_heads.size(); ++i) {                      // main stream up to each fork, the level's ops behind it on their stream
+        const SideHead& h = side_heads[i];
+        run_range(at, h.cut, 0, n, s);
+        at = h.cut;
+        HIP_CHECK(hipEventRecord(side_fork[i], s));
+        HIP_CHECK(hipStreamWaitEvent(side_stream[i], side_fork[i], 0));
+        run_range(h.a, h.b, 0, n, side_stream[i]);
+        HIP_CHECK(hipEventRecord(side_join[i], side_stream[i]));
+    }
+    for (size_t i = 0; i <= side_heads.size(); ++i) {                     // the rest of the list, around the sets
+        const size_t e = i < side_heads.size() ? side_heads[i].a : ops.size();
+        if (at < e) run_range(at, e, 0, n, s);
+        if (i < side_heads.size()) at = std::max(at, side_heads[i].b);
+    }
+    for (size_t i = 0; i < side_heads.size(); ++i) HIP_CHECK(hipStreamWaitEvent(s, side_join[i], 0));
 }
 
 bool Model::input_pix4_ok() const {
@@ -426,7 +548,7 @@ void Model::run(int n, hipStream_t s) {
         for (int i0 = 0; i0 < n; i0 += sub_items) run_range(0, lead_ops, i0, std::min(sub_items, n - i0), s);
         run_range(lead_ops, ops.size(), 0, n, s);
     } else {
-        run_range(0, ops.size(), 0, n, s);
+        run_ops(0, n, s);
     }
 }
 
@@ -449,7 +571,7 @@ void Model::run_frames(const uint8_t* frames, int n, const LetterboxGeom& g, hip
         }
         if (ok) {
             cls_reduced = box_decoded = 0;
-            run_range(1, ops.size(), 0, n, s);
+            run_ops(1, n, s);
             return;
         }
     }
@@ -780,7 +902,9 @@ int aic_yolo_infer(aic_model* mm, const float* images, int batch, int mem, float
         hipStream_t s = m.dev->s_main;
         load_input_nchw(m, images, batch, mem, s);
         m.reduce_cls = true;                    // (only the decoded outputs leave this call)
+        m.side_ok = true;
         m.run(batch, s);
+        m.side_ok = false;
         m.decode_nms(batch, conf, iou, max_det, nullptr, s);
         copy_out(num_dets, m.d_numdets.p, (size_t)batch * 4, mem, s);
         copy_out(bboxes, m.d_out_boxes.p, (size_t)batch * max_det * 16, mem, s);
@@ -799,7 +923,9 @@ int aic_yolo_head(aic_model* mm, const float* images, int batch, int mem, float*
         hipStream_t s = m.dev->s_main;
         load_input_nchw(m, images, batch, mem, s);
         m.reduce_cls = false;                   // the raw class logits are what this call returns
+        m.side_ok = true;
         m.run(batch, s);
+        m.side_ok = false;
         const int nc = m.meta[0], nb = 4 * m.meta[1];
         int a0 = 0;
         for (auto& o : m.outs) {
@@ -827,7 +953,9 @@ int aic_yolo_decode(aic_model* mm, const float* images, int batch, int mem, floa
         hipStream_t s = m.dev->s_main;
         load_input_nchw(m, images, batch, mem, s);
         m.reduce_cls = true;
+        m.side_ok = true;
         m.run(batch, s);
+        m.side_ok = false;
         const DetArgs a = m.det_args(batch, 0.5f, 0.5f, 1, nullptr);
         launch_decode(a, s);
         const size_t ba = (size_t)batch * m.n_anchors;
@@ -937,7 +1065,9 @@ int aic_detect(aic_model* mm, const uint8_t* frames, int batch, int h, int w, in
         const uint8_t* df = stage_frames(m, frames, (size_t)batch * h * w * 3, mem, s, batch == 1);
         const LetterboxGeom g = letterbox_geometry(h, w, m.in_h, m.in_w);
         m.reduce_cls = true;
+        m.side_ok = true;
         m.run_frames(df, batch, g, s);
+        m.side_ok = false;
         static const bool direct = getenv("AICAM_NO_DET_HOST_OUT") == nullptr;
         if (direct && batch <= 4 && num_dets && boxes && scores && labels) {
             // the per-frame plugin loop: the NMS kernel stores what it keeps into page-locked host memory itself

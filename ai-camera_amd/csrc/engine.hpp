@@ -80,6 +80,19 @@ struct Model {
     // u8 BGR frames -> letterbox -> the whole graph; fp16 YOLO engines fuse the letterbox into the stem conv
     void run_frames(const uint8_t* frames, int n, const LetterboxGeom& g, hipStream_t s);
     void run_range(size_t op0, size_t op1, int i0, int n, hipStream_t s);
+    // Launches of a FEW frames (the per-frame plugin loop: one 640 x 640 image is 6 - 150 workgroups per layer on 256 CUs, ~10 us per dependent
+    // launch): the detect branches of every level but the last leave the main stream -- level l's ops (those from which only output l is
+    // reachable) run on a side stream from the moment their feature map exists, beside the rest of the neck, and the main stream joins them
+    // before decode.  Planned at load time from the op table's read / write slices (plan_side_heads); same kernels, same arguments, same bits.
+    struct SideHead { size_t a, b, cut; };      // ops [a, b) on the side stream, forked once the main stream has issued every op below `cut`
+    std::vector<SideHead> side_heads;
+    hipStream_t side_stream[2] = {nullptr, nullptr};
+    hipEvent_t side_fork[2] = {nullptr, nullptr}, side_join[2] = {nullptr, nullptr};
+    bool side_ok = false;                       // set around run() by the per-call entry points (aic_detect, aic_yolo_*): the pipeline keeps its streams to itself
+    int side_max_items = 2;                     // aic_model_option-free: AICAM_SIDE_HEADS=0 turns the schedule off, =N moves the item bound
+    void plan_side_heads();
+    void run_ops(size_t op0, int n, hipStream_t s);     // ops [op0, end) of the whole batch: the side-head schedule where it applies, else run_range
+    ~Model();
     size_t lead_ops = 0;   // leading ops whose activations are large: run in sub-batches (Infinity-Cache residency)
     int sub_items = 0;
     // YOLO post-processing on the buffers left by run()

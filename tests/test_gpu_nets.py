@@ -309,6 +309,48 @@ sys.exit(0 if d < 3e-3 and np.allclose(np.linalg.norm(e_big, axis=1), 1, atol=1e
     assert r.returncode == 0
 
 
+@pytest.mark.parametrize("scale", ["n", "m"])
+def test_detect_heads_on_side_streams_bit_exact(gpu, engines, tmp_path, scale):
+    """Launches of one or two frames (the per-frame plugin loop): the detect branches of every level but the last run on side streams from
+    the moment their feature map exists, beside the rest of the neck (Model::plan_side_heads / run_ops, csrc/engine.cpp).  Same kernels,
+    same arguments: decoded boxes, max logits, labels and the NMS output of twelve different images, one and two per call, must be
+    IDENTICAL to the one-stream order (a child process with AICAM_SIDE_HEADS=0: read once per process), and the plan must exist --
+    two side heads for a three-level YOLOv8 (printed under AICAM_SIDE_DBG)."""
+    import subprocess
+    import sys
+    ef = pkg("engine_file")
+    epath = engines[0] if scale == "n" else ef.ensure_seeded_engines(ROOT, scale="m")[0]
+    code = r"""
+import importlib, sys, numpy as np
+sys.path.insert(0, %r)
+he = importlib.import_module("ai-camera_amd.hip_engine")
+rng = np.random.default_rng(11)
+out = {}
+eng = he.HipEngine(%r, dtype="fp16", max_items=2, warm_up=False)
+for it in range(12):
+    n = 1 + it %% 2
+    x = rng.random((n, 3, 640, 640), dtype=np.float32)
+    b, ml, lab = eng.yolo_decode_np(x)
+    nd, ob, sc, ol = eng.yolo_infer_np(x, conf=0.25, iou=0.45, max_det=300)
+    out.update({f"b{it}": b, f"ml{it}": ml, f"lab{it}": lab, f"nd{it}": nd, f"ob{it}": ob, f"sc{it}": sc, f"ol{it}": ol})
+eng.close()
+np.savez(sys.argv[1], **out)
+""" % (ROOT, epath)
+    files = []
+    for name, env in (("side", {"AICAM_SIDE_DBG": "1"}), ("one_stream", {"AICAM_SIDE_HEADS": "0", "AICAM_SIDE_DBG": "1"})):
+        f = str(tmp_path / (name + ".npz"))
+        r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        print(r.stdout[-300:], r.stderr[-600:])
+        assert r.returncode == 0
+        assert r.stderr.count("side head:") == (2 if name == "side" else 0), r.stderr[-600:]
+        files.append(np.load(f))
+    a, b = files
+    assert sorted(a.files) == sorted(b.files)
+    for k in a.files:
+        assert np.array_equal(a[k], b[k]), k
+    assert int(sum(a[f"nd{it}"].sum() for it in range(12))) > 0
+
+
 @pytest.mark.parametrize("scale", ["n", "x"])
 def test_detect_branch_tails_decode_in_place_bit_exact(gpu, engines, tmp_path, scale):
     """fp16 engines, calls that go on to decode: the class branch's 1x1 tail stores max logit + first arg-max per anchor and the box
