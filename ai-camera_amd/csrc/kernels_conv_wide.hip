@@ -141,6 +141,16 @@ __global__ __launch_bounds__(256) void conv_wide_kernel(const ConvArgs a, const 
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+    if (a.bias_init) {                         // bias first (ConvArgs::bias_init, k_order 2: the weights-resident kernels' placement); the epilogue's `bias` is a page of zeros
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            floatx4 b;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) b[e] = a.bias_init[n0 + wn * NT * 16 + perm_ch<NT>(j, q, e)];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) acc[i][j] = b;
+        }
+    }
 
     const int ngroups = (nsteps + G - 1) / G;
 #pragma unroll
@@ -182,7 +192,7 @@ __global__ __launch_bounds__(256) void conv_wide_kernel(const ConvArgs a, const 
     }
 }
 
-// ---- the K walk of a layer shape as a table (v2's walks, kernels_conv.hip: k_order 0 = tap outer / chunk inner, 1 = chunk outer / taps in
+// ---- the K walk of a layer shape as a table (v2's walks, kernels_conv.hip: k_order 0 = tap outer / chunk inner, 2 = tap column / chunk / tap row, 1 = chunk outer / taps in
 // order with the second source's chunk e behind tap (0, 0) of chunk e + 1, 3 = chunk outer / taps plane by plane).  One per distinct
 // (KH, W, x_cs, Cin, k_order, Cin2), built at first use, kept for the life of the process (a few KB each).
 struct KTab { const uint4* dev; int nsteps; };
@@ -201,6 +211,11 @@ static KTab ktab_for(const ConvArgs& a) {
     int ti = 0, cc = 0;
     bool xs = false;
     for (int k = 0; k < nsteps; ++k) {
+        if (a.k_order == 2) {                   // (kw, chunk, kh): the weights-resident kernels' order (3x3 only, conv_wide_ok)
+            const int kw2 = k / (3 * csteps), c2 = (k / 3) % csteps, kh2 = k % 3, tap2 = kh2 * 3 + kw2;
+            t.push_back(uint4{(unsigned)(((kh2 * a.W + kw2) * a.x_cs + c2 * 32) * 2), (unsigned)((tap2 * a.Cin + c2 * 32) * 2), 1u << tap2, 0u});
+            continue;
+        }
         const int tap = a.k_order == 3 ? (int)((0x453718620ull >> (4 * ti)) & 15) : ti;
         const int kh = ntap == 1 ? 0 : tap / 3, kw = tap - 3 * kh;
         uint4 e;
@@ -224,8 +239,9 @@ static KTab ktab_for(const ConvArgs& a) {
 static bool conv_wide_ok(const ConvArgs& a, long blocks, bool tail) {
     static const int max_blocks = [] { const char* e = getenv("AICAM_WIDE_BLOCKS"); return e ? atoi(e) : 256; }();
     if (blocks > max_blocks) return false;
-    if (a.xs || a.n_dev || a.bias_init || (a.w_tail != nullptr) != tail) return false;
-    if (a.k_order != 0 && a.k_order != 1 && a.k_order != 3) return false;
+    if (a.xs || a.n_dev || (a.w_tail != nullptr) != tail) return false;
+    if (a.k_order < 0 || a.k_order > 3) return false;
+    if ((a.k_order == 2) != (a.bias_init != nullptr) || (a.k_order == 2 && (a.KH != 3 || a.x2 || tail))) return false;      // order 2 comes with the bias in front
     if (a.x2 && (a.k_order != 1 || tail || a.Cin2 <= 0 || a.Cin2 % 32 || a.Cin2 / 32 >= a.Cin / 32)) return false;
     if (a.KH != a.KW || (a.KH != 1 && a.KH != 3) || a.pad != a.KH / 2 || a.Cin % 32 || a.Kp != a.KH * a.KW * a.Cin + (a.x2 ? a.Cin2 : 0)) return false;
     if (a.KH == 3 && a.tap_rows != 0x49u) return false;

@@ -277,7 +277,7 @@ def test_reid_embeddings_do_not_depend_on_the_batch(gpu, engines, dtype):
     big = HipEngine(engines[1], dtype=dtype, max_items=832, warm_up=False)
     e_big = big.reid_infer_np(x)
     big.close()
-    for n in (256, 64, 8):
+    for n in (256, 64, 30, 8):           # 30 and 8: the wide-step kernel, layer1 in the weights-resident kernels' K order on 256- and 128-pixel tiles
         eng = HipEngine(engines[1], dtype=dtype, max_items=n, warm_up=False)
         e = eng.reid_infer_np(x[:n])
         eng.close()
