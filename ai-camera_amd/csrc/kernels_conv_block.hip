@@ -290,7 +290,9 @@ bool conv_try_c64_block(const ConvArgs& c1, const ConvArgs& c2, hipStream_t s) {
     // Round 5: 960 blocks are 3.75 rounds of 256 CUs -- the last round runs three quarters full.  12 .. 16 images per block, whichever
     // wastes least of the last round (15 360 crops: 12 -> 1 280 blocks = 5 rounds; the layer alone 2 065 -> 2 000 us per conv, same box).
     static const int ipb_env = [] { const char* e = getenv("AICAM_BLK_IPB"); return e ? atoi(e) : -1; }();
-    const int cus = conv_cu_budget();
+    // (the CUs the blocks are dealt over: the budget leaves ONE out for the tracker's epoch block while it runs, which does not make 1 280
+    //  blocks six rounds -- counted against the whole chip)
+    const int cus = (conv_cu_budget() + 7) / 8 * 8;
     if (ipb_env > 0) a.ipb = ipb_env;
     else if (ipb_env == 0) a.ipb = (a.n_img + std::min(cus, a.n_img) - 1) / std::min(cus, a.n_img);
     else {

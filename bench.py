@@ -492,9 +492,14 @@ def main():
             old_cls = set(cfg.CLASSES_TO_TRACK)
             cfg.CLASSES_TO_TRACK.clear()
             cfg.CLASSES_TO_TRACK.update(cfg.CLASSES)
+            ys = None
             try:
+                # this leg is about SEEDED heads firing on texture: its detector is the seeded engine whatever the headline carries
+                ys = pipe.yolo
+                if ypath_headline != ypath:
+                    ys = importlib.import_module("ai-camera_amd.hip_engine").HipEngine(ypath, device=dev, dtype=args.dtype, max_items=args.batch, warm_up=False)
                 # the tracker floor that lets the headline's load through: `persons` detections per frame on average over the first 64 frames
-                probe = TP(pipe.yolo, pipe.reid, (args.height, args.width), batch=min(args.batch, 64), ring_frames=64, max_persons=64, device=dev,
+                probe = TP(ys, pipe.reid, (args.height, args.width), batch=min(args.batch, 64), ring_frames=64, max_persons=64, device=dev,
                            dtype=args.dtype, inject=False, min_confidence=0.999999, max_tracks=512)
                 probe.upload(0, host_frames[:64])
                 _, pd = probe.run(0, 64, want_dets=True)
@@ -504,7 +509,7 @@ def main():
                 own = {"workload": f"same clip, inject=0: detector boxes -> confidence/class filter -> crop+ReID -> association; all classes tracked, "
                                    f"tracker floor {floor:.4f} (= {args.persons} detections per frame pass on the first 64 frames)"}
                 for name, filt in (("device_filter", 1), ("host_filter", 0)):
-                    p2 = TP(pipe.yolo, pipe.reid, (args.height, args.width), batch=args.batch, ring_frames=2 * R, max_persons=64, device=dev,
+                    p2 = TP(ys, pipe.reid, (args.height, args.width), batch=args.batch, ring_frames=2 * R, max_persons=64, device=dev,
                             dtype=args.dtype, inject=False, min_confidence=floor, max_tracks=512)
                     p2.option("device_filter", filt)
                     p2.run_raw_from_host_passes(host_frames, 1)
@@ -547,6 +552,8 @@ def main():
             finally:
                 cfg.CLASSES_TO_TRACK.clear()
                 cfg.CLASSES_TO_TRACK.update(old_cls)
+                if ys is not None and ys is not pipe.yolo:
+                    ys.close()
         except Exception as e:
             own = {"error": str(e)}
 
