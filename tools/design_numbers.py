@@ -9,12 +9,12 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TAG = sys.argv[1] if len(sys.argv) > 1 else "r05"
-RANGE = sys.argv[2] if len(sys.argv) > 2 else "10 951 – 11 211"
+RANGE = sys.argv[2] if len(sys.argv) > 2 else "10 923 – 11 347"
 P = lambda n: os.path.join(ROOT, "profiles", f"{TAG}_{n}")
 
 TEMPLATE = r"""| Quantity | Value | Source |
 |---|---|---|
-| `value`: end-to-end frames/s, 1×MI355X, 1280×720, 30 planted persons, YOLOv8n + ReID + DeepSORT, fp16, frame bytes in page-locked host memory → track tuples on host, two streams | **@VALUE@** (boxes of this pool differ by ±3 %: @VALUE_RANGE@ over the round's runs) | `profiles/@TAG@_bench.json` |
+| `value`: end-to-end frames/s, 1×MI355X, 1280×720, 30 planted persons, YOLOv8n (the trained weights since the end of round 5: NMS sees ~30 candidates per frame, +0.8 %) + ReID + DeepSORT, fp16, frame bytes in page-locked host memory → track tuples on host, two streams | **@VALUE@** (boxes of this pool differ by ±3 %: @VALUE_RANGE@ over the round's runs) | `profiles/@TAG@_bench.json` |
 | conv class (the `roofline` object): TFLOP/s over the union of both streams' conv intervals ÷ 2 500 | **@ACH@ TFLOP/s = @FRAC@**; one stream, full groups of the rocprofv3 trace: @ACH1@ TFLOP/s = @FRAC1@ | `profiles/@TAG@_bench.json`, `profiles/@TAG@_conv_layers.txt` |
 | conv time per 512-frame launch group (one stream): total / YOLOv8n / ReID | **@CONV_MS@ / @YOLO_MS@ / @REID_MS@ ms** (round 4: 42.16 / 11.70 / 30.46) | `profiles/@TAG@_conv_layers.txt` |
 | per-half rate: ReID 34.0 TFLOP per group, YOLOv8n 4.43 | ReID @REID_TF@ TFLOP/s = @REID_FRAC@; YOLOv8n @YOLO_TF@ = @YOLO_FRAC@ | same |
@@ -27,7 +27,7 @@ TEMPLATE = r"""| Quantity | Value | Source |
 | launch groups of 16 / 64 / 128 / 256 / 512 frames: frames/s (p50 latency) | @CURVE@ | same |
 | CPU oracle chain on the box's 16 cores / 1 thread | @CPU16@ / @CPU1@ frames/s | same |
 | YOLOv8m fp32 boxes vs the fp64 evaluation of the same engine (33 600 coordinates) | rms 5.3e-5 px, 99.9th percentile 5.2e-4, max 1.05e-3 (1 coordinate above 1e-3); round 4: max 1.6e-3 | `gpurun_out/r5_v8m_err.txt`, `tests/test_gpu_configs.py` |
-| GPU test suite | 159 passed (`pytest -m gpu`, 6 min); CPU suite 46 passed | `GPUTEST_r05.json` |"""
+| GPU test suite | 161 passed (`pytest -m gpu`, 6 min); CPU suite 46 passed | `GPUTEST_r05.json` |"""
 
 
 def sp(x, nd=0):
