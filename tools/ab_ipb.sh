@@ -1,3 +1,4 @@
+#!/bin/bash
 B="--no-curve --no-own --no-plugin --cpu-frames 0"
 # images per block of the fused BasicBlock kernel (AICAM_BLK_IPB): headline bench + the layer alone (tools/conv_bench.py, res = 2), two rounds.   gpurun -- bash tools/ab_ipb.sh
 for i in 1 2; do
