@@ -132,6 +132,106 @@ static bool try_c16(const ConvArgs& a, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Direct 3x3 / stride 2 / pad 1 for 32 -> 64 channels, fp16, SiLU, WITH the 1x1 conv behind it in its epilogue (ConvArgs::w_tail):
+// YOLOv8n's `3.conv` + `4.c2f.cv1` at large batch (160 x 160 -> 80 x 80, round 5).  Through the LDS-DMA implicit GEMM the pair took
+// 845 us per 512 frames at 7.8 % MFMA busy -- four times its HBM floor (839 MB in, 419 MB out): a stride-2 im2col K-step gathers 64-byte
+// half lines and every input pixel comes through the L2 2.25 times.  Here a block owns 16 x 16 output pixels of one image:
+//  * the 33 x 33 x 32-channel input patch is read ONCE into LDS, pixel-major (64 bytes per pixel), even and odd columns apart (pitch 18
+//    pixels: the 64 lanes of a store hit every bank once, the 64 lanes of a fragment read -- 16 output pixels x 4 channel chunks of one
+//    tap -- 1 KB of consecutive bytes);
+//  * K in memory order (tap, channel): one v_mfma_f32_16x16x32_f16 per tap and channel tile, nine per accumulator, from zero, in tap
+//    order; bias + SiLU + fp16 rounding and the 1x1 in tail_1x1() (conv_common.hpp) -- the products, their order and the roundings of
+//    conv_igemm_dma_kernel<.., TAIL> and of the wide-step kernel small launches get: bit-identical;
+//  * wave w owns output rows 4w .. 4w + 3 (four 16-pixel tiles) and ALL 64 channels of them (the tail needs that), in two passes of 32
+//    channels: 18 weight fragments (72 VGPRs) at a time, fetched from L2 once per pass; the pixel fragments are read twice.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_c32s2_tail_kernel(const ConvArgs a, int tiles_x, int tiles_y) {
+    constexpr int T = 16, PR = 2 * T + 1, PCP = 18, ROWB = 2 * PCP * 64;          // patch rows / columns per parity (padded) / bytes per patch row
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6), r = lane & 15, q = lane >> 4;
+    int bx = xcd_tile((int)blockIdx.x, (int)gridDim.x, a.xcd_map);
+    const int tx = bx % tiles_x; bx /= tiles_x;
+    const int ty = bx % tiles_y;
+    const int img = bx / tiles_y;
+    const int oy0 = ty * T, ox0 = tx * T;
+    const int iy0 = 2 * oy0 - 1, ix0 = 2 * ox0 - 1;
+    const half_t* xg = reinterpret_cast<const half_t*>(a.x) + (size_t)img * a.H * a.W * a.x_cs + a.x_coff;
+
+    // patch -> LDS: a wave instruction = 16 consecutive pixels of one row x 4 chunks = 1 KB of consecutive input bytes
+    for (int idx = t; idx < PR * 36 * 4; idx += 256) {                                // (36 = 33 columns rounded up to whole 4-pixel groups)
+        const int c = idx & 3, pp = idx >> 2;
+        const int pr = pp / 36, pc = pp - pr * 36;
+        if (pc >= PR) continue;
+        const int iy = iy0 + pr, ix = ix0 + pc;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
+            v = *reinterpret_cast<const uint4*>(xg + ((size_t)iy * a.W + ix) * a.x_cs + c * 8);
+        *reinterpret_cast<uint4*>(smem + pr * ROWB + ((pc & 1) * PCP + (pc >> 1)) * 64 + c * 16) = v;
+    }
+    // this lane's fragment of tap (kh, kw), output row oyl, pixel r: patch pixel (2 oyl + kh, 2 r + kw), chunk q
+    int toff[9];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int kh = tap / 3, kw = tap - 3 * kh;
+        toff[tap] = kh * ROWB + ((kw & 1) * PCP + (kw >> 1) + r) * 64 + q * 16;
+    }
+    const half_t* wg = reinterpret_cast<const half_t*>(a.w);
+    floatx4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    static_for<2>([&](auto hc) {
+        constexpr int h = decltype(hc)::value;
+        asm volatile("" ::: "memory");                                               // the second pass's weights are fetched HERE, not ahead of the first pass (144 + 64 + 36 registers: one wave per SIMD)
+        __builtin_amdgcn_sched_barrier(0);
+        half8 wf[2][9];                                                              // channel tiles 2h, 2h + 1: rows perm_row<4>(j, r), K = 32 tap + 8 q
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const half_t* wr = wg + (size_t)perm_row<4>(2 * h + jj, r) * a.Kp + 8 * q;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) wf[jj][tap] = *reinterpret_cast<const half8*>(wr + 32 * tap);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const char* base = smem + (2 * (4 * wv + i)) * ROWB;
+            half8 xf[9];
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) xf[tap] = *reinterpret_cast<const half8*>(base + toff[tap]);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+                    acc[i][2 * h + jj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[jj][tap], xf[tap], acc[i][2 * h + jj], 0, 0, 0);
+        }
+    });
+    int mrow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) mrow[i] = (img * a.Ho + oy0 + 4 * wv + i) * a.Wo + ox0 + r;
+    tail_1x1<4, 4>(a, acc, mrow, lane);
+}
+
+static bool try_c32s2_tail(const ConvArgs& a, hipStream_t s) {
+    static const bool off = getenv("AICAM_NO_C32S2") != nullptr;
+    if (off || !a.w_tail || a.KH != 3 || a.KW != 3 || a.stride != 2 || a.pad != 1 || a.Cin != 32 || a.Cout != 64 || a.Kp != 288) return false;
+    if (a.act != 1 || a.res_mode != 0 || a.out_f32 || a.k_order != 0 || a.xs || a.x2 || a.n_dev || a.t_max || a.t_box) return false;
+    if (a.t_cout > 64 || a.t_cout % 8 || a.t_kp != 64 || a.cout_pad < 64) return false;
+    if (a.Ho % 16 || a.Wo % 16 || a.Ho != (a.H + 1) / 2 || a.Wo != (a.W + 1) / 2 || (a.x_cs | a.x_coff | a.t_y_cs | a.t_y_coff) % 8) return false;
+    const int tiles_x = a.Wo / 16, tiles_y = a.Ho / 16, n_img = a.M / (a.Ho * a.Wo);
+    const long blocks = (long)n_img * tiles_x * tiles_y;
+    if (blocks < 512 || (long)a.M * std::max(a.t_y_cs, 1) >= (1l << 31)) return false;     // a few tiles: the wide-step kernel (one block per CU there)
+    constexpr size_t lds = (size_t)33 * 2 * 18 * 64;
+    static bool attr = false;
+    if (!attr) {
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c32s2_tail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = true;
+    }
+    hipLaunchKernelGGL(conv3x3_c32s2_tail_kernel, dim3((unsigned)blocks), dim3(256), lds, s, a, tiles_x, tiles_y);
+    KCHECK();
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Persistent, weights-resident 3x3 / stride 1 / pad 1 for Cin = Cout = 64, fp16 (ReID layer1: 21 % of the FLOPs, tensors
 // of 1 GB per 128-frame launch group, K = 576 only).  A tile's K loop is too short to amortise a block's prologue and
 // epilogue (conv3x3_patch_kernel: 38 % MFMA busy), and every block re-fetches the 72 KB of weights through L2 -> LDS.
@@ -620,6 +720,7 @@ bool conv_try_patch(int dtype, const ConvArgs& a, hipStream_t s) {
     return dtype == AIC_F16 ? try_patch<half_t>(a, s) : false;          // (fp32 engines: the LDS-DMA implicit GEMM only, kernels_conv.hip)
 }
 bool conv_try_c16(const ConvArgs& a, hipStream_t s) { return try_c16(a, s); }
+bool conv_try_c32s2_tail(const ConvArgs& a, hipStream_t s) { return try_c32s2_tail(a, s); }
 bool conv_try_c64_resident(const ConvArgs& a, hipStream_t s) { return try_c64_resident(a, s); }
 
 // ------------------------------------------------------------------------------------------------

@@ -397,6 +397,35 @@ np.savez(sys.argv[1], **out)
     assert a["nd40"].min() > 0 and len(np.unique(a["lab40"])) > 10          # the check is not vacuous
 
 
+def test_stride2_direct_kernel_with_tail_bit_exact(gpu, engines, tmp_path):
+    """YOLOv8n's `3.conv` + `4.c2f.cv1` at large batch: conv3x3_c32s2_tail_kernel (3x3 / 2, 32 -> 64 channels, the input patch read once into
+    LDS, the 1x1 in its epilogue) against the LDS-DMA implicit GEMM with the same tail (AICAM_NO_C32S2=1, a child process: read once per
+    process).  Same products in the same order, same roundings: the raw head of 24 frames (600 tiles: the kernel takes launches of 512 and
+    more) must be IDENTICAL, and it must be a real head."""
+    import subprocess
+    import sys
+    code = r"""
+import importlib, sys, numpy as np
+sys.path.insert(0, %r)
+he = importlib.import_module("ai-camera_amd.hip_engine")
+x = np.random.default_rng(13).uniform(0, 1, (24, 3, 640, 640)).astype(np.float32)
+eng = he.HipEngine(%r, dtype="fp16", max_items=24, warm_up=False)
+dfl, cls = eng.yolo_head_np(x)
+eng.close()
+np.savez(sys.argv[1], dfl=dfl, cls=cls)
+""" % (ROOT, engines[0])
+    files = []
+    for name, env in (("direct", {}), ("igemm", {"AICAM_NO_C32S2": "1"})):
+        f = str(tmp_path / (name + ".npz"))
+        r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        print(r.stdout[-300:], r.stderr[-300:])
+        assert r.returncode == 0
+        files.append(np.load(f))
+    a, b = files
+    assert np.array_equal(a["dfl"], b["dfl"]) and np.array_equal(a["cls"], b["cls"])
+    assert np.isfinite(a["dfl"]).all() and a["cls"].std() > 0.05 and a["dfl"].std() > 0.05
+
+
 @pytest.mark.parametrize("dtype,tol", [("fp32", 5e-4), ("fp16", 6e-2)])
 def test_yolo_large_batch_kernels(gpu, engines, dtype, tol):
     """The detector's big-tile kernels (512 x 80 class-branch tiles, 16-channel direct kernel, patch forms) engage only
