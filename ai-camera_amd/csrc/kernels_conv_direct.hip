@@ -144,28 +144,55 @@ static bool try_c16(const ConvArgs& a, hipStream_t s) {
 //    conv_igemm_dma_kernel<.., TAIL> and of the wide-step kernel small launches get: bit-identical;
 //  * wave w owns output rows 4w .. 4w + 3 (four 16-pixel tiles) and ALL 64 channels of them (the tail needs that), in two passes of 32
 //    channels: 18 weight fragments (72 VGPRs) at a time, fetched from L2 once per pass; the pixel fragments are read twice.
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_c32s2_tail_kernel(const ConvArgs a, int tiles_x, int tiles_y) {
-    constexpr int T = 16, PR = 2 * T + 1, PCP = 18, ROWB = 2 * PCP * 64;          // patch rows / columns per parity (padded) / bytes per patch row
+//  * NW waves per block (2: 8 x 16 outputs, a 17 x 33 patch, four blocks per CU; 4: 16 x 16 outputs, two blocks per CU): what a block
+//    spends its time on is latency -- the patch, the weights of each pass, the tail's weights -- and the CU hides it behind OTHER blocks.
+template <int NW>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_c32s2_tail_kernel(const ConvArgs a, int tiles_x, int tiles_y) {
+    constexpr int TH = 4 * NW, TW = 16, PRH = 2 * TH + 1, PRW = 2 * TW + 1, PCP = 18, ROWB = 2 * PCP * 64;   // patch rows x columns; columns per parity (padded); bytes per patch row
+    constexpr int NTHR = 64 * NW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6), r = lane & 15, q = lane >> 4;
     int bx = xcd_tile((int)blockIdx.x, (int)gridDim.x, a.xcd_map);
     const int tx = bx % tiles_x; bx /= tiles_x;
     const int ty = bx % tiles_y;
     const int img = bx / tiles_y;
-    const int oy0 = ty * T, ox0 = tx * T;
+    const int oy0 = ty * TH, ox0 = tx * TW;
     const int iy0 = 2 * oy0 - 1, ix0 = 2 * ox0 - 1;
     const half_t* xg = reinterpret_cast<const half_t*>(a.x) + (size_t)img * a.H * a.W * a.x_cs + a.x_coff;
+    const half_t* wg = reinterpret_cast<const half_t*>(a.w);
 
-    // patch -> LDS: a wave instruction = 16 consecutive pixels of one row x 4 chunks = 1 KB of consecutive input bytes
-    for (int idx = t; idx < PR * 36 * 4; idx += 256) {                                // (36 = 33 columns rounded up to whole 4-pixel groups)
-        const int c = idx & 3, pp = idx >> 2;
-        const int pr = pp / 36, pc = pp - pr * 36;
-        if (pc >= PR) continue;
-        const int iy = iy0 + pr, ix = ix0 + pc;
-        uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
-            v = *reinterpret_cast<const uint4*>(xg + ((size_t)iy * a.W + ix) * a.x_cs + c * 8);
-        *reinterpret_cast<uint4*>(smem + pr * ROWB + ((pc & 1) * PCP + (pc >> 1)) * 64 + c * 16) = v;
+    // the first pass's weights are requested FIRST: their L2 round trip runs beside the patch's
+    half8 wf[2][9];                                                                  // channel tiles 2h, 2h + 1: rows perm_row<4>(j, r), K = 32 tap + 8 q
+    auto load_w = [&](int h) {
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const half_t* wr = wg + (size_t)perm_row<4>(2 * h + jj, r) * a.Kp + 8 * q;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) wf[jj][tap] = *reinterpret_cast<const half8*>(wr + 32 * tap);
+        }
+    };
+    load_w(0);
+
+    // patch -> LDS: a wave instruction = 16 consecutive pixels of one row x 4 chunks = 1 KB of consecutive input bytes; nine loads in flight
+    // per thread (as a rolled load-store loop a block spent ~20 us in eighteen dependent HBM round trips)
+    constexpr int NSLOT = PRH * PRW * 4, NB = 9, NBATCH = (NSLOT + NB * NTHR - 1) / (NB * NTHR);
+#pragma unroll
+    for (int b = 0; b < NBATCH; ++b) {
+        uint4 v[NB];
+        int dst[NB];
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int idx = t + (b * NB + u) * NTHR;
+            const int pr = idx / (PRW * 4), rem = idx - pr * (PRW * 4), pc = rem >> 2, c = rem & 3;
+            const int iy = iy0 + pr, ix = ix0 + pc;
+            v[u] = make_uint4(0u, 0u, 0u, 0u);
+            if (idx < NSLOT && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
+                v[u] = *reinterpret_cast<const uint4*>(xg + ((size_t)iy * a.W + ix) * a.x_cs + c * 8);
+            dst[u] = idx < NSLOT ? pr * ROWB + ((pc & 1) * PCP + (pc >> 1)) * 64 + c * 16 : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < NB; ++u)
+            if (dst[u] >= 0) *reinterpret_cast<uint4*>(smem + dst[u]) = v[u];
     }
     // this lane's fragment of tap (kh, kw), output row oyl, pixel r: patch pixel (2 oyl + kh, 2 r + kw), chunk q
     int toff[9];
@@ -174,7 +201,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int kh = tap / 3, kw = tap - 3 * kh;
         toff[tap] = kh * ROWB + ((kw & 1) * PCP + (kw >> 1) + r) * 64 + q * 16;
     }
-    const half_t* wg = reinterpret_cast<const half_t*>(a.w);
     floatx4 acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -183,14 +209,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     __syncthreads();
     static_for<2>([&](auto hc) {
         constexpr int h = decltype(hc)::value;
-        asm volatile("" ::: "memory");                                               // the second pass's weights are fetched HERE, not ahead of the first pass (144 + 64 + 36 registers: one wave per SIMD)
-        __builtin_amdgcn_sched_barrier(0);
-        half8 wf[2][9];                                                              // channel tiles 2h, 2h + 1: rows perm_row<4>(j, r), K = 32 tap + 8 q
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-            const half_t* wr = wg + (size_t)perm_row<4>(2 * h + jj, r) * a.Kp + 8 * q;
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) wf[jj][tap] = *reinterpret_cast<const half8*>(wr + 32 * tap);
+        if constexpr (h == 1) {
+            asm volatile("" ::: "memory");                                           // the second pass's weights are fetched HERE, not ahead of the first pass (144 + 64 + 36 registers: one wave per SIMD)
+            __builtin_amdgcn_sched_barrier(0);
+            load_w(1);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -211,23 +233,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     tail_1x1<4, 4>(a, acc, mrow, lane);
 }
 
+template <int NW>
+static void launch_c32s2_tail(const ConvArgs& a, hipStream_t s) {
+    constexpr size_t lds = (size_t)(8 * NW + 1) * 2 * 18 * 64;
+    const int tiles_x = a.Wo / 16, tiles_y = a.Ho / (4 * NW), n_img = a.M / (a.Ho * a.Wo);
+    static bool attr = false;
+    if (!attr) {
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c32s2_tail_kernel<NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = true;
+    }
+    hipLaunchKernelGGL(conv3x3_c32s2_tail_kernel<NW>, dim3((unsigned)(n_img * tiles_x * tiles_y)), dim3(64 * NW), lds, s, a, tiles_x, tiles_y);
+    KCHECK();
+}
+
 static bool try_c32s2_tail(const ConvArgs& a, hipStream_t s) {
+    static const int mode = [] { const char* e = getenv("AICAM_C32S2"); return e ? atoi(e) : 2; }();   // waves per block: 2 (default) or 4; 0: off (AICAM_NO_C32S2=1 as well)
     static const bool off = getenv("AICAM_NO_C32S2") != nullptr;
-    if (off || !a.w_tail || a.KH != 3 || a.KW != 3 || a.stride != 2 || a.pad != 1 || a.Cin != 32 || a.Cout != 64 || a.Kp != 288) return false;
+    if (off || mode <= 0 || !a.w_tail || a.KH != 3 || a.KW != 3 || a.stride != 2 || a.pad != 1 || a.Cin != 32 || a.Cout != 64 || a.Kp != 288) return false;
     if (a.act != 1 || a.res_mode != 0 || a.out_f32 || a.k_order != 0 || a.xs || a.x2 || a.n_dev || a.t_max || a.t_box) return false;
     if (a.t_cout > 64 || a.t_cout % 8 || a.t_kp != 64 || a.cout_pad < 64) return false;
     if (a.Ho % 16 || a.Wo % 16 || a.Ho != (a.H + 1) / 2 || a.Wo != (a.W + 1) / 2 || (a.x_cs | a.x_coff | a.t_y_cs | a.t_y_coff) % 8) return false;
-    const int tiles_x = a.Wo / 16, tiles_y = a.Ho / 16, n_img = a.M / (a.Ho * a.Wo);
-    const long blocks = (long)n_img * tiles_x * tiles_y;
+    const long blocks = (long)(a.M / (a.Ho * a.Wo)) * (a.Wo / 16) * (a.Ho / 16);
     if (blocks < 512 || (long)a.M * std::max(a.t_y_cs, 1) >= (1l << 31)) return false;     // a few tiles: the wide-step kernel (one block per CU there)
-    constexpr size_t lds = (size_t)33 * 2 * 18 * 64;
-    static bool attr = false;
-    if (!attr) {
-        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c32s2_tail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr = true;
-    }
-    hipLaunchKernelGGL(conv3x3_c32s2_tail_kernel, dim3((unsigned)blocks), dim3(256), lds, s, a, tiles_x, tiles_y);
-    KCHECK();
+    if (mode == 4) launch_c32s2_tail<4>(a, s);
+    else launch_c32s2_tail<2>(a, s);
     return true;
 }
 
@@ -512,7 +541,7 @@ template <int CPP> __device__ __forceinline__ int patch_swz(int p) { return CPP 
 // KORD: 0 = K-steps in memory order (kh, kw, cc); 2 = (kw, cc, kh), the accumulation order of the weights-resident 64-channel
 // kernels (ConvArgs::k_order): the same layer then gives the same bits below and above their batch threshold.
 template <typename T, int MT, int NT, int WM, int WN, int TH, int TW, int NSTAGE, int LGCPP, bool TAIL = false, int KORD = 0>
-__global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(const ConvArgs a, int tiles_x, int tiles_y) {
+__global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu((NT == 5 || TAIL) ? 2 : 1))) void conv3x3_patch_kernel(const ConvArgs a, int tiles_x, int tiles_y) {
     constexpr int CH = 16 / (int)sizeof(T);
     constexpr int BKE = 4 * CH;
     constexpr int NTHR = 64 * WM * WN;
@@ -528,7 +557,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(const ConvA
     constexpr int TOTAL = PH * PWP * CPP;
     constexpr int PATCH_BYTES = (TOTAL + NTHR - 1) / NTHR * NTHR * 16;
     constexpr int ROWB = PWP * CPP * 16;                    // bytes per patch row
-    static_assert(BM == TH * TW && TW % 16 == 0 && (TW & (TW - 1)) == 0 && B_PER == 1, "tile geometry");
+    static_assert(BM == TH * TW && TW % 16 == 0 && (TW & (TW - 1)) == 0 && B_PER <= 2, "tile geometry");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ring = smem + PATCH_BYTES;
@@ -560,12 +589,17 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(const ConvA
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + (size_t)(base + 64 * wv) * 16), 16, 0, 0);
     }
 
-    // ---- weight stream: one 16-byte chunk per thread per K-step; rows past Cout read the zero page with stride 0
+    // ---- weight stream: B_PER 16-byte chunks per thread per K-step (rows r0, r0 + RP); rows past Cout read the zero page with stride 0
     const int slot = t & 3, r0 = t >> 2;
     const int kc = slot ^ lds_swz(r0);
-    const bool wrow_ok = r0 < BN;
-    const T* wptr = wrow_ok ? wg + (size_t)(n0 + r0) * a.Kp + kc * CH : zero;
-    const int winc = wrow_ok ? BKE : 0;
+    const T* wptr[B_PER];
+    int winc[B_PER];
+#pragma unroll
+    for (int jb = 0; jb < B_PER; ++jb) {
+        const bool wrow_ok = r0 + RP * jb < BN;
+        wptr[jb] = wrow_ok ? wg + (size_t)(n0 + r0 + RP * jb) * a.Kp + kc * CH : zero;
+        winc[jb] = wrow_ok ? BKE : 0;
+    }
     char* wdst = ring + (16 * wv) * 64;
     // step s of the walk -> (kh, kw, cc) and the K-step's position in the packed weights (memory order is (kh, kw, cc))
     auto step_kh = [](int s) constexpr { return KORD == 2 ? s % 3 : s / (3 * CSTEPS); };
@@ -574,9 +608,13 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(const ConvA
     auto step_mem = [=](int s) constexpr { return (step_kh(s) * 3 + step_kw(s)) * CSTEPS + step_cc(s); };
 #pragma unroll
     for (int st = 0; st < NSTAGE - 1; ++st) {
-        __builtin_amdgcn_global_load_lds((gptr_t)(wptr + step_mem(st) * winc), (lptr_t)(wdst + st * WSTAGE), 16, 0, 0);
+#pragma unroll
+        for (int jb = 0; jb < B_PER; ++jb)
+            __builtin_amdgcn_global_load_lds((gptr_t)(wptr[jb] + step_mem(st) * winc[jb]), (lptr_t)(wdst + st * WSTAGE + jb * (RP * 64)), 16, 0, 0);
     }
-    const T* wnext = wptr + (NSTAGE - 1) * winc;            // memory order (KORD 0): the stream is a pointer increment
+    const T* wnext[B_PER];                                   // memory order (KORD 0): the stream is a pointer increment
+#pragma unroll
+    for (int jb = 0; jb < B_PER; ++jb) wnext[jb] = wptr[jb] + (NSTAGE - 1) * winc[jb];
 
     const int wm = wv / WN, wn = wv % WN;
     const int q = lane >> 4, r = lane & 15;
@@ -621,15 +659,16 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_patch_kernel(const ConvA
         const int cur = step % NSTAGE, nxt = (step + NSTAGE - 1) % NSTAGE;
         wait_vmcnt<(NSTAGE - 2) * B_PER>();
         __builtin_amdgcn_s_barrier();
-        {   // refill the stage that step-1 released (zero page once the real K-steps are exhausted)
+#pragma unroll
+        for (int jb = 0; jb < B_PER; ++jb) {   // refill the stage that step-1 released (zero page once the real K-steps are exhausted)
             const T* src = zero;
             if constexpr (KORD == 0) {
-                if (step + NSTAGE - 1 < NSTEPS) src = wnext;
-                wnext += winc;
+                if (step + NSTAGE - 1 < NSTEPS) src = wnext[jb];
+                wnext[jb] += winc[jb];
             } else {
-                if (step + NSTAGE - 1 < NSTEPS) src = wptr + step_mem(step + NSTAGE - 1 < NSTEPS ? step + NSTAGE - 1 : 0) * winc;
+                if (step + NSTAGE - 1 < NSTEPS) src = wptr[jb] + step_mem(step + NSTAGE - 1 < NSTEPS ? step + NSTAGE - 1 : 0) * winc[jb];
             }
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(wdst + nxt * WSTAGE), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(wdst + nxt * WSTAGE + jb * (RP * 64)), 16, 0, 0);
         }
         frag_t xf[MT], wf[NT];
 #pragma unroll
@@ -698,6 +737,15 @@ static bool try_patch(const ConvArgs& a, hipStream_t s) {
         constexpr int LG64 = sizeof(T) == 2 ? 3 : 4;    // Cin = 64: 8 chunks (fp16) / 16 chunks (fp32) per pixel
         if (wide) return launch_patch<T, 4, 4, 4, 1, 8, 32, 3, LG64>(a, s);
         return launch_patch<T, 4, 4, 4, 1, 16, 16, 3, LG64>(a, s);
+    }
+    if (a.Cout == 80) {                                 // YOLOv8n's 22.cls0.0 (64 -> 80 at 80 x 80; round 5): 461 TFLOP/s on the 512 x 80 implicit-GEMM tile
+        static const bool c80 = getenv("AICAM_NO_PATCH_C80") == nullptr;
+        if constexpr (sizeof(T) == 2) {
+            if (!c80) return false;
+            if (wide) return launch_patch<T, 4, 5, 4, 1, 8, 32, 3, 3>(a, s);
+            return launch_patch<T, 4, 5, 4, 1, 16, 16, 3, 3>(a, s);
+        }
+        return false;
     }
     if (a.Cout == 32 && c32) {
         constexpr int LG32 = sizeof(T) == 2 ? 2 : 3;    // Cin = 32
