@@ -722,6 +722,7 @@ void launch_conv_igemm(int dtype, const ConvArgs& a0, hipStream_t s) {
         return;
     }
     if (dtype == AIC_F16 && conv_try_c16(a, s)) return;
+    if (dtype == AIC_F16 && conv_try_1x1_stream(a, s)) return;
     if (dtype == AIC_F16 && conv_try_c64_resident(a, s)) return;
     if (dtype == AIC_F16) launch_conv_t<half_t>(a, s);
     else launch_conv_t<float>(a, s);

@@ -261,6 +261,80 @@ static bool try_c32s2_tail(const ConvArgs& a, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Streaming 1x1 conv for 64 output channels and at most 128 input channels, fp16 (YOLOv8n's `4.c2f.cv2` and `15.c2f.cv2` at large batch:
+// 1 GB in + out per 512 frames each, 2x their HBM floor on the LDS-DMA implicit GEMM, whose K loop is three or four steps long).  No LDS, no
+// barrier: a wave keeps the whole weight matrix as MFMA A fragments (KS x 4 tiles) and walks 16-pixel tiles; a lane fetches ITS 16 bytes of
+// every K-step of a tile straight from memory (16 pixels x 64 contiguous bytes per instruction), the next tile's under this tile's MFMAs and
+// epilogue.  K in memory order from zero, the shared epilogue: the bits of the implicit GEMM.
+template <int KS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void conv1x1_stream_kernel(const ConvArgs a, int n_tiles) {
+    const int t = threadIdx.x, lane = t & 63, r = lane & 15, q = lane >> 4;
+    const int wave = (int)blockIdx.x * 4 + (t >> 6), n_waves = (int)gridDim.x * 4;
+    const half_t* wg = reinterpret_cast<const half_t*>(a.w);
+    half8 wf[4][KS];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) wf[j][s] = *reinterpret_cast<const half8*>(wg + (size_t)perm_row<4>(j, r) * a.Kp + 32 * s + 8 * q);
+    // a load instruction = 16 pixels x the 64 bytes of one K-step, lane L = (pixel L >> 2, 16-byte chunk L & 3): four consecutive lanes read
+    // 64 consecutive bytes.  (Fetched in the MFMA operand's own lane order -- lane (r, q) = (pixel r, chunk q), consecutive lanes a pixel
+    // pitch apart -- every lane is a memory request of its own: measured no faster than the implicit GEMM.)  The operand order is
+    // restored inside the wave: lane (r, q) takes the four dwords of lane 4 r + q (ds_bpermute).
+    const char* xb = reinterpret_cast<const char*>(a.x) + ((size_t)a.x_coff + 8 * (lane & 3)) * 2;
+    const size_t pitch = (size_t)a.x_cs * 2;
+    const int src_lane4 = (4 * r + q) * 4;
+    auto fetch = [&](int tile, int4 (&xr)[KS]) {
+        const int m = min(tile * 16 + (lane >> 2), a.M - 1);   // (rows past the end: any pixel; nothing of them is stored)
+        const char* p = xb + (size_t)m * pitch;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) xr[s] = *reinterpret_cast<const int4*>(p + 64 * s);
+    };
+    int4 xr[KS], xn[KS];
+    int tile = wave;
+    if (tile < n_tiles) fetch(tile, xr);
+    for (; tile < n_tiles; tile += n_waves) {
+        const int nt = tile + n_waves;
+        if (nt < n_tiles) fetch(nt, xn);
+        floatx4 acc[1][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[0][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            int4 g;
+            g.x = __builtin_amdgcn_ds_bpermute(src_lane4, xr[s].x), g.y = __builtin_amdgcn_ds_bpermute(src_lane4, xr[s].y);
+            g.z = __builtin_amdgcn_ds_bpermute(src_lane4, xr[s].z), g.w = __builtin_amdgcn_ds_bpermute(src_lane4, xr[s].w);
+            const half8 xf = __builtin_bit_cast(half8, g);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j][s], xf, acc[0][j], 0, 0, 0);
+        }
+        const int m = tile * 16 + r;
+        const int mrow[1] = {m < a.M ? m : -1};
+        epilogue_dispatch<half_t, 1, 4, true>(a, acc, mrow, 0, q);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) xr[s] = xn[s];
+    }
+}
+
+template <int KS>
+static void launch_1x1_stream(const ConvArgs& a, hipStream_t s) {
+    const int n_tiles = (a.M + 15) / 16;
+    const int blocks = std::min((n_tiles + 3) / 4, 256 * 4);           // 3 - 4 waves per SIMD resident: every wave walks a strided run of tiles
+    hipLaunchKernelGGL(conv1x1_stream_kernel<KS>, dim3(blocks), dim3(256), 0, s, a, n_tiles);
+    KCHECK();
+}
+
+static bool try_1x1_stream(const ConvArgs& a, hipStream_t s) {
+    static const bool off = getenv("AICAM_NO_1X1_STREAM") != nullptr;
+    if (off || a.KH != 1 || a.KW != 1 || a.stride != 1 || a.pad != 0 || a.Cout != 64 || a.Cin % 32 || a.Cin > 128 || a.Cin < 64 || a.Kp != a.Cin) return false;
+    if (a.res_mode != 0 || a.out_f32 || a.k_order != 0 || a.xs || a.x2 || a.w_tail || a.n_dev || a.bias_init || a.cout_pad < 64) return false;
+    if (a.M < 150000 || (a.x_cs | a.x_coff | a.y_cs | a.y_coff) % 8 || (long)a.M * std::max(a.x_cs, a.y_cs) >= (1l << 31)) return false;
+    if (a.Cin == 128) launch_1x1_stream<4>(a, s);
+    else if (a.Cin == 96) launch_1x1_stream<3>(a, s);
+    else launch_1x1_stream<2>(a, s);
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Persistent, weights-resident 3x3 / stride 1 / pad 1 for Cin = Cout = 64, fp16 (ReID layer1: 21 % of the FLOPs, tensors
 // of 1 GB per 128-frame launch group, K = 576 only).  A tile's K loop is too short to amortise a block's prologue and
 // epilogue (conv3x3_patch_kernel: 38 % MFMA busy), and every block re-fetches the 72 KB of weights through L2 -> LDS.
@@ -769,6 +843,7 @@ bool conv_try_patch(int dtype, const ConvArgs& a, hipStream_t s) {
 }
 bool conv_try_c16(const ConvArgs& a, hipStream_t s) { return try_c16(a, s); }
 bool conv_try_c32s2_tail(const ConvArgs& a, hipStream_t s) { return try_c32s2_tail(a, s); }
+bool conv_try_1x1_stream(const ConvArgs& a, hipStream_t s) { return try_1x1_stream(a, s); }
 bool conv_try_c64_resident(const ConvArgs& a, hipStream_t s) { return try_c64_resident(a, s); }
 
 // ------------------------------------------------------------------------------------------------

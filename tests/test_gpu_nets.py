@@ -400,7 +400,8 @@ np.savez(sys.argv[1], **out)
 def test_stride2_direct_kernel_with_tail_bit_exact(gpu, engines, tmp_path):
     """YOLOv8n's `3.conv` + `4.c2f.cv1` at large batch: conv3x3_c32s2_tail_kernel (3x3 / 2, 32 -> 64 channels, the input patch read once into
     LDS, the 1x1 in its epilogue) against the LDS-DMA implicit GEMM with the same tail (AICAM_NO_C32S2=1, a child process: read once per
-    process).  Same products in the same order, same roundings: the raw head of 24 frames (600 tiles: the kernel takes launches of 512 and
+    process); `4.c2f.cv2` and `15.c2f.cv2` likewise: conv1x1_stream_kernel (weights in registers, pixels straight from memory, no LDS)
+    against the implicit GEMM (AICAM_NO_1X1_STREAM=1).  Same products in the same order, same roundings: the raw head of 24 frames (600 tiles: the kernel takes launches of 512 and
     more) must be IDENTICAL, and it must be a real head."""
     import subprocess
     import sys
@@ -415,7 +416,7 @@ eng.close()
 np.savez(sys.argv[1], dfl=dfl, cls=cls)
 """ % (ROOT, engines[0])
     files = []
-    for name, env in (("direct", {}), ("igemm", {"AICAM_NO_C32S2": "1"})):
+    for name, env in (("direct", {}), ("igemm", {"AICAM_NO_C32S2": "1", "AICAM_NO_1X1_STREAM": "1"})):
         f = str(tmp_path / (name + ".npz"))
         r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
         print(r.stdout[-300:], r.stderr[-300:])

@@ -33,7 +33,7 @@ for k in keys[:int(sys.argv[3]) if len(sys.argv) > 3 else 30]:
 # The conv class as bench.py defines it (every MFMA conv kernel except the two fused 3-channel stems), weighted by busy cycles
 # = by time: the figure to hold against the north star's "MFMA utilisation on the conv kernels".
 def conv_class(name):
-    return any(t in name for t in ("conv_igemm", "conv3x3", "c2f16"))
+    return any(t in name for t in ("conv_igemm", "conv3x3", "conv1x1", "c2f16"))
 
 num = sum(a[k].get("SQ_VALU_MFMA_BUSY_CYCLES", 0) * a[k]["_n"] for k in a if conv_class(k[0]))
 den = sum(a[k].get("SQ_BUSY_CYCLES", 0) * a[k]["_n"] for k in a if conv_class(k[0]))
