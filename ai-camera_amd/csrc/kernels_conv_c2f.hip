@@ -77,14 +77,24 @@ __global__ __launch_bounds__(256) void c2f16_fused_kernel(const C2fArgs a, int t
     const half_t* xg = a.x + (size_t)img * a.H * a.W * a.x_cs + a.x_coff;
 
     // ---- S1: input tile with halo 2 -> LDS (four 16-byte channel groups per pixel)
-    for (int idx = t; idx < XR * XC * 4; idx += 256) {
-        const int g = idx & 3, p = idx >> 2;
-        const int pr = p / XC, pc = p - pr * XC;
-        const int iy = oy0 - 2 + pr, ix = ox0 - 2 + pc;
-        uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
-            v = *reinterpret_cast<const uint4*>(xg + ((size_t)iy * a.W + ix) * a.x_cs + g * 8);
-        *reinterpret_cast<uint4*>(smem + LDS_X + g * PX + x_slot(p, g) * 16) = v;
+    {   // (all of a thread's loads in flight before the first store: rolled, the loop was seven dependent HBM round trips per block)
+        constexpr int NSLOT = XR * XC * 4, NIT = (NSLOT + 255) / 256;
+        uint4 v[NIT];
+        int dst[NIT];
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) {
+            const int idx = t + u * 256;
+            const int g = idx & 3, p = idx >> 2;
+            const int pr = p / XC, pc = p - pr * XC;
+            const int iy = oy0 - 2 + pr, ix = ox0 - 2 + pc;
+            v[u] = make_uint4(0u, 0u, 0u, 0u);
+            if (idx < NSLOT && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
+                v[u] = *reinterpret_cast<const uint4*>(xg + ((size_t)iy * a.W + ix) * a.x_cs + g * 8);
+            dst[u] = idx < NSLOT ? LDS_X + g * PX + x_slot(p, g) * 16 : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < NIT; ++u)
+            if (dst[u] >= 0) *reinterpret_cast<uint4*>(smem + dst[u]) = v[u];
     }
     // weights as A fragments
     half8 w1[2], w2[5], w3[5], w4[2][2];

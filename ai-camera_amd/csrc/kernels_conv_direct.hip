@@ -31,15 +31,26 @@ __global__ __launch_bounds__(256) void conv3x3_c16_kernel(const ConvArgs a, int 
     const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
     const half_t* xg = reinterpret_cast<const half_t*>(a.x) + (size_t)img * a.H * a.W * a.x_cs + a.x_coff;
 
-    for (int idx = t; idx < PR * PC * 2; idx += 256) {
-        const int h = idx & 1, pp = idx >> 1;
-        const int pr = pp / PC, pc = pp - pr * PC;
-        const int iy = iy0 + pr, ix = ix0 + pc;
-        uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
-            v = *reinterpret_cast<const uint4*>(xg + ((size_t)iy * a.W + ix) * a.x_cs + h * 8);
-        const int par = pc % NPAR, c2 = pc / NPAR;
-        *reinterpret_cast<uint4*>(smem + (((pr * NPAR + par) * 2 + h) * PCP + c2) * 16) = v;
+    // all of a thread's patch loads in flight before the first store (rolled, the loop was nine dependent HBM round trips per block)
+    constexpr int NSLOT = PR * PC * 2, NIT = (NSLOT + 255) / 256;
+    {
+        uint4 v[NIT];
+        int dst[NIT];
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) {
+            const int idx = t + u * 256;
+            const int h = idx & 1, pp = idx >> 1;
+            const int pr = pp / PC, pc = pp - pr * PC;
+            const int iy = iy0 + pr, ix = ix0 + pc;
+            v[u] = make_uint4(0u, 0u, 0u, 0u);
+            if (idx < NSLOT && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
+                v[u] = *reinterpret_cast<const uint4*>(xg + ((size_t)iy * a.W + ix) * a.x_cs + h * 8);
+            const int par = pc % NPAR, c2 = pc / NPAR;
+            dst[u] = idx < NSLOT ? (((pr * NPAR + par) * 2 + h) * PCP + c2) * 16 : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < NIT; ++u)
+            if (dst[u] >= 0) *reinterpret_cast<uint4*>(smem + dst[u]) = v[u];
     }
 
     // A fragments: MFMA m covers K = 32m .. 32m+31 = taps 2m, 2m+1 x 16 channels (Kp = 160: k >= 144 are zero rows)
@@ -136,9 +147,10 @@ static bool try_c16(const ConvArgs& a, hipStream_t s) {
 // YOLOv8n's `3.conv` + `4.c2f.cv1` at large batch (160 x 160 -> 80 x 80, round 5).  Through the LDS-DMA implicit GEMM the pair took
 // 845 us per 512 frames at 7.8 % MFMA busy -- four times its HBM floor (839 MB in, 419 MB out): a stride-2 im2col K-step gathers 64-byte
 // half lines and every input pixel comes through the L2 2.25 times.  Here a block owns 16 x 16 output pixels of one image:
-//  * the 33 x 33 x 32-channel input patch is read ONCE into LDS, pixel-major (64 bytes per pixel), even and odd columns apart (pitch 18
-//    pixels: the 64 lanes of a store hit every bank once, the 64 lanes of a fragment read -- 16 output pixels x 4 channel chunks of one
-//    tap -- 1 KB of consecutive bytes);
+//  * the 33 x 33 x 32-channel input patch is read ONCE into LDS as [row][column parity][8-channel chunk][column / 2] x 16 bytes (pitch 18
+//    columns): the 16 lanes that share a chunk of a fragment read -- 16 output pixels of one tap -- take 256 consecutive bytes, and the
+//    16 lanes of a store (four pixels x four chunks, 288 bytes from chunk to chunk, 1 152 from parity to parity) hit every bank once.
+//    (Pixel-major, 64 bytes per pixel, the same 16 lanes read 64 bytes apart: a 4-way conflict, 45 % of the kernel's LDS cycles);
 //  * K in memory order (tap, channel): one v_mfma_f32_16x16x32_f16 per tap and channel tile, nine per accumulator, from zero, in tap
 //    order; bias + SiLU + fp16 rounding and the 1x1 in tail_1x1() (conv_common.hpp) -- the products, their order and the roundings of
 //    conv_igemm_dma_kernel<.., TAIL> and of the wide-step kernel small launches get: bit-identical;
@@ -188,7 +200,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
             v[u] = make_uint4(0u, 0u, 0u, 0u);
             if (idx < NSLOT && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
                 v[u] = *reinterpret_cast<const uint4*>(xg + ((size_t)iy * a.W + ix) * a.x_cs + c * 8);
-            dst[u] = idx < NSLOT ? pr * ROWB + ((pc & 1) * PCP + (pc >> 1)) * 64 + c * 16 : -1;
+            dst[u] = idx < NSLOT ? pr * ROWB + (((pc & 1) * 4 + c) * PCP + (pc >> 1)) * 16 : -1;
         }
 #pragma unroll
         for (int u = 0; u < NB; ++u)
@@ -199,7 +211,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
         const int kh = tap / 3, kw = tap - 3 * kh;
-        toff[tap] = kh * ROWB + ((kw & 1) * PCP + (kw >> 1) + r) * 64 + q * 16;
+        toff[tap] = kh * ROWB + (((kw & 1) * 4 + q) * PCP + (kw >> 1) + r) * 16;
     }
     floatx4 acc[4][4];
 #pragma unroll
