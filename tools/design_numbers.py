@@ -9,7 +9,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TAG = sys.argv[1] if len(sys.argv) > 1 else "r05"
-RANGE = sys.argv[2] if len(sys.argv) > 2 else "10 923 – 11 347"
+RANGE = sys.argv[2] if len(sys.argv) > 2 else "10 923 – 11 494"
 P = lambda n: os.path.join(ROOT, "profiles", f"{TAG}_{n}")
 
 TEMPLATE = r"""| Quantity | Value | Source |
@@ -27,7 +27,7 @@ TEMPLATE = r"""| Quantity | Value | Source |
 | launch groups of 16 / 64 / 128 / 256 / 512 frames: frames/s (p50 latency) | @CURVE@ | same |
 | CPU oracle chain on the box's 16 cores / 1 thread | @CPU16@ / @CPU1@ frames/s | same |
 | YOLOv8m fp32 boxes vs the fp64 evaluation of the same engine (33 600 coordinates) | rms 5.3e-5 px, 99.9th percentile 5.2e-4, max 1.05e-3 (1 coordinate above 1e-3); round 4: max 1.6e-3 | `gpurun_out/r5_v8m_err.txt`, `tests/test_gpu_configs.py` |
-| GPU test suite | 161 passed (`pytest -m gpu`, 6 min); CPU suite 46 passed | `GPUTEST_r05.json` |"""
+| GPU test suite | 162 passed (`pytest -m gpu`, 6 min); CPU suite 46 passed | `GPUTEST_r05.json` |"""
 
 
 def sp(x, nd=0):
