@@ -514,6 +514,7 @@ void Model::run_ops(size_t op0, int n, hipStream_t s) {
         return;
     }
     size_t at = op0;
+    try {
     for (size_t i = 0; i < side_heads.size(); ++i) {                      // main stream up to each fork, the level's ops behind it on their stream
         const SideHead& h = side_heads[i];
         run_range(at, h.cut, 0, n, s);
@@ -529,6 +530,11 @@ void Model::run_ops(size_t op0, int n, hipStream_t s) {
         if (i < side_heads.size()) at = std::max(at, side_heads[i].b);
     }
     for (size_t i = 0; i < side_heads.size(); ++i) HIP_CHECK(hipStreamWaitEvent(s, side_join[i], 0));
+    } catch (...) {                                                       // a launch failed between a fork and its join: nothing of this call may still run when the next one starts
+        for (size_t i = 0; i < side_heads.size(); ++i) (void)hipStreamSynchronize(side_stream[i]);
+        (void)hipStreamSynchronize(s);
+        throw;
+    }
 }
 
 bool Model::input_pix4_ok() const {
