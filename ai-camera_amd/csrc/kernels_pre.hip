@@ -137,7 +137,7 @@ typedef float floatx4_t __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void yolo_stem_fused_kernel(const uint8_t* __restrict__ frames, LetterboxGeom g,
                                                               const half_t* __restrict__ w, const float* __restrict__ bias, int Kp,
                                                               half_t* __restrict__ y, int y_cs, int y_coff, int Ho, int Wo, int tiles_x,
-                                                              int tiles_y) {
+                                                              int tiles_y, unsigned frames_limit) {
     constexpr int TH = 8, TW = 32, PR = 2 * TH + 1, PC = 2 * TW + 1, PCP = (PC + 1) / 2;
     __shared__ uint2 patch[PR * 2 * PCP];      // entry (row, column parity, column / 2)
 
@@ -150,6 +150,12 @@ __global__ __launch_bounds__(256) void yolo_stem_fused_kernel(const uint8_t* __r
     const int Y0 = 2 * oy0 - 1, X0 = 2 * ox0 - 1;
     const uint8_t* f = frames + (size_t)img * g.src_h * g.src_w * 3;
     const bool area2 = is_area2(g.src_w, g.src_h, g.unpad_w, g.unpad_h);
+    // 32-bit byte offsets from the frames pointer rounded down to 4 bytes (fast6: the launcher checked that every frame of the call fits them)
+    const uintptr_t fb = reinterpret_cast<uintptr_t>(frames);
+    const uint8_t* fa = reinterpret_cast<const uint8_t*>(fb & ~(uintptr_t)3);
+    const int pitch = g.src_w * 3;
+    const unsigned img_off = (unsigned)(fb & 3) + (unsigned)img * (unsigned)g.src_h * (unsigned)pitch;
+    const bool fast6 = frames_limit != 0u;
     const double sx = 1.0 / ((double)g.unpad_w / (double)g.src_w);
     const double sy = 1.0 / ((double)g.unpad_h / (double)g.src_h);
 
@@ -160,8 +166,28 @@ __global__ __launch_bounds__(256) void yolo_stem_fused_kernel(const uint8_t* __r
         if ((unsigned)Y < (unsigned)g.out_h && (unsigned)X < (unsigned)g.out_w) {
             int px[3] = {114, 114, 114};
             const int yy = Y - g.top, xx = X - g.left;
-            if (yy >= 0 && yy < g.unpad_h && xx >= 0 && xx < g.unpad_w)
-                sample_px(f, g.src_w * 3, 0, 0, g.src_w, g.src_h, xx, yy, g.unpad_w, g.unpad_h, area2, sx, sy, px);
+            if (yy >= 0 && yy < g.unpad_h && xx >= 0 && xx < g.unpad_w) {
+                // the 2 x 2 area path (1280 x 720 -> 640 x 360): a pixel is two rows of six consecutive bytes -- one aligned 12-byte load per
+                // row and a byte alignment instead of twelve byte loads (sample_px's sums on the same bytes: same integers); the byte form
+                // where the 12 bytes would reach past the frames handed in
+                const unsigned o0 = img_off + (unsigned)(2 * yy) * (unsigned)pitch + (unsigned)(2 * xx) * 3u;
+                if (area2 && fast6 && o0 + (unsigned)pitch + 12u <= frames_limit) {
+                    int b[2][6];
+#pragma unroll
+                    for (int rr = 0; rr < 2; ++rr) {
+                        const unsigned o = o0 + (rr ? (unsigned)pitch : 0u);
+                        const uint3 w3 = *reinterpret_cast<const uint3*>(fa + (o & ~3u));
+                        const unsigned shb = o & 3u;
+                        const unsigned q0 = __builtin_amdgcn_alignbyte(w3.y, w3.x, shb), q1 = __builtin_amdgcn_alignbyte(w3.z, w3.y, shb);
+                        b[rr][0] = q0 & 255u, b[rr][1] = (q0 >> 8) & 255u, b[rr][2] = (q0 >> 16) & 255u;
+                        b[rr][3] = q0 >> 24, b[rr][4] = q1 & 255u, b[rr][5] = (q1 >> 8) & 255u;
+                    }
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) px[c] = (b[0][c] + b[0][3 + c] + b[1][c] + b[1][3 + c] + 2) >> 2;
+                } else {
+                    sample_px(f, g.src_w * 3, 0, 0, g.src_w, g.src_h, xx, yy, g.unpad_w, g.unpad_h, area2, sx, sy, px);
+                }
+            }
             const half4_t h = {(half_t)((float)px[2] / 255.0f), (half_t)((float)px[1] / 255.0f), (half_t)((float)px[0] / 255.0f), (half_t)0.f};
             v = __builtin_bit_cast(uint2, h);
         }
@@ -210,8 +236,11 @@ bool launch_yolo_stem_fused(const uint8_t* frames, int n, const LetterboxGeom& g
     if (n <= 0) return true;
     if (Ho % 8 || Wo % 32 || Ho * 2 != g.out_h || Wo * 2 != g.out_w || (y_cs | y_coff) % 4) return false;
     const int tiles_x = Wo / 32, tiles_y = Ho / 8;
+    // bytes from the 4-byte-aligned base to the end of the call's last frame, or 0 when they do not fit 32 bits (the kernel then reads bytes)
+    const unsigned long long total = (unsigned long long)(reinterpret_cast<uintptr_t>(frames) & 3) + (unsigned long long)n * g.src_h * g.src_w * 3;
+    const unsigned frames_limit = total < (1ull << 32) - 64 ? (unsigned)total : 0u;
     hipLaunchKernelGGL(yolo_stem_fused_kernel, dim3(n * tiles_x * tiles_y), dim3(256), 0, s, frames, g, reinterpret_cast<const half_t*>(w),
-                       bias, Kp, reinterpret_cast<half_t*>(y), y_cs, y_coff, Ho, Wo, tiles_x, tiles_y);
+                       bias, Kp, reinterpret_cast<half_t*>(y), y_cs, y_coff, Ho, Wo, tiles_x, tiles_y, frames_limit);
     KCHECK();
     return true;
 }
