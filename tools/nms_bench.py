@@ -17,6 +17,8 @@ he = importlib.import_module("ai-camera_amd.hip_engine")
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 ypath, _ = ef.ensure_seeded_engines(ROOT)
+if os.environ.get("TRAINED", "0") != "0":            # the trained detector (~30 candidates per frame instead of ~3 000)
+    ypath = ef.ensure_trained_detector(ROOT)
 sc = syn.Scene(seed=0, n_targets=30)
 frames = sc.render_batch(0, n)
 eng = he.HipEngine(ypath, dtype="fp16", max_items=n, warm_up=False)
