@@ -841,6 +841,135 @@ static bool try_patch(const ConvArgs& a, hipStream_t s) {
     return false;
 }
 
+// ------------------------------------------------------------------------------------------------
+// The patch form for 80 -> 80 channels with the 1x1 behind it (YOLOv8n's `22.cls{l}.1` + `.2` at large batch; round 5).  80 channels are ten
+// 16-byte chunks per pixel -- not a power of two, not a multiple of the 32-element K-step -- so conv3x3_patch_kernel (chunk index by shift
+// and mask, XOR swizzle, one tap per K-step) does not take the layer and it ran on the implicit GEMM's generic gather path (880 us per 512
+// frames at level 0, 23 % MFMA busy; the patch kernel runs the 64 -> 80 conv beside it at 750 TFLOP/s).  Here:
+//  * the 18 x 18 x 80-channel patch of a 16 x 16 tile goes into LDS ONCE by LDS-DMA, pixel-major, 160 bytes per pixel, unswizzled (the 16
+//    lanes of a fragment read are 160 bytes apart: a 2-way conflict on four reads per 20 MFMAs; a pitch of 176 would be conflict-free and
+//    would not leave room for two blocks per CU);
+//  * K in memory order (tap, channel) in 32-element steps FROM k = 0, as the implicit GEMM walks it: step s is the flattened chunks
+//    4 s .. 4 s + 3 = (tap, chunk) (kc / 10, kc % 10) -- a step straddles taps, so a lane's (tap, chunk) depends on its q: 23 per-lane
+//    offsets, worked out once; the last step's chunks 90, 91 meet the zero columns of the padded weights (Kp = 736) and read chunk 0;
+//  * weights through the 3-stage ring of conv3x3_patch_kernel (128 padded rows: two 16-byte chunks per thread and step), the epilogue is
+//    tail_1x1<4, 5>: bit-identical to conv_igemm_dma_kernel<.., TAIL> (child-process test).
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv3x3_c80_patch_tail_kernel(const ConvArgs a, int tiles_x, int tiles_y) {
+    typedef half_t T;
+    constexpr int MT = 4, NT = 5, TH = 16, TW = 16, CPP = 10, PW = TW + 2, PH = TH + 2, NSTAGE = 3;
+    constexpr int NTHR = 256, RP = 64, BN = 80, BNP = 128, B_PER = 2, WSTAGE = BNP * 64, BKE = 32, CH = 8;
+    constexpr int TOTAL = PH * PW * CPP, PATCH_BYTES = (TOTAL + NTHR - 1) / NTHR * NTHR * 16, NSTEPS = (9 * CPP + 3) / 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* ring = smem + PATCH_BYTES;
+
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    int bx = xcd_tile((int)blockIdx.x, (int)gridDim.x, a.xcd_map);
+    const int tx = bx % tiles_x; bx /= tiles_x;
+    const int ty = bx % tiles_y;
+    const int img = bx / tiles_y;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const T* __restrict__ wg = reinterpret_cast<const T*>(a.w);
+    const T* zero = reinterpret_cast<const T*>(a.zero);
+    const T* ximg = reinterpret_cast<const T*>(a.x) + (size_t)img * a.H * a.W * a.x_cs + a.x_coff;
+
+    // ---- the input patch, once (out-of-image pixels come from the zero page)
+#pragma unroll 2
+    for (int base = 0; base < TOTAL; base += NTHR) {
+        const int L = base + t;
+        const int p = L / CPP, j = L - p * CPP;
+        const int py = p / PW, px = p - py * PW;
+        const int iy = oy0 + py - 1, ix = ox0 + px - 1;
+        const bool ok = L < TOTAL && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        const T* src = ok ? ximg + ((size_t)iy * a.W + ix) * a.x_cs + j * CH : zero;
+        asm volatile("" : "+v"(src));
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + (size_t)(base + 64 * wv) * 16), 16, 0, 0);
+    }
+    // ---- weight stream: two 16-byte chunks per thread per K-step (rows r0, r0 + 64); rows past Cout read the zero page with stride 0
+    const int slot = t & 3, r0 = t >> 2;
+    const int kc = slot ^ lds_swz(r0);
+    const T* wnext[B_PER];
+    int winc[B_PER];
+#pragma unroll
+    for (int jb = 0; jb < B_PER; ++jb) {
+        const bool wrow_ok = r0 + RP * jb < BN;
+        wnext[jb] = wrow_ok ? wg + (size_t)(r0 + RP * jb) * a.Kp + kc * CH : zero;
+        winc[jb] = wrow_ok ? BKE : 0;
+    }
+    char* wdst = ring + (16 * wv) * 64;
+#pragma unroll
+    for (int st = 0; st < NSTAGE - 1; ++st)
+#pragma unroll
+        for (int jb = 0; jb < B_PER; ++jb) {
+            __builtin_amdgcn_global_load_lds((gptr_t)wnext[jb], (lptr_t)(wdst + st * WSTAGE + jb * (RP * 64)), 16, 0, 0);
+            wnext[jb] += winc[jb];
+        }
+
+    const int q = lane >> 4, r = lane & 15;
+    int koff[NSTEPS];                           // this lane's (tap, chunk) of every K-step, as a byte offset from its pixel's tap (0, 0), chunk 0
+#pragma unroll
+    for (int s2 = 0; s2 < NSTEPS; ++s2) {
+        int c = 4 * s2 + q;
+        if (c >= 9 * CPP) c = 0;
+        const int tap = c / CPP, ch = c - tap * CPP, kh = tap / 3, kw = tap - 3 * kh;
+        koff[s2] = ((kh * PW + kw) * CPP + ch) * 16;
+    }
+    int xbase[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) xbase[i] = ((wv * MT + i) * PW + r) * (CPP * 16);          // pixel tile (wave, i) = row 4 wv + i of the tile, pixel r
+    int woff[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) woff[j] = PATCH_BYTES + lds_off(perm_row<NT>(j, r), q);
+
+    floatx4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int step = 0; step < NSTEPS; ++step) {                     // fully unrolled: ring stages are compile-time
+        const int cur = step % NSTAGE, nxt = (step + NSTAGE - 1) % NSTAGE;
+        wait_vmcnt<(NSTAGE - 2) * B_PER>();
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int jb = 0; jb < B_PER; ++jb) {    // refill the stage that step - 1 released (zero page once the real K-steps are exhausted)
+            const T* src = step + NSTAGE - 1 < NSTEPS ? wnext[jb] : zero;
+            wnext[jb] += winc[jb];
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(wdst + nxt * WSTAGE + jb * (RP * 64)), 16, 0, 0);
+        }
+        half8 xf[MT], wf[NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) xf[i] = *reinterpret_cast<const half8*>(smem + xbase[i] + koff[step]);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) wf[j] = *reinterpret_cast<const half8*>(smem + woff[j] + cur * WSTAGE);
+        mma_tiles<T, MT, NT>(acc, wf, xf);
+    }
+    wait_vmcnt<0>();
+
+    int mrow[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) mrow[i] = (img * a.Ho + oy0 + wv * MT + i) * a.Wo + ox0 + r;
+    tail_1x1<MT, NT>(a, acc, mrow, lane);
+}
+
+bool conv_try_c80_patch_tail(const ConvArgs& a, hipStream_t s) {
+    static const bool off = getenv("AICAM_NO_PATCH_C80") != nullptr;
+    if (off || !a.w_tail || a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.Cin != 80 || a.Cout != 80 || a.Kp != 736) return false;
+    if (a.k_order != 0 || a.xs || a.x2 || a.n_dev || a.res_mode != 0 || a.out_f32 || a.act != 1 || a.cout_pad < 128) return false;
+    if (a.Ho != a.H || a.Wo != a.W || a.Wo % 16 || a.Ho % 16 || a.M < 200000 || (a.x_cs | a.x_coff) % 8) return false;
+    constexpr size_t lds = (size_t)((18 * 18 * 10 + 255) / 256 * 256) * 16 + (size_t)3 * 128 * 64;
+    static_assert(2 * lds <= 160 * 1024, "two blocks per CU");
+    static bool attr = false;
+    if (!attr) {
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c80_patch_tail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = true;
+    }
+    const int tiles_x = a.Wo / 16, tiles_y = a.Ho / 16, n_img = a.M / (a.Ho * a.Wo);
+    hipLaunchKernelGGL(conv3x3_c80_patch_tail_kernel, dim3(n_img * tiles_x * tiles_y), dim3(256), lds, s, a, tiles_x, tiles_y);
+    KCHECK();
+    return true;
+}
+
 // the Cout = 64 patch kernel with a 1x1 tail (same eligibility as try_patch)
 bool conv_try_patch_tail(const ConvArgs& a, hipStream_t s) {
     static const bool off = getenv("AICAM_NO_PATCH") != nullptr;

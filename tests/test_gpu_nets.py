@@ -401,22 +401,24 @@ def test_stride2_direct_kernel_with_tail_bit_exact(gpu, engines, tmp_path):
     """YOLOv8n's `3.conv` + `4.c2f.cv1` at large batch: conv3x3_c32s2_tail_kernel (3x3 / 2, 32 -> 64 channels, the input patch read once into
     LDS, the 1x1 in its epilogue) against the LDS-DMA implicit GEMM with the same tail (AICAM_NO_C32S2=1, a child process: read once per
     process); `4.c2f.cv2` and `15.c2f.cv2` likewise: conv1x1_stream_kernel (weights in registers, pixels straight from memory, no LDS)
-    against the implicit GEMM (AICAM_NO_1X1_STREAM=1).  Same products in the same order, same roundings: the raw head of 24 frames (600 tiles: the kernel takes launches of 512 and
-    more) must be IDENTICAL, and it must be a real head."""
+    against the implicit GEMM (AICAM_NO_1X1_STREAM=1); `22.cls0.0` on the patch kernel's 80-channel form and `22.cls0.1` + `.2` on
+    conv3x3_c80_patch_tail_kernel (the patch form for ten chunks per pixel, K-steps that straddle taps) against the implicit GEMM's
+    tiles (AICAM_NO_PATCH_C80=1).  Same products in the same order, same roundings: the raw head of 32 frames (every one of these kernels
+    engages at that size) must be IDENTICAL, and it must be a real head."""
     import subprocess
     import sys
     code = r"""
 import importlib, sys, numpy as np
 sys.path.insert(0, %r)
 he = importlib.import_module("ai-camera_amd.hip_engine")
-x = np.random.default_rng(13).uniform(0, 1, (24, 3, 640, 640)).astype(np.float32)
-eng = he.HipEngine(%r, dtype="fp16", max_items=24, warm_up=False)
+x = np.random.default_rng(13).uniform(0, 1, (32, 3, 640, 640)).astype(np.float32)
+eng = he.HipEngine(%r, dtype="fp16", max_items=32, warm_up=False)
 dfl, cls = eng.yolo_head_np(x)
 eng.close()
 np.savez(sys.argv[1], dfl=dfl, cls=cls)
 """ % (ROOT, engines[0])
     files = []
-    for name, env in (("direct", {}), ("igemm", {"AICAM_NO_C32S2": "1", "AICAM_NO_1X1_STREAM": "1"})):
+    for name, env in (("direct", {}), ("igemm", {"AICAM_NO_C32S2": "1", "AICAM_NO_1X1_STREAM": "1", "AICAM_NO_PATCH_C80": "1"})):
         f = str(tmp_path / (name + ".npz"))
         r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
         print(r.stdout[-300:], r.stderr[-300:])
