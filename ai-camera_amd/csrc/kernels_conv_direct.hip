@@ -948,7 +948,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
 
     int mrow[MT];
 #pragma unroll
-    for (int i = 0; i < MT; ++i) mrow[i] = (img * a.Ho + oy0 + wv * MT + i) * a.Wo + ox0 + r;
+    for (int i = 0; i < MT; ++i) {             // (tiles may hang over the map's edge -- a 40 x 40 map is 3 x 3 of them: those pixels are computed on zeros and not stored)
+        const int oy = oy0 + wv * MT + i, ox = ox0 + r;
+        mrow[i] = (oy < a.Ho && ox < a.Wo) ? (img * a.Ho + oy) * a.Wo + ox : -1;
+    }
     tail_1x1<MT, NT>(a, acc, mrow, lane);
 }
 
@@ -956,7 +959,11 @@ bool conv_try_c80_patch_tail(const ConvArgs& a, hipStream_t s) {
     static const bool off = getenv("AICAM_NO_PATCH_C80") != nullptr;
     if (off || !a.w_tail || a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.Cin != 80 || a.Cout != 80 || a.Kp != 736) return false;
     if (a.k_order != 0 || a.xs || a.x2 || a.n_dev || a.res_mode != 0 || a.out_f32 || a.act != 1 || a.cout_pad < 128) return false;
-    if (a.Ho != a.H || a.Wo != a.W || a.Wo % 16 || a.Ho % 16 || a.M < 200000 || (a.x_cs | a.x_coff) % 8) return false;
+    if (a.Ho != a.H || a.Wo != a.W || a.M < 50000 || (a.x_cs | a.x_coff) % 8) return false;      // (below: a few tiles, the wide-step kernel or v2)
+    {   // whole 16 x 16 tiles, or at most half as many pixels again hanging over the edge (40 x 40: 1.44; 20 x 20 would be 2.56)
+        const long cover = (long)ceil_div(a.Wo, 16) * 16 * ceil_div(a.Ho, 16) * 16;
+        if (2 * cover > 3 * (long)a.Wo * a.Ho) return false;
+    }
     constexpr size_t lds = (size_t)((18 * 18 * 10 + 255) / 256 * 256) * 16 + (size_t)3 * 128 * 64;
     static_assert(2 * lds <= 160 * 1024, "two blocks per CU");
     static bool attr = false;
@@ -964,7 +971,7 @@ bool conv_try_c80_patch_tail(const ConvArgs& a, hipStream_t s) {
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c80_patch_tail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr = true;
     }
-    const int tiles_x = a.Wo / 16, tiles_y = a.Ho / 16, n_img = a.M / (a.Ho * a.Wo);
+    const int tiles_x = ceil_div(a.Wo, 16), tiles_y = ceil_div(a.Ho, 16), n_img = a.M / (a.Ho * a.Wo);
     hipLaunchKernelGGL(conv3x3_c80_patch_tail_kernel, dim3(n_img * tiles_x * tiles_y), dim3(256), lds, s, a, tiles_x, tiles_y);
     KCHECK();
     return true;
