@@ -585,7 +585,7 @@ __device__ __forceinline__ void tail_1x1(const ConvArgs& a, floatx4 (&acc)[MT][N
         } else if (NT == 4 && a.t_box) {
             // box decode (ConvArgs::t_box).  Lane (r, q) holds bins 8 (q & 1) .. + 7 of side q >> 1 (tiles 0, 1) and of side 2 + (q >> 1)
             // (tiles 2, 3); its partner q ^ 1 holds the other eight.  decode_kernel's order is kept exactly: the maximum of the sixteen
-            // (exact in any order), then e_k = expf(v_k - max), sum += e_k, ex += e_k * k for k = 0 .. 15 IN THAT ORDER -- the even lane
+            // (exact in any order), then e_k = exp(v_k - max) (v_exp_f32 of the product with log2 e: decode_kernel's fp16 form), sum += e_k, ex += e_k * k for k = 0 .. 15 IN THAT ORDER -- the even lane
             // runs bins 0 .. 7 from zero, hands its two running sums to the odd lane, which continues with 8 .. 15 and divides.
             if constexpr (NT == 4) {
                 floatx4 bt[4];
@@ -607,7 +607,7 @@ __device__ __forceinline__ void tail_1x1(const ConvArgs& a, floatx4 (&acc)[MT][N
                     mx = fmaxf(mx, __shfl_xor(mx, 16));
                     float e[8];
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) e[k] = expf(v[k] - mx);
+                    for (int k = 0; k < 8; ++k) e[k] = __builtin_amdgcn_exp2f((v[k] - mx) * 1.4426950408889634f);   // (DetArgs::fast_exp: decode_kernel's form for fp16 engines -- 64 expf per lane and pixel tile were a third of the box tails' time)
                     float sum = 0.f, ex = 0.f;
                     if (!odd) {
 #pragma unroll
@@ -735,7 +735,7 @@ int conv_pp_patch_shape(int dtype, const ConvArgs& a);                 // != 0 (
 bool conv_try_pp(int dtype, const ConvArgs& a, hipStream_t s);         // kernels_conv_pp.hip: v4 ping-pong im2col (long K, Cout 128 / 256k)
 bool conv_try_patch(int dtype, const ConvArgs& a, hipStream_t s);      // kernels_conv_direct.hip: 4-wave patch kernel (Cout 64 / 32)
 bool conv_try_patch_tail(const ConvArgs& a, hipStream_t s);            // same kernel, Cout 64, with a.w_tail's 1x1 in its epilogue (fp16)
-bool conv_try_c80_patch_tail(const ConvArgs& a, hipStream_t s);        // kernels_conv_direct.hip: 3x3 / 1, 80 -> 80 channels with a.w_tail's 1x1 in its epilogue (fp16, large batch)
+bool conv_try_pm_patch_tail(const ConvArgs& a, hipStream_t s);         // kernels_conv_direct.hip: 3x3 / 1, 80 -> 80 or 64 -> 64 channels with a.w_tail's 1x1 in its epilogue, pixel-major patch (fp16)
 bool conv_try_c16(const ConvArgs& a, hipStream_t s);                   // kernels_conv_direct.hip: 16 input channels, fp16
 bool conv_try_1x1_stream(const ConvArgs& a, hipStream_t s);             // kernels_conv_direct.hip: 1x1, <= 128 -> 64 channels, no LDS (fp16, large batch)
 bool conv_try_c32s2_tail(const ConvArgs& a, hipStream_t s);            // kernels_conv_direct.hip: 3x3 / 2, 32 -> 64 channels with a.w_tail's 1x1 in its epilogue (fp16, large batch)

@@ -756,6 +756,7 @@ DetArgs Model::det_args(int batch, float conf, float iou, int max_det, const Let
         a0 += v[3] * v[4];
     }
     a.n_levels = (int)outs.size(), a.n_anchors = n_anchors, a.nc = meta[0], a.reg_max = meta[1], a.batch = batch;
+    a.fast_exp = dtype == AIC_F16;
     a.logit_thr = (float)std::log((double)conf / (1.0 - (double)conf));
     a.iou_thr = iou, a.max_det = max_det;
     a.pad_w = g ? g->pad_w : 0.f, a.pad_h = g ? g->pad_h : 0.f, a.ratio = g ? g->ratio : 1.f;

@@ -137,6 +137,7 @@ struct HeadLevel { const float* box; const float* cls; int h, w, stride, a0; int
 struct DetArgs {
     HeadLevel lvl[4];
     int n_levels, n_anchors, nc, reg_max, batch;
+    int fast_exp;      // fp16 engines: the DFL softmax's exponential as v_exp_f32(x log2 e), the form the box branches' tails use (tail_1x1); fp32 engines: expf
     float logit_thr, iou_thr;
     int max_det;
     // letterbox undo (K4)

@@ -689,11 +689,12 @@ bool conv_x2_supported(int dtype, const ConvArgs& a, int cin2) {
 static void launch_conv_tail(const ConvArgs& a, hipStream_t s) {
     if (a.Cout == 64) {
         if (conv_try_c32s2_tail(a, s)) return;
+        if (conv_try_pm_patch_tail(a, s)) return;
         if (conv_try_patch_tail(a, s)) return;
         if ((long)ceil_div(a.M, 128) >= 512) launch_dma<half_t, 4, 4, 4, 1, 4, true>(a, s);   // 256 px x 64 ch
         else if (!conv_try_wide_tail<2, 4>(a, s)) launch_dma<half_t, 2, 4, 4, 1, 4, true>(a, s);   // 128 px x 64 ch (a few tiles: kernels_conv_wide.hip)
     } else {                                                                                  // 80
-        if (conv_try_c80_patch_tail(a, s)) return;
+        if (conv_try_pm_patch_tail(a, s)) return;
         if (ceil_div(a.M, 512) >= 256) launch_dma<half_t, 4, 5, 8, 1, 3, true>(a, s);          // 512 px x 80 ch
         else if (!conv_try_wide_tail<2, 5>(a, s)) launch_dma<half_t, 2, 5, 4, 1, 4, true>(a, s);   // 128 px x 80 ch
     }

@@ -842,23 +842,30 @@ static bool try_patch(const ConvArgs& a, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// The patch form for 80 -> 80 channels with the 1x1 behind it (YOLOv8n's `22.cls{l}.1` + `.2` at large batch; round 5).  80 channels are ten
-// 16-byte chunks per pixel -- not a power of two, not a multiple of the 32-element K-step -- so conv3x3_patch_kernel (chunk index by shift
-// and mask, XOR swizzle, one tap per K-step) does not take the layer and it ran on the implicit GEMM's generic gather path (880 us per 512
-// frames at level 0, 23 % MFMA busy; the patch kernel runs the 64 -> 80 conv beside it at 750 TFLOP/s).  Here:
-//  * the 18 x 18 x 80-channel patch of a 16 x 16 tile goes into LDS ONCE by LDS-DMA, pixel-major, 160 bytes per pixel, unswizzled (the 16
-//    lanes of a fragment read are 160 bytes apart: a 2-way conflict on four reads per 20 MFMAs; a pitch of 176 would be conflict-free and
-//    would not leave room for two blocks per CU);
+// The patch form with a PIXEL-MAJOR patch, for the detect branches' second convs with the 1x1 behind them (YOLOv8n's `22.cls{l}.1` + `.2`,
+// `22.box{l}.1` + `.2` at launches of 50 000 pixels and more; round 5).  80 channels are ten 16-byte chunks per pixel -- not a power of two,
+// not a multiple of the 32-element K-step -- so conv3x3_patch_kernel (chunk index by shift and mask, XOR swizzle, one tap per K-step) does
+// not take the class branch and it ran on the implicit GEMM's generic gather path (880 us per 512 frames at level 0, 23 % MFMA busy; the
+// patch kernel runs the 64 -> 80 conv beside it at 750 TFLOP/s).  Here:
+//  * the 18 x 18 x Cin patch of a 16 x 16 tile goes into LDS ONCE by LDS-DMA, pixel-major, PITCH chunks per pixel, unswizzled: 80 channels at
+//    160 bytes per pixel (the 16 lanes of a fragment read are 160 bytes apart: a 2-way conflict on four reads per 20 MFMAs; a pitch of 176
+//    would be conflict-free and would not leave room for two blocks per CU), 64 channels at 144 (128 would be an 8-way conflict);
 //  * K in memory order (tap, channel) in 32-element steps FROM k = 0, as the implicit GEMM walks it: step s is the flattened chunks
-//    4 s .. 4 s + 3 = (tap, chunk) (kc / 10, kc % 10) -- a step straddles taps, so a lane's (tap, chunk) depends on its q: 23 per-lane
-//    offsets, worked out once; the last step's chunks 90, 91 meet the zero columns of the padded weights (Kp = 736) and read chunk 0;
-//  * weights through the 3-stage ring of conv3x3_patch_kernel (128 padded rows: two 16-byte chunks per thread and step), the epilogue is
-//    tail_1x1<4, 5>: bit-identical to conv_igemm_dma_kernel<.., TAIL> (child-process test).
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv3x3_c80_patch_tail_kernel(const ConvArgs a, int tiles_x, int tiles_y) {
+//    4 s .. 4 s + 3 = (tap, chunk) (kc / CPP, kc % CPP) -- with ten chunks a step straddles taps, so a lane's (tap, chunk) depends on its q:
+//    per-lane offsets, worked out once; the last step's chunks 90, 91 meet the zero columns of the padded weights (Kp = 736) and read chunk 0;
+//  * weights through the 3-stage ring of conv3x3_patch_kernel (80 channels: 128 padded rows, two 16-byte chunks per thread and step), the
+//    epilogue is tail_1x1; tiles may hang over the map's edge (a 40 x 40 map is 3 x 3 tiles);
+//  * bit-identical to conv_igemm_dma_kernel<.., TAIL> / conv3x3_patch_kernel<.., TAIL> (child-process test at 32 frames).
+// 22.cls0.1 + .2: 883 -> 487 us per 512 frames (860 TFLOP/s), 22.cls1.1 + .2: 250 -> 190; the 64-channel form against conv3x3_patch_kernel's
+// tail form: 513 -> 500 and 191 -> 177 (without a tail it is no faster than that kernel: measured, not kept).
+// CPP: 16-byte chunks per input pixel (Cin / 8); PITCH: chunks a pixel takes in LDS (CPP, or CPP + 1 where CPP chunks would put the 16 lanes
+// of a fragment read on the same banks: 8 chunks = 128 bytes is an 8-way conflict, 9 is none); NT: channel tiles (Cout / 16); TAIL: a.w_tail's 1x1.
+template <int CPP, int PITCH, int NT, bool TAIL>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv3x3_pm_patch_kernel(const ConvArgs a, int tiles_x, int tiles_y) {
     typedef half_t T;
-    constexpr int MT = 4, NT = 5, TH = 16, TW = 16, CPP = 10, PW = TW + 2, PH = TH + 2, NSTAGE = 3;
-    constexpr int NTHR = 256, RP = 64, BN = 80, BNP = 128, B_PER = 2, WSTAGE = BNP * 64, BKE = 32, CH = 8;
-    constexpr int TOTAL = PH * PW * CPP, PATCH_BYTES = (TOTAL + NTHR - 1) / NTHR * NTHR * 16, NSTEPS = (9 * CPP + 3) / 4;
+    constexpr int MT = 4, TH = 16, TW = 16, PW = TW + 2, PH = TH + 2, NSTAGE = 3;
+    constexpr int NTHR = 256, RP = 64, BN = NT * 16, BNP = (BN + RP - 1) / RP * RP, B_PER = BNP / RP, WSTAGE = BNP * 64, BKE = 32, CH = 8;
+    constexpr int TOTAL = PH * PW * PITCH, PATCH_BYTES = (TOTAL + NTHR - 1) / NTHR * NTHR * 16, NSTEPS = (9 * CPP + 3) / 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ring = smem + PATCH_BYTES;
 
@@ -876,10 +883,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
 #pragma unroll 2
     for (int base = 0; base < TOTAL; base += NTHR) {
         const int L = base + t;
-        const int p = L / CPP, j = L - p * CPP;
+        const int p = L / PITCH, j = L - p * PITCH;
         const int py = p / PW, px = p - py * PW;
         const int iy = oy0 + py - 1, ix = ox0 + px - 1;
-        const bool ok = L < TOTAL && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        const bool ok = L < TOTAL && j < CPP && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
         const T* src = ok ? ximg + ((size_t)iy * a.W + ix) * a.x_cs + j * CH : zero;
         asm volatile("" : "+v"(src));
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + (size_t)(base + 64 * wv) * 16), 16, 0, 0);
@@ -911,11 +918,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
         int c = 4 * s2 + q;
         if (c >= 9 * CPP) c = 0;
         const int tap = c / CPP, ch = c - tap * CPP, kh = tap / 3, kw = tap - 3 * kh;
-        koff[s2] = ((kh * PW + kw) * CPP + ch) * 16;
+        koff[s2] = ((kh * PW + kw) * PITCH + ch) * 16;
     }
     int xbase[MT];
 #pragma unroll
-    for (int i = 0; i < MT; ++i) xbase[i] = ((wv * MT + i) * PW + r) * (CPP * 16);          // pixel tile (wave, i) = row 4 wv + i of the tile, pixel r
+    for (int i = 0; i < MT; ++i) xbase[i] = ((wv * MT + i) * PW + r) * (PITCH * 16);          // pixel tile (wave, i) = row 4 wv + i of the tile, pixel r
     int woff[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) woff[j] = PATCH_BYTES + lds_off(perm_row<NT>(j, r), q);
@@ -952,31 +959,45 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
         const int oy = oy0 + wv * MT + i, ox = ox0 + r;
         mrow[i] = (oy < a.Ho && ox < a.Wo) ? (img * a.Ho + oy) * a.Wo + ox : -1;
     }
-    tail_1x1<MT, NT>(a, acc, mrow, lane);
+    if constexpr (TAIL) tail_1x1<MT, NT>(a, acc, mrow, lane);
+    else epilogue_dispatch<T, MT, NT, true>(a, acc, mrow, 0, q);
 }
 
-bool conv_try_c80_patch_tail(const ConvArgs& a, hipStream_t s) {
-    static const bool off = getenv("AICAM_NO_PATCH_C80") != nullptr;
-    if (off || !a.w_tail || a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.Cin != 80 || a.Cout != 80 || a.Kp != 736) return false;
-    if (a.k_order != 0 || a.xs || a.x2 || a.n_dev || a.res_mode != 0 || a.out_f32 || a.act != 1 || a.cout_pad < 128) return false;
-    if (a.Ho != a.H || a.Wo != a.W || a.M < 50000 || (a.x_cs | a.x_coff) % 8) return false;      // (below: a few tiles, the wide-step kernel or v2)
-    {   // whole 16 x 16 tiles, or at most half as many pixels again hanging over the edge (40 x 40: 1.44; 20 x 20 would be 2.56)
-        const long cover = (long)ceil_div(a.Wo, 16) * 16 * ceil_div(a.Ho, 16) * 16;
-        if (2 * cover > 3 * (long)a.Wo * a.Ho) return false;
-    }
-    constexpr size_t lds = (size_t)((18 * 18 * 10 + 255) / 256 * 256) * 16 + (size_t)3 * 128 * 64;
+template <int CPP, int PITCH, int NT, bool TAIL>
+static bool launch_pm_patch(const ConvArgs& a, hipStream_t s) {
+    constexpr int BNP = (NT * 16 + 63) / 64 * 64;
+    constexpr size_t lds = (size_t)((18 * 18 * PITCH + 255) / 256 * 256) * 16 + (size_t)3 * BNP * 64;
     static_assert(2 * lds <= 160 * 1024, "two blocks per CU");
+    auto kfn = conv3x3_pm_patch_kernel<CPP, PITCH, NT, TAIL>;
     static bool attr = false;
     if (!attr) {
-        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c80_patch_tail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr = true;
     }
     const int tiles_x = ceil_div(a.Wo, 16), tiles_y = ceil_div(a.Ho, 16), n_img = a.M / (a.Ho * a.Wo);
-    hipLaunchKernelGGL(conv3x3_c80_patch_tail_kernel, dim3(n_img * tiles_x * tiles_y), dim3(256), lds, s, a, tiles_x, tiles_y);
+    hipLaunchKernelGGL(kfn, dim3(n_img * tiles_x * tiles_y), dim3(256), lds, s, a, tiles_x, tiles_y);
     KCHECK();
     return true;
 }
 
+// shapes both forms share: 3x3 / 1 / 1 on whole maps, fp16, memory K order, launches of 50 000 pixels and more (below: a few tiles, the
+// wide-step kernel or v2), 16 x 16 tiles that cover the map with at most half as many pixels again hanging over the edge (40 x 40: 1.44)
+static bool pm_patch_shape(const ConvArgs& a) {
+    if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.k_order != 0 || a.xs || a.x2 || a.n_dev || a.out_f32 || a.bias_init) return false;
+    if (a.Ho != a.H || a.Wo != a.W || a.M < 50000 || (a.x_cs | a.x_coff | a.y_cs | a.y_coff | a.r_cs | a.r_coff) % 8) return false;
+    const long cover = (long)ceil_div(a.Wo, 16) * 16 * ceil_div(a.Ho, 16) * 16;
+    return 2 * cover <= 3 * (long)a.Wo * a.Ho;
+}
+
+// lead + 1x1 tail: 80 -> 80 (the class branches), 64 -> 64 (the box branches)
+bool conv_try_pm_patch_tail(const ConvArgs& a, hipStream_t s) {
+    static const bool off = getenv("AICAM_NO_PATCH_C80") != nullptr;
+    if (off || !a.w_tail || !pm_patch_shape(a) || a.res_mode != 0 || a.act != 1) return false;
+    if (a.Cin == 80 && a.Cout == 80 && a.Kp == 736 && a.cout_pad >= 128) return launch_pm_patch<10, 10, 5, true>(a, s);
+    static const bool c64 = getenv("AICAM_NO_PM64") == nullptr;
+    if (c64 && a.Cin == 64 && a.Cout == 64 && a.Kp == 576 && a.cout_pad >= 64) return launch_pm_patch<8, 9, 4, true>(a, s);
+    return false;
+}
 // the Cout = 64 patch kernel with a 1x1 tail (same eligibility as try_patch)
 bool conv_try_patch_tail(const ConvArgs& a, hipStream_t s) {
     static const bool off = getenv("AICAM_NO_PATCH") != nullptr;

@@ -43,7 +43,7 @@ __global__ void decode_kernel(const DetArgs a) {
             float sum = 0.f, ex = 0.f;
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
-                const float e = expf(v[k] - mx);
+                const float e = a.fast_exp ? __builtin_amdgcn_exp2f((v[k] - mx) * 1.4426950408889634f) : expf(v[k] - mx);
                 sum += e;
                 ex += e * (float)k;
             }
@@ -56,7 +56,7 @@ __global__ void decode_kernel(const DetArgs a) {
             for (int k = 1; k < a.reg_max; ++k) mx = fmaxf(mx, v[k]);
             float sum = 0.f, ex = 0.f;
             for (int k = 0; k < a.reg_max; ++k) {
-                const float e = expf(v[k] - mx);
+                const float e = a.fast_exp ? __builtin_amdgcn_exp2f((v[k] - mx) * 1.4426950408889634f) : expf(v[k] - mx);
                 sum += e;
                 ex += e * (float)k;
             }

@@ -594,7 +594,7 @@ def main():
                                 f"{now_digest} (re-run tools/refresh_profiles.sh)")
             except Exception:
                 pass
-            roof = {"kernel": "conv class = conv_igemm_dma / conv_igemm_pp / conv3x3_pp_patch / conv3x3_sp_patch / conv3x3s2_sp_patch / conv3x3_patch / conv3x3_c16 / conv1x1_stream / conv3x3_c32s2_tail / conv3x3_c80_patch_tail / conv3x3_c64_resident / conv3x3_c64_block / c2f16_fused kernels (MFMA implicit GEMM: every conv of YOLOv8 + ReID except the two fused 3-channel stems)",
+            roof = {"kernel": "conv class = conv_igemm_dma / conv_igemm_pp / conv3x3_pp_patch / conv3x3_sp_patch / conv3x3s2_sp_patch / conv3x3_patch / conv3x3_c16 / conv1x1_stream / conv3x3_c32s2_tail / conv3x3_pm_patch / conv3x3_c64_resident / conv3x3_c64_block / c2f16_fused kernels (MFMA implicit GEMM: every conv of YOLOv8 + ReID except the two fused 3-channel stems)",
                     "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                     "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": tsrc, "traffic_algorithmic_same_basis": talg,
                     "denominator": ("union of the conv class's bracketed intervals over both streams (paired HIP events per stream, device clock)" if have_union

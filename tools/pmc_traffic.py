@@ -4,7 +4,7 @@ MI355X_MICROARCH.md prescribes) -> profiles/pmc_traffic.json (read by bench.py's
   python tools/pmc_traffic.py <fetch_dir> <write_dir> "<method note>" [tag]   (tag: also profiles/<tag>_pmc_traffic.json) """
 import csv, glob, json, os, sys
 
-CONV = ("conv_igemm_dma_kernel", "conv3x3_patch_kernel", "conv_igemm_pp_kernel", "conv3x3_pp_patch_kernel", "conv3x3_sp_patch_kernel", "conv3x3s2_sp_patch_kernel", "conv_igemm_kernel", "conv3x3_c16_kernel", "conv1x1_stream_kernel", "conv3x3_c32s2_tail_kernel", "conv3x3_c80_patch_tail_kernel", "conv3x3_c64_resident_kernel", "conv3x3_c64_block_kernel", "c2f16_fused_kernel")
+CONV = ("conv_igemm_dma_kernel", "conv3x3_patch_kernel", "conv_igemm_pp_kernel", "conv3x3_pp_patch_kernel", "conv3x3_sp_patch_kernel", "conv3x3s2_sp_patch_kernel", "conv_igemm_kernel", "conv3x3_c16_kernel", "conv1x1_stream_kernel", "conv3x3_c32s2_tail_kernel", "conv3x3_pm_patch_kernel", "conv3x3_c64_resident_kernel", "conv3x3_c64_block_kernel", "c2f16_fused_kernel")
 
 
 def per_launch(d, counter):
@@ -20,7 +20,7 @@ def per_launch(d, counter):
 fetch_kib, n1 = per_launch(sys.argv[1], "FETCH_SIZE")
 write_kib, n2 = per_launch(sys.argv[2], "WRITE_SIZE")
 out = {
-    "kernel": "conv class of bench.py: conv_igemm_dma / conv_igemm_pp / conv3x3_pp_patch / conv3x3_sp_patch / conv3x3s2_sp_patch / conv3x3_patch / conv3x3_c16 / conv1x1_stream / conv3x3_c32s2_tail / conv3x3_c80_patch_tail / conv3x3_c64_resident / conv3x3_c64_block / c2f16_fused kernels",
+    "kernel": "conv class of bench.py: conv_igemm_dma / conv_igemm_pp / conv3x3_pp_patch / conv3x3_sp_patch / conv3x3s2_sp_patch / conv3x3_patch / conv3x3_c16 / conv1x1_stream / conv3x3_c32s2_tail / conv3x3_pm_patch / conv3x3_c64_resident / conv3x3_c64_block / c2f16_fused kernels",
     "launches_sampled": n1,
     "fetch_bytes_per_launch_raw": fetch_kib * 1024,
     "fetch_bytes_per_launch_corrected_x2": fetch_kib * 2048,

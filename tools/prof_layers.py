@@ -34,7 +34,7 @@ def main(d, frames=16, crops=480, top=30, fused_stem=1, fused_yolo_stem=1, fused
     print(f"{'kernel':42s} {'calls':>7s} {'total ms':>9s} {'%':>6s} {'avg us':>8s}")
     for n, (c, us) in sorted(tot.items(), key=lambda kv: -kv[1][1])[:24]:
         print(f"{n[:42]:42s} {c:7d} {us / 1e3:9.2f} {100 * us / all_us:6.1f} {us / c:8.1f}")
-    conv = [r for r in rows if any(k in r["Kernel_Name"] for k in ("conv_igemm", "conv3x3_patch", "conv3x3_pp_patch", "conv3x3_sp_patch", "conv3x3s2_sp_patch", "conv3x3_c16", "conv1x1_stream", "conv3x3_c32s2_tail", "conv3x3_c80_patch_tail", "conv3x3_c64_resident", "conv3x3_c64_block", "c2f16_fused"))]
+    conv = [r for r in rows if any(k in r["Kernel_Name"] for k in ("conv_igemm", "conv3x3_patch", "conv3x3_pp_patch", "conv3x3_sp_patch", "conv3x3s2_sp_patch", "conv3x3_c16", "conv1x1_stream", "conv3x3_c32s2_tail", "conv3x3_pm_patch", "conv3x3_c64_resident", "conv3x3_c64_block", "c2f16_fused"))]
     # the conv class over the steady-state middle of the trace: summed kernel durations against the UNION of their intervals (with the class
     # on two streams -- bench.py's default since round 4 -- the sum counts every overlapped microsecond twice; bench.py's roofline uses
     # the union, from paired HIP events per stream), and the class's rate over each, from the full launch groups that START in the window
@@ -125,7 +125,7 @@ def main(d, frames=16, crops=480, top=30, fused_stem=1, fused_yolo_stem=1, fused
     per = len(layers)
     # a launch group starts at its (fused) YOLO stem; groups of other sizes (tapered tail of a call: fewer frames, and below
     # the fused-block threshold two more launches) are dropped: keep the groups with `per` conv launches and the modal grid
-    is_conv = lambda r: any(k in r["Kernel_Name"] for k in ("conv_igemm", "conv3x3_patch", "conv3x3_pp_patch", "conv3x3_sp_patch", "conv3x3s2_sp_patch", "conv3x3_c16", "conv1x1_stream", "conv3x3_c32s2_tail", "conv3x3_c80_patch_tail", "conv3x3_c64_resident", "conv3x3_c64_block", "c2f16_fused"))
+    is_conv = lambda r: any(k in r["Kernel_Name"] for k in ("conv_igemm", "conv3x3_patch", "conv3x3_pp_patch", "conv3x3_sp_patch", "conv3x3s2_sp_patch", "conv3x3_c16", "conv1x1_stream", "conv3x3_c32s2_tail", "conv3x3_pm_patch", "conv3x3_c64_resident", "conv3x3_c64_block", "c2f16_fused"))
     glist, cur = [], None
     for r in rows:
         if "yolo_stem_fused" in r["Kernel_Name"] or "letterbox" in r["Kernel_Name"]:
