@@ -735,6 +735,7 @@ int conv_pp_patch_shape(int dtype, const ConvArgs& a);                 // != 0 (
 bool conv_try_pp(int dtype, const ConvArgs& a, hipStream_t s);         // kernels_conv_pp.hip: v4 ping-pong im2col (long K, Cout 128 / 256k)
 bool conv_try_patch(int dtype, const ConvArgs& a, hipStream_t s);      // kernels_conv_direct.hip: 4-wave patch kernel (Cout 64 / 32)
 bool conv_try_patch_tail(const ConvArgs& a, hipStream_t s);            // same kernel, Cout 64, with a.w_tail's 1x1 in its epilogue (fp16)
+bool conv_try_pm_patch(const ConvArgs& a, hipStream_t s);              // the same form without a tail: 64 -> 64 on 40-row maps, in 40 x 8 strips
 bool conv_try_pm_patch_tail(const ConvArgs& a, hipStream_t s);         // kernels_conv_direct.hip: 3x3 / 1, 80 -> 80 or 64 -> 64 channels with a.w_tail's 1x1 in its epilogue, pixel-major patch (fp16)
 bool conv_try_c16(const ConvArgs& a, hipStream_t s);                   // kernels_conv_direct.hip: 16 input channels, fp16
 bool conv_try_1x1_stream(const ConvArgs& a, hipStream_t s);             // kernels_conv_direct.hip: 1x1, <= 128 -> 64 channels, no LDS (fp16, large batch)

@@ -615,6 +615,7 @@ static void launch_conv_t(const ConvArgs& a_in, hipStream_t s) {
         return;
     } else {
     if (conv_impl() == 2 && conv_try_pp_patch(DT, a, s)) return;
+    if (conv_impl() == 2 && !a.x2 && DT == AIC_F16 && conv_try_pm_patch(a, s)) return;
     if (conv_impl() == 2 && !a.x2 && conv_try_patch(DT, a, s)) return;        // (a second source: the ping-pong patch kernel above or the LDS-DMA implicit GEMMs below)
     if (c % 128 == 0 || c > 160) {
         static const bool t256 = getenv("AICAM_NO_T256") == nullptr;   // +12% on ReID layer3/4 over 256x128 (profiles/)

@@ -860,10 +860,13 @@ static bool try_patch(const ConvArgs& a, hipStream_t s) {
 // tail form: 513 -> 500 and 191 -> 177 (without a tail it is no faster than that kernel: measured, not kept).
 // CPP: 16-byte chunks per input pixel (Cin / 8); PITCH: chunks a pixel takes in LDS (CPP, or CPP + 1 where CPP chunks would put the 16 lanes
 // of a fragment read on the same banks: 8 chunks = 128 bytes is an 8-way conflict, 9 is none); NT: channel tiles (Cout / 16); TAIL: a.w_tail's 1x1.
-template <int CPP, int PITCH, int NT, bool TAIL>
+// TH x TW: the block's output tile, 64 MT pixels, walked row-major in 16-pixel MFMA tiles (TW = 16: a tile row each; TW = 8: two rows of eight --
+// a 40 x 40 map is five 40 x 8 strips exactly, where 16 x 16 tiles cover 1.44 maps and conv3x3_patch_kernel's 8 x 32 tiles 1.6).
+template <int CPP, int PITCH, int NT, bool TAIL, int TH = 16, int TW = 16, int MT = 4>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv3x3_pm_patch_kernel(const ConvArgs a, int tiles_x, int tiles_y) {
     typedef half_t T;
-    constexpr int MT = 4, TH = 16, TW = 16, PW = TW + 2, PH = TH + 2, NSTAGE = 3;
+    constexpr int PW = TW + 2, PH = TH + 2, NSTAGE = 3;
+    static_assert(TH * TW == 64 * MT && (TW == 16 || TW == 8), "tile geometry");
     constexpr int NTHR = 256, RP = 64, BN = NT * 16, BNP = (BN + RP - 1) / RP * RP, B_PER = BNP / RP, WSTAGE = BNP * 64, BKE = 32, CH = 8;
     constexpr int TOTAL = PH * PW * PITCH, PATCH_BYTES = (TOTAL + NTHR - 1) / NTHR * NTHR * 16, NSTEPS = (9 * CPP + 3) / 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -922,7 +925,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
     }
     int xbase[MT];
 #pragma unroll
-    for (int i = 0; i < MT; ++i) xbase[i] = ((wv * MT + i) * PW + r) * (PITCH * 16);          // pixel tile (wave, i) = row 4 wv + i of the tile, pixel r
+    for (int i = 0; i < MT; ++i) {             // pixel tile (wave, i): pixels 16 (wv MT + i) .. + 15 of the tile in row-major order
+        const int pt = (wv * MT + i) * 16 + r;
+        xbase[i] = ((pt / TW) * PW + pt % TW) * (PITCH * 16);
+    }
     int woff[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) woff[j] = PATCH_BYTES + lds_off(perm_row<NT>(j, r), q);
@@ -956,35 +962,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
     int mrow[MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) {             // (tiles may hang over the map's edge -- a 40 x 40 map is 3 x 3 of them: those pixels are computed on zeros and not stored)
-        const int oy = oy0 + wv * MT + i, ox = ox0 + r;
+        const int pt = (wv * MT + i) * 16 + r;
+        const int oy = oy0 + pt / TW, ox = ox0 + pt % TW;
         mrow[i] = (oy < a.Ho && ox < a.Wo) ? (img * a.Ho + oy) * a.Wo + ox : -1;
     }
     if constexpr (TAIL) tail_1x1<MT, NT>(a, acc, mrow, lane);
     else epilogue_dispatch<T, MT, NT, true>(a, acc, mrow, 0, q);
 }
 
-template <int CPP, int PITCH, int NT, bool TAIL>
+template <int CPP, int PITCH, int NT, bool TAIL, int TH = 16, int TW = 16, int MT = 4>
 static bool launch_pm_patch(const ConvArgs& a, hipStream_t s) {
     constexpr int BNP = (NT * 16 + 63) / 64 * 64;
-    constexpr size_t lds = (size_t)((18 * 18 * PITCH + 255) / 256 * 256) * 16 + (size_t)3 * BNP * 64;
+    constexpr size_t lds = (size_t)(((TH + 2) * (TW + 2) * PITCH + 255) / 256 * 256) * 16 + (size_t)3 * BNP * 64;
     static_assert(2 * lds <= 160 * 1024, "two blocks per CU");
-    auto kfn = conv3x3_pm_patch_kernel<CPP, PITCH, NT, TAIL>;
+    auto kfn = conv3x3_pm_patch_kernel<CPP, PITCH, NT, TAIL, TH, TW, MT>;
     static bool attr = false;
     if (!attr) {
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr = true;
     }
-    const int tiles_x = ceil_div(a.Wo, 16), tiles_y = ceil_div(a.Ho, 16), n_img = a.M / (a.Ho * a.Wo);
+    const int tiles_x = ceil_div(a.Wo, TW), tiles_y = ceil_div(a.Ho, TH), n_img = a.M / (a.Ho * a.Wo);
     hipLaunchKernelGGL(kfn, dim3(n_img * tiles_x * tiles_y), dim3(256), lds, s, a, tiles_x, tiles_y);
     KCHECK();
     return true;
 }
 
-// shapes both forms share: 3x3 / 1 / 1 on whole maps, fp16, memory K order, launches of 50 000 pixels and more (below: a few tiles, the
-// wide-step kernel or v2), 16 x 16 tiles that cover the map with at most half as many pixels again hanging over the edge (40 x 40: 1.44)
+// shapes every form shares: 3x3 / 1 / 1 on whole maps, fp16, memory K order, launches of 50 000 pixels and more (below: a few tiles, the
+// wide-step kernel or v2)
 static bool pm_patch_shape(const ConvArgs& a) {
     if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.k_order != 0 || a.xs || a.x2 || a.n_dev || a.out_f32 || a.bias_init) return false;
-    if (a.Ho != a.H || a.Wo != a.W || a.M < 50000 || (a.x_cs | a.x_coff | a.y_cs | a.y_coff | a.r_cs | a.r_coff) % 8) return false;
+    return a.Ho == a.H && a.Wo == a.W && a.M >= 50000 && (a.x_cs | a.x_coff | a.y_cs | a.y_coff | a.r_cs | a.r_coff) % 8 == 0;
+}
+// 16 x 16 tiles cover the map with at most half as many pixels again hanging over the edge (40 x 40: 1.44; 20 x 20 would be 2.56)
+static bool pm_cover16(const ConvArgs& a) {
     const long cover = (long)ceil_div(a.Wo, 16) * 16 * ceil_div(a.Ho, 16) * 16;
     return 2 * cover <= 3 * (long)a.Wo * a.Ho;
 }
@@ -993,11 +1003,22 @@ static bool pm_patch_shape(const ConvArgs& a) {
 bool conv_try_pm_patch_tail(const ConvArgs& a, hipStream_t s) {
     static const bool off = getenv("AICAM_NO_PATCH_C80") != nullptr;
     if (off || !a.w_tail || !pm_patch_shape(a) || a.res_mode != 0 || a.act != 1) return false;
-    if (a.Cin == 80 && a.Cout == 80 && a.Kp == 736 && a.cout_pad >= 128) return launch_pm_patch<10, 10, 5, true>(a, s);
-    static const bool c64 = getenv("AICAM_NO_PM64") == nullptr;
-    if (c64 && a.Cin == 64 && a.Cout == 64 && a.Kp == 576 && a.cout_pad >= 64) return launch_pm_patch<8, 9, 4, true>(a, s);
+    if (a.Cin == 80 && a.Cout == 80 && a.Kp == 736 && a.cout_pad >= 128 && pm_cover16(a)) return launch_pm_patch<10, 10, 5, true>(a, s);
+    if (a.Cin == 64 && a.Cout == 64 && a.Kp == 576 && a.cout_pad >= 64) {
+        if (a.Ho == 40 && a.Wo % 8 == 0) return launch_pm_patch<8, 9, 4, true, 40, 8, 5>(a, s);
+        if (pm_cover16(a)) return launch_pm_patch<8, 9, 4, true>(a, s);
+    }
     return false;
 }
+// without a tail: 64 -> 64 on 40-row maps in 40 x 8 strips (YOLOv8n's P4 bottlenecks: eight layers on conv3x3_patch_kernel's 8 x 32 tiles,
+// which cover 1.6 maps).  On maps its 16 x 16 tiles cover exactly this form is no faster than that kernel (measured: 22.box0.0 348 against 354 us).
+bool conv_try_pm_patch(const ConvArgs& a, hipStream_t s) {
+    static const bool off = getenv("AICAM_NO_PATCH_C80") != nullptr || getenv("AICAM_NO_PM_STRIPS") != nullptr;
+    if (off || a.w_tail || !pm_patch_shape(a) || a.act != 1 || (a.res_mode != 0 && a.res_mode != 2)) return false;
+    if (a.Cin == 64 && a.Cout == 64 && a.Kp == 576 && a.cout_pad >= 64 && a.Ho == 40 && a.Wo % 8 == 0) return launch_pm_patch<8, 9, 4, false, 40, 8, 5>(a, s);
+    return false;
+}
+
 // the Cout = 64 patch kernel with a 1x1 tail (same eligibility as try_patch)
 bool conv_try_patch_tail(const ConvArgs& a, hipStream_t s) {
     static const bool off = getenv("AICAM_NO_PATCH") != nullptr;
