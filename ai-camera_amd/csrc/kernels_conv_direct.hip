@@ -863,7 +863,7 @@ static bool try_patch(const ConvArgs& a, hipStream_t s) {
 // TH x TW: the block's output tile, 64 MT pixels, walked row-major in 16-pixel MFMA tiles (TW = 16: a tile row each; TW = 8: two rows of eight --
 // a 40 x 40 map is five 40 x 8 strips exactly, where 16 x 16 tiles cover 1.44 maps and conv3x3_patch_kernel's 8 x 32 tiles 1.6).
 template <int CPP, int PITCH, int NT, bool TAIL, int TH = 16, int TW = 16, int MT = 4>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv3x3_pm_patch_kernel(const ConvArgs a, int tiles_x, int tiles_y) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT >= 9 ? 1 : 2))) void conv3x3_pm_patch_kernel(const ConvArgs a, int tiles_x, int tiles_y) {
     typedef half_t T;
     constexpr int PW = TW + 2, PH = TH + 2, NSTAGE = 3;
     static_assert(TH * TW == 64 * MT && (TW == 16 || TW == 8), "tile geometry");
@@ -974,7 +974,7 @@ template <int CPP, int PITCH, int NT, bool TAIL, int TH = 16, int TW = 16, int M
 static bool launch_pm_patch(const ConvArgs& a, hipStream_t s) {
     constexpr int BNP = (NT * 16 + 63) / 64 * 64;
     constexpr size_t lds = (size_t)(((TH + 2) * (TW + 2) * PITCH + 255) / 256 * 256) * 16 + (size_t)3 * BNP * 64;
-    static_assert(2 * lds <= 160 * 1024, "two blocks per CU");
+    static_assert((NT >= 9 ? 1 : 2) * lds <= 160 * 1024, "two blocks per CU (the 144-channel form: one, its patch alone is 112 KB)");
     auto kfn = conv3x3_pm_patch_kernel<CPP, PITCH, NT, TAIL, TH, TW, MT>;
     static bool attr = false;
     if (!attr) {
@@ -1016,6 +1016,15 @@ bool conv_try_pm_patch(const ConvArgs& a, hipStream_t s) {
     static const bool off = getenv("AICAM_NO_PATCH_C80") != nullptr || getenv("AICAM_NO_PM_STRIPS") != nullptr;
     if (off || a.w_tail || !pm_patch_shape(a) || a.act != 1 || (a.res_mode != 0 && a.res_mode != 2)) return false;
     if (a.Cin == 64 && a.Cout == 64 && a.Kp == 576 && a.cout_pad >= 64 && a.Ho == 40 && a.Wo % 8 == 0) return launch_pm_patch<8, 9, 4, false, 40, 8, 5>(a, s);
+    // (32 -> 32 on 80 x 80 maps -- YOLOv8n's P3 bottlenecks, which conv3x3_patch_kernel's 8 x 32 tiles cover 1.2 times -- as
+    //  launch_pm_patch<4, 5, 2, false> on 16 x 16 tiles that cover the map exactly: built, bit-identical, measured 843 against 830 us for the
+    //  four layers of 4.c2f.  They do not wait for their tiles: they read and write 64-byte slices of a 256-byte-pitch concat buffer.  Not kept.)
+    // 128 -> 144 on 40-row maps: the merged first convs of YOLOv8n's 40 x 40 detect level (22.box1.0 + 22.cls1.0), which the implicit GEMM runs on a
+    // 256 x 144 tile with 36 accumulator tiles per wave, one wave per SIMD.  Sixteen chunks per pixel at a pitch of 17 (272 bytes: the 16 lanes of a
+    // fragment read sit four banks apart), nine channel tiles (the odd last one keeps the identity map), one block per CU.  AICAM_NO_PM144=1: off
+    static const bool no144 = getenv("AICAM_NO_PM144") != nullptr;
+    if (!no144 && a.res_mode == 0 && a.Cin == 128 && a.Cout == 144 && a.Kp == 1152 && a.cout_pad >= 144 && a.Ho == 40 && a.Wo % 8 == 0)
+        return launch_pm_patch<16, 17, 9, false, 40, 8, 5>(a, s);
     return false;
 }
 

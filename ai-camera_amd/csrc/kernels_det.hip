@@ -184,7 +184,9 @@ __global__ __launch_bounds__(NMS_THREADS) void select_sort_nms_kernel(const DetA
         }
         bool alive = have;
         int seen = 0;                           // this candidate has been tested against kbox[0 .. seen)
-        for (int w = 0; w < NMS_THREADS / 64 && nk < a.max_det; ++w) {
+        const int wtiles = min(NMS_THREADS / 64, (n - c0 + 63) / 64);   // wave tiles that hold candidates (a trained detector: ~30 candidates, one tile;
+                                                                        // the empty tiles were fifteen block barriers per frame)
+        for (int w = 0; w < wtiles && nk < a.max_det; ++w) {
             if (wv >= w) {                      // (wave-uniform) earlier tiles of this chunk are settled
                 for (int k = seen; k < nk && alive; ++k)
                     if (klab[k] == lab && iou_xyxy(kbox[k], bx) > a.iou_thr) alive = false;
