@@ -278,6 +278,9 @@ static bool try_c32s2_tail(const ConvArgs& a, hipStream_t s) {
 // barrier: a wave keeps the whole weight matrix as MFMA A fragments (KS x 4 tiles) and walks 16-pixel tiles; a lane fetches ITS 16 bytes of
 // every K-step of a tile straight from memory (16 pixels x 64 contiguous bytes per instruction), the next tile's under this tile's MFMAs and
 // epilogue.  K in memory order from zero, the shared epilogue: the bits of the implicit GEMM.
+// (Measured late in round 5: two tiles ahead instead of one -- 8 KB in flight per wave -- and a grid of exactly the resident blocks (768 at 152
+//  registers; the 1 024 launched are 1.33 rounds): 4.c2f.cv2 347 / 335 us against 339, 15.c2f.cv2 290 / 267 against 252.  It is not
+//  bytes in flight that this kernel waits for.  Not kept.)
 template <int KS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void conv1x1_stream_kernel(const ConvArgs a, int n_tiles) {
     const int t = threadIdx.x, lane = t & 63, r = lane & 15, q = lane >> 4;
