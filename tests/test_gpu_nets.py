@@ -403,7 +403,8 @@ def test_stride2_direct_kernel_with_tail_bit_exact(gpu, engines, tmp_path):
     process); `4.c2f.cv2` and `15.c2f.cv2` likewise: conv1x1_stream_kernel (weights in registers, pixels straight from memory, no LDS)
     against the implicit GEMM (AICAM_NO_1X1_STREAM=1); `22.cls0.0` on the patch kernel's 80-channel form and `22.cls0.1` + `.2` on
     conv3x3_c80_patch_tail_kernel (the patch form for ten chunks per pixel, K-steps that straddle taps) against the implicit GEMM's
-    tiles (AICAM_NO_PATCH_C80=1).  Same products in the same order, same roundings: the raw head of 32 frames (every one of these kernels
+    tiles (AICAM_NO_PATCH_C80=1: the same switch takes every conv3x3_pm_patch_kernel form off -- the box / class tails, the 40 x 8 strips of the
+    40 x 40 level's bottleneck convs and the merged 128 -> 144 head conv `22.box1.0` + `22.cls1.0`).  Same products in the same order, same roundings: the raw head of 32 frames (every one of these kernels
     engages at that size) must be IDENTICAL, and it must be a real head."""
     import subprocess
     import sys
