@@ -404,7 +404,8 @@ def test_stride2_direct_kernel_with_tail_bit_exact(gpu, engines, tmp_path):
     against the implicit GEMM (AICAM_NO_1X1_STREAM=1); `22.cls0.0` on the patch kernel's 80-channel form and `22.cls0.1` + `.2` on
     conv3x3_c80_patch_tail_kernel (the patch form for ten chunks per pixel, K-steps that straddle taps) against the implicit GEMM's
     tiles (AICAM_NO_PATCH_C80=1: the same switch takes every conv3x3_pm_patch_kernel form off -- the box / class tails, the 40 x 8 strips of the
-    40 x 40 level's bottleneck convs and the merged 128 -> 144 head conv `22.box1.0` + `22.cls1.0`).  Same products in the same order, same roundings: the raw head of 32 frames (every one of these kernels
+    40 x 40 level's bottleneck convs and the merged 128 -> 144 head conv `22.box1.0` + `22.cls1.0`); the 80 x 80 level's 32 -> 32 bottleneck convs on
+    conv3x3_patch_kernel against the implicit GEMM (AICAM_NO_PATCH_C32=1).  Same products in the same order, same roundings: the raw head of 32 frames (every one of these kernels
     engages at that size) must be IDENTICAL, and it must be a real head."""
     import subprocess
     import sys
@@ -419,7 +420,7 @@ eng.close()
 np.savez(sys.argv[1], dfl=dfl, cls=cls)
 """ % (ROOT, engines[0])
     files = []
-    for name, env in (("direct", {}), ("igemm", {"AICAM_NO_C32S2": "1", "AICAM_NO_1X1_STREAM": "1", "AICAM_NO_PATCH_C80": "1"})):
+    for name, env in (("direct", {}), ("igemm", {"AICAM_NO_C32S2": "1", "AICAM_NO_1X1_STREAM": "1", "AICAM_NO_PATCH_C80": "1", "AICAM_NO_PATCH_C32": "1"})):
         f = str(tmp_path / (name + ".npz"))
         r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
         print(r.stdout[-300:], r.stderr[-300:])
